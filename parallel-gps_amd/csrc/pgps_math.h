@@ -1,0 +1,599 @@
+// pgps_math.h -- small-matrix algebra of the parallel Kalman filter / RTS smoother scan.
+//
+// Everything here is a register-resident, compile-time-D, fully unrolled device function:
+// one lane owns whole d x d operands (d <= 6 or so).  No MFMA -- there is no dense
+// contraction at these sizes; the kernels that use these functions are bound by HBM/L2
+// traffic.  The header also compiles as plain C++ (g++) so the algebra can be
+// checked on the CPU against the numpy oracle (tests/cpu_math/).
+//
+// Reference semantics (paths relative to /root/reference):
+//   filtering elements   pssgp/kalman/parallel.py:13-72,83-97
+//   filtering operator   pssgp/kalman/parallel.py:100-118
+//   log-likelihood       pssgp/kalman/parallel.py:135-151
+//   smoothing elements   pssgp/kalman/parallel.py:155-173
+//   smoothing operator   pssgp/kalman/parallel.py:176-184
+//
+// Symmetric matrices (C, J, L, P) are stored as their upper triangle, row-major packed.
+#pragma once
+
+#if defined(__HIPCC__)
+#define PGPS_HD __host__ __device__ __forceinline__
+#else
+#define PGPS_HD inline
+#endif
+
+#include <cmath>
+
+namespace pgps {
+
+template <int D>
+struct Dim {
+    static constexpr int MAT = D * D;
+    static constexpr int SYM = D * (D + 1) / 2;
+    static constexpr int NFILT = MAT + D + SYM + SYM + D;   // A, b, C, J, eta
+    static constexpr int NSMTH = MAT + D + SYM;             // E, g, L
+    static constexpr int NMP = D + SYM;                     // m, P
+};
+
+// packed index of (i, j) in an upper-triangular row-major store
+template <int D>
+PGPS_HD constexpr int symi(int i, int j) {
+    return i <= j ? (i * D - (i * (i - 1)) / 2 + (j - i)) : (j * D - (j * (j - 1)) / 2 + (i - j));
+}
+
+template <typename T, int D>
+struct FiltElem {           // x_out | x_in ~ N(A x_in + b, C);  p(y | x_in) ~ N_info(eta, J)
+    T A[D * D];
+    T b[D];
+    T C[Dim<D>::SYM];
+    T J[Dim<D>::SYM];
+    T eta[D];
+};
+
+template <typename T, int D>
+struct SmthElem {           // x_k | x_next ~ N(E x_next + g, L)
+    T E[D * D];
+    T g[D];
+    T L[Dim<D>::SYM];
+};
+
+template <typename T, int D>
+struct MeanCov {
+    T m[D];
+    T P[Dim<D>::SYM];
+};
+
+template <typename T>
+PGPS_HD bool is_nan(T x) { return x != x; }
+
+// ------------------------------------------------------------------------------------
+// basic products
+// ------------------------------------------------------------------------------------
+// out = X * Y  (general D x D)
+template <typename T, int D>
+PGPS_HD void mat_mul(const T* X, const T* Y, T* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += X[i * D + k] * Y[k * D + j];
+            out[i * D + j] = acc;
+        }
+}
+
+// out = X * S  with S symmetric-packed
+template <typename T, int D>
+PGPS_HD void mat_mul_sym(const T* X, const T* S, T* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += X[i * D + k] * S[symi<D>(k, j)];
+            out[i * D + j] = acc;
+        }
+}
+
+// out = S * X  with S symmetric-packed
+template <typename T, int D>
+PGPS_HD void sym_mul_mat(const T* S, const T* X, T* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += S[symi<D>(i, k)] * X[k * D + j];
+            out[i * D + j] = acc;
+        }
+}
+
+// out(sym) = sym_part(X * Y^T) + add(sym)      (add may be nullptr)
+template <typename T, int D>
+PGPS_HD void mat_mul_t_sym(const T* X, const T* Y, const T* add, T* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            T acc = T(0);
+            if (i == j) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += X[i * D + k] * Y[i * D + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+                    acc += X[i * D + k] * Y[j * D + k] + X[j * D + k] * Y[i * D + k];
+                acc *= T(0.5);
+            }
+            out[symi<D>(i, j)] = add ? acc + add[symi<D>(i, j)] : acc;
+        }
+}
+
+// out(sym) = sym_part(X^T * Y) + add(sym)
+template <typename T, int D>
+PGPS_HD void mat_t_mul_sym(const T* X, const T* Y, const T* add, T* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            T acc = T(0);
+            if (i == j) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += X[k * D + i] * Y[k * D + i];
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+                    acc += X[k * D + i] * Y[k * D + j] + X[k * D + j] * Y[k * D + i];
+                acc *= T(0.5);
+            }
+            out[symi<D>(i, j)] = add ? acc + add[symi<D>(i, j)] : acc;
+        }
+}
+
+template <typename T, int D>
+PGPS_HD void mat_vec(const T* X, const T* v, T* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc += X[i * D + k] * v[k];
+        out[i] = acc;
+    }
+}
+
+template <typename T, int D>
+PGPS_HD void mat_t_vec(const T* X, const T* v, T* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc += X[k * D + i] * v[k];
+        out[i] = acc;
+    }
+}
+
+template <typename T, int D>
+PGPS_HD void sym_vec(const T* S, const T* v, T* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc += S[symi<D>(i, k)] * v[k];
+        out[i] = acc;
+    }
+}
+
+// out(sym) = F * P(sym) * F^T + Q(sym);  FP (general) is also returned (= F P)
+template <typename T, int D>
+PGPS_HD void predict_cov(const T* F, const T* P, const T* Q, T* FP, T* out) {
+    mat_mul_sym<T, D>(F, P, FP);
+    mat_mul_t_sym<T, D>(FP, F, Q, out);
+}
+
+// ------------------------------------------------------------------------------------
+// Solves.  gj_solve: M X = B for general M (partial pivoting by predicated row swaps, so
+// every index stays compile-time and operands stay in registers).  M and B are destroyed;
+// B holds X on return.  D = 1, 2 take closed forms.
+// ------------------------------------------------------------------------------------
+template <typename T, int D, int NR, bool PIVOT>
+PGPS_HD void gj_solve(T* M, T* B) {
+    if constexpr (D == 1) {
+        const T inv = T(1) / M[0];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) B[j] *= inv;
+        return;
+    } else if constexpr (D == 2) {
+        const T a = M[0], b = M[1], c = M[2], d = M[3];
+        const T inv = T(1) / (a * d - b * c);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const T x0 = B[j], x1 = B[NR + j];
+            B[j] = (d * x0 - b * x1) * inv;
+            B[NR + j] = (a * x1 - c * x0) * inv;
+        }
+        return;
+    } else {
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        if (PIVOT) {
+#pragma unroll
+            for (int r = c + 1; r < D; ++r) {
+                const bool sw = std::fabs(M[r * D + c]) > std::fabs(M[c * D + c]);
+#pragma unroll
+                for (int j = c; j < D; ++j) {
+                    const T u = M[c * D + j], v = M[r * D + j];
+                    M[c * D + j] = sw ? v : u;
+                    M[r * D + j] = sw ? u : v;
+                }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const T u = B[c * NR + j], v = B[r * NR + j];
+                    B[c * NR + j] = sw ? v : u;
+                    B[r * NR + j] = sw ? u : v;
+                }
+            }
+        }
+        const T inv = T(1) / M[c * D + c];
+#pragma unroll
+        for (int j = c + 1; j < D; ++j) M[c * D + j] *= inv;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) B[c * NR + j] *= inv;
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            if (r == c) continue;
+            const T f = M[r * D + c];
+#pragma unroll
+            for (int j = c + 1; j < D; ++j) M[r * D + j] -= f * M[c * D + j];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) B[r * NR + j] -= f * B[c * NR + j];
+        }
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Filtering elements and operator
+// ------------------------------------------------------------------------------------
+template <typename T, int D>
+PGPS_HD void filt_identity(FiltElem<T, D>& e) {
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.A[i] = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { e.A[i * D + i] = T(1); e.b[i] = T(0); e.eta[i] = T(0); }
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) { e.C[i] = T(0); e.J[i] = T(0); }
+}
+
+// First element of the series (parallel.py:13-43 with m0 = 0, parallel.py:125): the prior is
+// updated WITHOUT a predict step.  J, eta of this element never reach an output (they only
+// feed J, eta of prefixes, and a prefix is never a right operand), so they are left zero.
+template <typename T, int D>
+PGPS_HD void filt_first(FiltElem<T, D>& e, const T* P0 /*sym*/, T y, const T* h, T R) {
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.A[i] = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { e.b[i] = T(0); e.eta[i] = T(0); }
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) { e.C[i] = P0[i]; e.J[i] = T(0); }
+    if (!is_nan(y)) {
+        T u[D];
+        sym_vec<T, D>(P0, h, u);
+        T S = R;
+#pragma unroll
+        for (int i = 0; i < D; ++i) S += h[i] * u[i];
+        const T inv = T(1) / S;
+#pragma unroll
+        for (int i = 0; i < D; ++i) e.b[i] = u[i] * (y * inv);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) e.C[symi<D>(i, j)] -= u[i] * u[j] * inv;
+    }
+}
+
+// e <- e (x) element(F, Q, y): extend an aggregate by one raw time step on its right.
+// Written as "predict the conditional, then scalar-innovation update", which is the
+// filtering operator (parallel.py:100-118) specialised to a raw right operand
+// (parallel.py:46-72): J2 = (HF)^T (HF) / S is rank one, so (I + C1 J2)^-1 collapses to
+// Sherman-Morrison and no d x d solve is needed.  Starting from the identity it reproduces
+// the raw element itself.  NaN y = pure predict (parallel.py:46-53).
+template <typename T, int D>
+PGPS_HD void filt_extend(FiltElem<T, D>& e, const T* F, const T* Q /*sym*/, T y, const T* h, T R) {
+    T Ap[D * D], bp[D], FC[D * D], Cp[Dim<D>::SYM];
+    mat_mul<T, D>(F, e.A, Ap);
+    mat_vec<T, D>(F, e.b, bp);
+    predict_cov<T, D>(F, e.C, Q, FC, Cp);
+    if (is_nan(y)) {
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) e.A[i] = Ap[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) e.b[i] = bp[i];
+#pragma unroll
+        for (int i = 0; i < Dim<D>::SYM; ++i) e.C[i] = Cp[i];
+        return;
+    }
+    T u[D], v[D];
+    sym_vec<T, D>(Cp, h, u);            // Cp H^T
+    mat_t_vec<T, D>(Ap, h, v);          // (H Ap)^T
+    T S = R, hb = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; hb += h[i] * bp[i]; }
+    const T inv = T(1) / S;
+    const T res = y - hb;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const T Ki = u[i] * inv;
+#pragma unroll
+        for (int j = 0; j < D; ++j) e.A[i * D + j] = Ap[i * D + j] - Ki * v[j];
+        e.b[i] = bp[i] + Ki * res;
+        e.eta[i] += v[i] * (res * inv);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            e.C[symi<D>(i, j)] = Cp[symi<D>(i, j)] - u[i] * u[j] * inv;
+            e.J[symi<D>(i, j)] += v[i] * v[j] * inv;
+        }
+}
+
+// out = e1 (x) e2, the general filtering operator (parallel.py:100-118).
+// One factorisation of M = I + C1 J2 serves both halves because (I + J2 C1) = M^T.
+//   G = M^-1 A1, N = M^-1 C1, w = M^-1 (b1 + C1 eta2)
+//   A = A2 G;  b = A2 w + b2;  C = sym(A2 N A2^T) + C2
+//   eta = G^T (eta2 - J2 b1) + eta1;  J = sym(G^T J2 A1) + J1
+template <typename T, int D>
+PGPS_HD void filt_combine(const FiltElem<T, D>& e1, const FiltElem<T, D>& e2, FiltElem<T, D>& out) {
+    constexpr int NR = 2 * D + 1;
+    T M[D * D], B[D * NR];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T wi = e1.b[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            T acc = (i == j) ? T(1) : T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += e1.C[symi<D>(i, k)] * e2.J[symi<D>(k, j)];
+            M[i * D + j] = acc;
+            B[i * NR + j] = e1.A[i * D + j];
+            B[i * NR + D + j] = e1.C[symi<D>(i, j)];
+            wi += e1.C[symi<D>(i, j)] * e2.eta[j];
+        }
+        B[i * NR + 2 * D] = wi;
+    }
+    gj_solve<T, D, NR, true>(M, B);
+    T G[D * D], Nm[D * D], w[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) { G[i * D + j] = B[i * NR + j]; Nm[i * D + j] = B[i * NR + D + j]; }
+        w[i] = B[i * NR + 2 * D];
+    }
+    T X[D * D];
+    mat_mul<T, D>(e2.A, G, out.A);
+    mat_vec<T, D>(e2.A, w, out.b);
+#pragma unroll
+    for (int i = 0; i < D; ++i) out.b[i] += e2.b[i];
+    mat_mul<T, D>(e2.A, Nm, X);
+    mat_mul_t_sym<T, D>(X, e2.A, e2.C, out.C);
+    T z[D], Jb[D];
+    sym_vec<T, D>(e2.J, e1.b, Jb);
+#pragma unroll
+    for (int i = 0; i < D; ++i) z[i] = e2.eta[i] - Jb[i];
+    mat_t_vec<T, D>(G, z, out.eta);
+#pragma unroll
+    for (int i = 0; i < D; ++i) out.eta[i] += e1.eta[i];
+    sym_mul_mat<T, D>(e2.J, e1.A, X);
+    mat_t_mul_sym<T, D>(G, X, e1.J, out.J);
+}
+
+// (m, P) <- (0, m, P, ., .) (x) e2: push a filtered state through an aggregate.  This is
+// filt_combine with A1 = 0 (every prefix that contains the first element has A = 0).
+template <typename T, int D>
+PGPS_HD void filt_apply(MeanCov<T, D>& s, const FiltElem<T, D>& e2) {
+    constexpr int NR = D + 1;
+    T M[D * D], B[D * NR];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T wi = s.m[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            T acc = (i == j) ? T(1) : T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += s.P[symi<D>(i, k)] * e2.J[symi<D>(k, j)];
+            M[i * D + j] = acc;
+            B[i * NR + j] = s.P[symi<D>(i, j)];
+            wi += s.P[symi<D>(i, j)] * e2.eta[j];
+        }
+        B[i * NR + D] = wi;
+    }
+    gj_solve<T, D, NR, true>(M, B);
+    T Nm[D * D], w[D], X[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) Nm[i * D + j] = B[i * NR + j];
+        w[i] = B[i * NR + D];
+    }
+    mat_vec<T, D>(e2.A, w, s.m);
+#pragma unroll
+    for (int i = 0; i < D; ++i) s.m[i] += e2.b[i];
+    mat_mul<T, D>(e2.A, Nm, X);
+    mat_mul_t_sym<T, D>(X, e2.A, e2.C, s.P);
+}
+
+// ------------------------------------------------------------------------------------
+// One Kalman step from a carried state, with the log-likelihood term of
+// parallel.py:135-151.  `first` = first step of the whole series: the update uses the prior
+// P0 directly (parallel.py:24-30) while the likelihood term uses F0 P0 F0^T + Q0
+// (parallel.py:136-141).  Outputs mp, Pp (the predicted moments) for the smoother element.
+// ------------------------------------------------------------------------------------
+struct LogLik {
+    double quad = 0.0;      // sum (y - mu)^2 / s2
+    double logdet = 0.0;    // sum log s2
+    long long count = 0;    // number of observed steps
+};
+
+template <typename T, int D>
+PGPS_HD void kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, const T* h, T R,
+                     bool first, LogLik& ll, T* mp, T* Pp, T* FP) {
+    mat_vec<T, D>(F, s.m, mp);
+    predict_cov<T, D>(F, s.P, Q, FP, Pp);
+    const bool obs = !is_nan(y);
+    T u[D];
+    sym_vec<T, D>(Pp, h, u);
+    T S = R, mu = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; mu += h[i] * mp[i]; }
+    if (obs) {
+        const double r = double(y) - double(mu);
+        ll.quad += r * r / double(S);
+        ll.logdet += std::log(double(S));
+        ll.count += 1;
+    }
+    if (first) {
+        // update straight from the prior (s holds m0 = 0, P0)
+        T u0[D];
+        sym_vec<T, D>(s.P, h, u0);
+        T S0 = R, mu0 = T(0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { S0 += h[i] * u0[i]; mu0 += h[i] * s.m[i]; }
+        if (obs) {
+            const T inv = T(1) / S0;
+            const T res = y - mu0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) s.m[i] += u0[i] * (res * inv);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] -= u0[i] * u0[j] * inv;
+        }
+        return;
+    }
+    if (obs) {
+        const T inv = T(1) / S;
+        const T res = y - mu;
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] = mp[i] + u[i] * (res * inv);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] = Pp[symi<D>(i, j)] - u[i] * u[j] * inv;
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] = mp[i];
+#pragma unroll
+        for (int i = 0; i < Dim<D>::SYM; ++i) s.P[i] = Pp[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Smoothing
+// ------------------------------------------------------------------------------------
+template <typename T, int D>
+PGPS_HD void smth_identity(SmthElem<T, D>& e) {
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.E[i] = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { e.E[i * D + i] = T(1); e.g[i] = T(0); }
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) e.L[i] = T(0);
+}
+
+// Smoother gain E = P F^T Pp^-1 (parallel.py:160-162) from FP = F P and Pp (sym, SPD).
+template <typename T, int D>
+PGPS_HD void smth_gain(const T* FP, const T* Pp, T* E) {
+    T M[D * D], B[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) { M[i * D + j] = Pp[symi<D>(i, j)]; B[i * D + j] = FP[i * D + j]; }
+    gj_solve<T, D, D, false>(M, B);     // B = Pp^-1 F P = E^T
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) E[i * D + j] = B[j * D + i];
+}
+
+// Element (E, g, L) of step k from its filtered (m, P) and the NEXT step's predict
+// (mp = F m, Pp = F P F^T + Q, FP = F P): g = m - E mp, L = sym(P - E (F P))
+// (parallel.py:159-166; E Pp E^T = E F P because Pp E^T = F P).
+template <typename T, int D>
+PGPS_HD void smth_element(const MeanCov<T, D>& s, const T* mp, const T* Pp, const T* FP, SmthElem<T, D>& e) {
+    smth_gain<T, D>(FP, Pp, e.E);
+    T Em[D];
+    mat_vec<T, D>(e.E, mp, Em);
+#pragma unroll
+    for (int i = 0; i < D; ++i) e.g[i] = s.m[i] - Em[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                acc += e.E[i * D + k] * FP[k * D + j] + e.E[j * D + k] * FP[k * D + i];
+            e.L[symi<D>(i, j)] = s.P[symi<D>(i, j)] - T(0.5) * acc;
+        }
+}
+
+// Last element of the series: (0, m_N, P_N) (parallel.py:155-156)
+template <typename T, int D>
+PGPS_HD void smth_last(const MeanCov<T, D>& s, SmthElem<T, D>& e) {
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.E[i] = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) e.g[i] = s.m[i];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) e.L[i] = s.P[i];
+}
+
+// out = earlier (x) later in TIME order (the reference scans the reversed series, so its
+// elem2 is `earlier` and elem1 is `later`, parallel.py:176-184):
+//   E = Ea Eb;  g = Ea gb + ga;  L = Ea Lb Ea^T + La
+template <typename T, int D>
+PGPS_HD void smth_combine(const SmthElem<T, D>& a, const SmthElem<T, D>& b, SmthElem<T, D>& out) {
+    T X[D * D], gv[D];
+    mat_mul<T, D>(a.E, b.E, out.E);
+    mat_vec<T, D>(a.E, b.g, gv);
+#pragma unroll
+    for (int i = 0; i < D; ++i) out.g[i] = gv[i] + a.g[i];
+    mat_mul_sym<T, D>(a.E, b.L, X);
+    mat_mul_t_sym<T, D>(X, a.E, a.L, out.L);
+}
+
+// (sm, sP) at the step after an aggregate -> (sm, sP) at the aggregate's first step
+template <typename T, int D>
+PGPS_HD void smth_apply(const SmthElem<T, D>& a, MeanCov<T, D>& s) {
+    T X[D * D], gv[D], Ls[Dim<D>::SYM];
+    mat_vec<T, D>(a.E, s.m, gv);
+#pragma unroll
+    for (int i = 0; i < D; ++i) s.m[i] = gv[i] + a.g[i];
+    mat_mul_sym<T, D>(a.E, s.P, X);
+    mat_mul_t_sym<T, D>(X, a.E, a.L, Ls);
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) s.P[i] = Ls[i];
+}
+
+// One RTS step (parallel.py:159-166 + 176-184 collapsed to Rauch-Tung-Striebel form):
+//   sm_k = m_k + E (sm_{k+1} - mp);  sP_k = P_k + E (sP_{k+1} - Pp) E^T
+// `s` holds (sm_{k+1}, sP_{k+1}) on entry and (sm_k, sP_k) on exit.
+template <typename T, int D>
+PGPS_HD void rts_step(const MeanCov<T, D>& f, const T* mp, const T* Pp, const T* FP, MeanCov<T, D>& s) {
+    T E[D * D], dm[D], dP[Dim<D>::SYM], X[D * D], Em[D];
+    smth_gain<T, D>(FP, Pp, E);
+#pragma unroll
+    for (int i = 0; i < D; ++i) dm[i] = s.m[i] - mp[i];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) dP[i] = s.P[i] - Pp[i];
+    mat_vec<T, D>(E, dm, Em);
+#pragma unroll
+    for (int i = 0; i < D; ++i) s.m[i] = f.m[i] + Em[i];
+    mat_mul_sym<T, D>(E, dP, X);
+    mat_mul_t_sym<T, D>(X, E, f.P, s.P);
+}
+
+}  // namespace pgps

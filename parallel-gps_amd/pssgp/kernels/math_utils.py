@@ -1,0 +1,65 @@
+"""Host-side numerics for building a kernel's LTI SDE (once per call, O(d^6) at most).
+
+balance_ss      -- diagonal-similarity balancing, arXiv 1401.5766
+                   (reference: pssgp/kernels/math_utils.py:10-81; numba loop 10-29)
+solve_lyap_vec  -- stationary covariance by the vectorised Lyapunov system
+                   (reference: pssgp/kernels/math_utils.py:84-120)
+"""
+import numpy as np
+
+
+def _balancing_diagonal(F, n_iter):
+    """Sweep `n_iter` times over the states; each visit equalises the off-diagonal
+    column and row 2-norms of the progressively rescaled matrix.  Returns the
+    accumulated diagonal scaling d (math_utils.py:10-29: the norms are taken on the
+    working copy, which is rescaled in place)."""
+    W = np.array(F, dtype=np.float64, copy=True)
+    dim = W.shape[0]
+    scale = np.ones(dim)
+    off = ~np.eye(dim, dtype=bool)
+    for _ in range(int(n_iter)):
+        for i in range(dim):
+            col = np.sqrt(np.sum(W[off[:, i], i] ** 2))
+            row = np.sqrt(np.sum(W[i, off[i, :]] ** 2))
+            f = np.sqrt(row / col)
+            scale[i] *= f
+            W[:, i] *= f
+            W[i, :] /= f
+    return scale
+
+
+def balance_ss(F, L, H, q, n_iter=5):
+    """Balance (F, L, H, q) for numerical stability; returns (F, L, H, q).
+
+    F <- D^-1 F D, L <- D^-1 L, H <- H D, then L and H are normalised to unit
+    max-abs with q absorbing both squared factors (math_utils.py:68-81).
+    """
+    F = np.asarray(F, dtype=np.float64)
+    L = np.asarray(L, dtype=np.float64)
+    H = np.asarray(H, dtype=np.float64)
+    q = np.asarray(q, dtype=np.float64)
+    d = _balancing_diagonal(F, n_iter)
+    Fb = F * d[None, :] / d[:, None]
+    Lb = L / d[:, None]
+    Hb = H * d[None, :]
+    l_max = np.max(np.abs(Lb))
+    Lb = Lb / l_max
+    q = (l_max ** 2) * q
+    h_max = np.max(np.abs(Hb))
+    Hb = Hb / h_max
+    q = (h_max ** 2) * q
+    return Fb, Lb, Hb, q
+
+
+def solve_lyap_vec(F, L, Q):
+    """P solving F P + P F^T + L Q L^T = 0 through (I (x) F + F (x) I) vec(P) = vec(L Q L^T)
+    and a final -1/2 (P + P^T) (math_utils.py:106-120)."""
+    F = np.asarray(F, dtype=np.float64)
+    L = np.asarray(L, dtype=np.float64)
+    Q = np.atleast_2d(np.asarray(Q, dtype=np.float64))
+    dim = F.shape[0]
+    eye = np.eye(dim)
+    big = np.kron(eye, F) + np.kron(F, eye)
+    rhs = (L @ Q @ L.T).reshape(-1)
+    P = np.linalg.solve(big, rhs).reshape(dim, dim)
+    return -0.5 * (P + P.T)
