@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- timesteps/s of filter + smoother + log-likelihood (BASELINE.json's metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one series already resident in HBM:
+`pgps_pkfs_dev_f64` = k_filter_reduce + k_filter_apply + k_smoother_apply, producing the
+filtered and smoothed moments of every time step and the log-likelihood.
+
+Workload at N = 1: BASELINE.json configs[1] -- Matern-3/2 (state dim 2), 2^20 steps, fp64,
+irregular times, observations drawn from the model's own prior.
+At N > 1 the series is N * 2^20 steps long and rank r owns the contiguous segment
+[r * 2^20, (r+1) * 2^20) ("weak" scaling); the segments are stitched by two tiny all-gathers
+of segment totals over RCCL (pssgp/distributed.py).
+
+PyTorch is plumbing here: device buffers, the stream handed to libpgps, torch.distributed.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "parallel-gps_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--log2n", type=int, default=20, help="log2 of the steps per GPU (default 20 = config c2)")
+    ap.add_argument("--kernel", default="matern32", choices=["matern32", "matern52", "rbf6", "matern12"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nan-frac", type=float, default=0.0)
+    return ap.parse_args()
+
+
+def make_kernel(name):
+    from pssgp.kernels import Matern12, Matern32, Matern52, RBF
+    return {"matern12": lambda: Matern12(1.0, 1.0), "matern32": lambda: Matern32(1.0, 1.0),
+            "matern52": lambda: Matern52(1.0, 1.0),
+            "rbf6": lambda: RBF(1.0, 1.0, order=6, balancing_iter=10)}[name]()
+
+
+def sample_prior_observations(P0, Fs, Qs, H, R, rng):
+    """y_k = H x_k + N(0, R) with x from the SSM prior, by a log-depth doubling scan over the
+    affine maps x -> F_k x + w_k in numpy (host-side data generation, not the product)."""
+    n, d = Fs.shape[0], Fs.shape[1]
+
+    def psd_sqrt(A):
+        w, V = np.linalg.eigh(0.5 * (A + np.swapaxes(A, -1, -2)))
+        return V * np.sqrt(np.clip(w, 0.0, None))[..., None, :]
+
+    A = np.array(Fs, dtype=np.float64)
+    b = np.einsum("nij,nj->ni", psd_sqrt(np.asarray(Qs, np.float64)), rng.standard_normal((n, d)))
+    x0 = psd_sqrt(np.asarray(P0, np.float64)) @ rng.standard_normal(d)
+    b[0] += A[0] @ x0
+    s = 1
+    while s < n:
+        A2 = A.copy()
+        b2 = b.copy()
+        b2[s:] = np.einsum("nij,nj->ni", A[s:], b[:-s]) + b[s:]
+        A2[s:] = A[s:] @ A[:-s]
+        A, b = A2, b2
+        s *= 2
+    h = np.asarray(H, np.float64).reshape(d)
+    return b @ h + np.sqrt(R) * rng.standard_normal(n)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from pssgp import _backend
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" %
+                             (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    dtype_np = np.float64 if args.dtype == "f64" else np.float32
+    dtype_t = torch.float64 if args.dtype == "f64" else torch.float32
+    suf = args.dtype
+    w = 8 if suf == "f64" else 4
+    n_local = 1 << args.log2n
+    n_total = n_local * world
+
+    # ---- model + synthetic series (seeded; identical on every rank, each keeps its segment) ----
+    kern = make_kernel(args.kernel)
+    sde = kern.get_sde()
+    d = sde.F.shape[0]
+    noise = 0.1
+    rng = np.random.default_rng(0)
+    ts_all = np.cumsum(0.05 * rng.uniform(0.5, 1.5, size=n_total))
+    lo, hi = rank * n_local, (rank + 1) * n_local
+    ts = ts_all[lo:hi]
+    t_prev = 0.0 if rank == 0 else float(ts_all[lo - 1])
+
+    ctx = _backend.Context(local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    if args.chunk:
+        ctx.set_chunk(args.chunk)
+
+    def dev_from(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    F_d = dev_from(np.asarray(sde.F, dtype_np))
+    P0_d = dev_from(np.asarray(sde.P0, dtype_np))
+    H_d = dev_from(np.asarray(sde.H, dtype_np).reshape(-1))
+    ts_d = dev_from(ts.astype(dtype_np))
+    Fs_d = torch.empty((n_local, d, d), dtype=dtype_t, device=dev)
+    Qs_d = torch.empty((n_local, d, d), dtype=dtype_t, device=dev)
+    real = ctypes.c_double if suf == "f64" else ctypes.c_float
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    # LTI discretisation on the GPU (the product path); Fs / Qs stay resident
+    ctx.call(f"pgps_discretise_dev_{suf}", ctypes.c_long(n_local), ctypes.c_int(d), P(F_d), P(P0_d), P(ts_d),
+             real(t_prev), P(Fs_d), P(Qs_d))
+    torch.cuda.synchronize(dev)
+    # observations from the model's prior (host), generated from the GPU-discretised model
+    Fs_h, Qs_h = Fs_d.cpu().numpy(), Qs_d.cpu().numpy()
+    ys_h = sample_prior_observations(sde.P0, Fs_h, Qs_h, sde.H, noise, np.random.default_rng(1000 + rank))
+    if args.nan_frac > 0:
+        ys_h[np.random.default_rng(7 + rank).random(n_local) < args.nan_frac] = np.nan
+    ys_d = dev_from(ys_h.astype(dtype_np))
+
+    fms = torch.empty((n_local, d), dtype=dtype_t, device=dev)
+    fPs = torch.empty((n_local, d, d), dtype=dtype_t, device=dev)
+    sms = torch.empty((n_local, d), dtype=dtype_t, device=dev)
+    sPs = torch.empty((n_local, d, d), dtype=dtype_t, device=dev)
+    ll_d = torch.zeros((2,), dtype=torch.float64, device=dev)
+
+    if world == 1:
+        def step():
+            ctx.call(f"pgps_pkfs_dev_{suf}", ctypes.c_long(n_local), ctypes.c_int(d), P(P0_d), P(Fs_d), P(Qs_d),
+                     P(H_d), real(noise), P(ys_d), P(fms), P(fPs), P(sms), P(sPs), P(ll_d))
+    else:
+        from pssgp import distributed as pdist
+        seg = pdist.SegmentScan(ctx, rank, world, d, dtype_np, torch_device=dev)
+
+        def step():
+            seg.pkfs(n_local, P0_d, Fs_d, Qs_d, H_d, noise, ys_d, fms, fPs, sms, sPs, ll_d)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warm-up, then the timed region ---------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    dominant = "k_smoother_apply"
+    ctx.profile_read(reset=True)
+    ctx.profile_enable(1 << 3)          # hipEvents around the dominant kernel only (slot 3)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # per-kernel breakdown (separate, untimed loop with events around every launch)
+    ctx.profile_enable(0x3f)
+    for _ in range(min(args.steps, 50)):
+        step()
+    breakdown = ctx.profile_read(reset=True)
+    ctx.profile_enable(0)
+
+    ll_val = float(ll_d[0].item())
+
+    # ---- roofline of the dominant kernel -----------------------------------------------------
+    dom_ms, dom_n = prof[dominant]
+    dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
+    dom_bytes = (4 * d * d + 2 * d) * w * n_local          # smoother: reads Fs,Qs,fms,fPs; writes sms,sPs
+    achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    alg_bytes_step = (7 * d * d + 3 * d + 1) * w
+
+    out = {
+        "metric": "timesteps/sec (filter+smooth+log-lik)",
+        "value": n_total * args.steps / elapsed,
+        "unit": "timesteps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": suf,
+        "data": "synthetic",
+        "config": {"workload": f"{args.kernel} state-dim {d}, N=2^{args.log2n} steps per GPU "
+                               f"({n_total} total), {suf}, irregular times, prior-sampled observations",
+                   "steps_per_gpu": n_local, "state_dim": d,
+                   "parallelism": "1 GPU" if world == 1 else f"{world} contiguous time segments, 2 RCCL all-gathers"},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_avg_s * 1e3},
+        "whole_path_effective_GBps": alg_bytes_step * n_total * args.steps / elapsed / 1e9,
+        "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in breakdown.items() if v[1]},
+        "log_likelihood": ll_val,
+        "chunk": ctx.get_chunk(n_local),
+    }
+
+    # ---- CPU baseline: the oracle's C restatement of the reference's sequential path ----------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle
+        ssm = (np.asarray(sde.P0), Fs_h.astype(np.float64), Qs_h.astype(np.float64),
+               np.asarray(sde.H).reshape(1, -1), np.array([[noise]]))
+        times = []
+        reps = 5
+        for _ in range(reps):
+            c0 = time.perf_counter()
+            res = c_oracle.kfs(ssm, ys_h, dtype_np)
+            times.append(time.perf_counter() - c0)
+        cpu_t = float(np.median(times))
+        out["cpu_baseline"] = {"value": n_local / cpu_t, "unit": "timesteps/s", "cores": 1, "kind": "port",
+                               "sample": f"the full workload ({n_local} steps), sequential kf+ks "
+                                         f"(oracle/kalman_seq.c), median of {reps} runs"}
+        # the checker also checks: GPU result vs the sequential oracle on the benchmarked arrays
+        cf, cP, cs, csP, cll = res
+        out["parity_vs_cpu_oracle"] = {
+            "ll_rel": abs(ll_val - cll) / abs(cll),
+            "smoothed_mean_rel": float(np.max(np.abs(sms.cpu().numpy() - cs)) / np.max(np.abs(cs))),
+            "smoothed_cov_rel": float(np.max(np.abs(sPs.cpu().numpy() - csP)) / np.max(np.abs(csP))),
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

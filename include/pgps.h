@@ -1,0 +1,151 @@
+/* pgps.h -- C ABI of libpgps.so: the parallel Kalman filter / RTS smoother scan of
+ * EEA-sensors/parallel-gps (`pssgp`) as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference has no native boundary (it is pure Python on TensorFlow); the boundary it
+ * does have is the Python signature of the functions below, so every entry point names the
+ * reference function whose arguments and results it carries (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; row-major, time-major arrays: Fs[k][i][j].
+ *   - `_f64` / `_f32` = the dtype every array of that call has (ll is always double).
+ *   - host entry points take HOST pointers: the library stages to the device, runs, copies
+ *     back and returns when the results are in the caller's buffers.
+ *   - `_dev` entry points take DEVICE pointers (16-byte aligned) and are asynchronous on the
+ *     context's stream (pgps_set_stream / pgps_synchronize).
+ *   - the caller owns every buffer; the library owns only the context (stream, scratch).
+ *   - return value 0 = PGPS_OK, negative = error (pgps_strerror); nothing throws across the
+ *     ABI; outputs are undefined after an error.
+ *   - one call in flight per context; contexts are independent (one per GPU / per thread).
+ *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels.
+ *   - NaN in `ys` marks a missing observation (parallel.py:42,86-95).
+ */
+#ifndef PGPS_H_
+#define PGPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGPS_OK 0
+#define PGPS_E_INVALID (-1)         /* bad argument (null pointer, N < 1, misaligned device pointer) */
+#define PGPS_E_UNSUPPORTED_DIM (-2) /* state dimension outside the compiled kernels */
+#define PGPS_E_HIP (-3)             /* a HIP runtime call failed (pgps_last_hip_error) */
+#define PGPS_E_NOMEM (-4)           /* device or host allocation failed */
+#define PGPS_E_NUMERIC (-5)         /* non-finite result (reference: TF raises on CPU, NaNs on GPU) */
+#define PGPS_E_NO_DEVICE (-6)       /* no HIP device visible */
+
+#define PGPS_MAX_DIM_LANE 6
+
+typedef struct pgps_ctx pgps_ctx;
+
+/* ---- library / context ---------------------------------------------------------------- */
+int pgps_version(void);
+const char* pgps_strerror(int code);
+int pgps_device_count(int* n);
+/* Create a context on HIP device `device` (own non-blocking stream + scratch). */
+int pgps_create(int device, pgps_ctx** out);
+int pgps_destroy(pgps_ctx* ctx);
+/* Borrow an external hipStream_t (e.g. the caller's framework stream); NULL = own stream. */
+int pgps_set_stream(pgps_ctx* ctx, void* hip_stream);
+int pgps_synchronize(pgps_ctx* ctx);
+/* Steps per lane of the scan kernels; 0 = automatic. */
+int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
+int pgps_get_chunk(pgps_ctx* ctx, long n_steps, int* steps_per_lane, int* n_workgroups);
+const char* pgps_last_hip_error(pgps_ctx* ctx);
+
+/* ---- device memory helpers (for hosts without a device-array library) ----------------- */
+int pgps_malloc(pgps_ctx* ctx, size_t bytes, void** dptr);
+int pgps_free(pgps_ctx* ctx, void* dptr);
+int pgps_memcpy_h2d(pgps_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int pgps_memcpy_d2h(pgps_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- per-kernel timing (hipEvents on the context's stream) ----------------------------- */
+#define PGPS_K_FILTER_REDUCE 0
+#define PGPS_K_FILTER_APPLY 1
+#define PGPS_K_SMOOTHER_REDUCE 2
+#define PGPS_K_SMOOTHER_APPLY 3
+#define PGPS_K_LL_FINALIZE 4
+#define PGPS_K_DISCRETISE 5
+#define PGPS_K_COUNT 6
+/* mask: bit i set = record a hipEvent pair around every launch of slot i; 0 = off. */
+int pgps_profile_enable(pgps_ctx* ctx, int mask);
+/* Synchronises, then returns accumulated milliseconds and launch counts per PGPS_K_* slot
+ * since the last reset (arrays of PGPS_K_COUNT). */
+int pgps_profile_read(pgps_ctx* ctx, double* total_ms, long* launches, int reset);
+const char* pgps_kernel_name(int slot);
+
+/* ---- LTI discretisation: pssgp/kernels/base.py:29-47 (_get_ssm) ------------------------
+ * ts (N,), F (d,d), Pinf (d,d) -> Fs (N,d,d), Qs (N,d,d);  dt_0 = ts[0] - t0.
+ * Qs = Pinf - Fs Pinf Fs^T (Pinf must be the stationary covariance of the SDE). */
+int pgps_discretise_f64(pgps_ctx*, long N, int d, const double* F, const double* Pinf, const double* ts,
+                        double t0, double* Fs, double* Qs);
+int pgps_discretise_f32(pgps_ctx*, long N, int d, const float* F, const float* Pinf, const float* ts,
+                        float t0, float* Fs, float* Qs);
+int pgps_discretise_dev_f64(pgps_ctx*, long N, int d, const double* F, const double* Pinf, const double* ts,
+                            double t0, double* Fs, double* Qs);
+int pgps_discretise_dev_f32(pgps_ctx*, long N, int d, const float* F, const float* Pinf, const float* ts,
+                            float t0, float* Fs, float* Qs);
+
+/* ---- parallel filter: pssgp/kalman/parallel.py:121-152 (pkf) ---------------------------
+ * LGSSM (P0 (d,d), Fs (N,d,d), Qs (N,d,d), H (1,d), R scalar) + observations ys (N,)
+ *   -> fms (N,d), fPs (N,d,d), and the log-likelihood if `ll` != NULL
+ * (return_loglikelihood=True, parallel.py:135-151).  m0 = 0 (parallel.py:125). */
+int pgps_pkf_f64(pgps_ctx*, long N, int d, const double* P0, const double* Fs, const double* Qs,
+                 const double* H, double R, const double* ys, double* fms, double* fPs, double* ll);
+int pgps_pkf_f32(pgps_ctx*, long N, int d, const float* P0, const float* Fs, const float* Qs,
+                 const float* H, float R, const float* ys, float* fms, float* fPs, double* ll);
+int pgps_pkf_dev_f64(pgps_ctx*, long N, int d, const double* P0, const double* Fs, const double* Qs,
+                     const double* H, double R, const double* ys, double* fms, double* fPs, double* ll);
+int pgps_pkf_dev_f32(pgps_ctx*, long N, int d, const float* P0, const float* Fs, const float* Qs,
+                     const float* H, float R, const float* ys, float* fms, float* fPs, double* ll);
+
+/* ---- parallel smoother: pssgp/kalman/parallel.py:187-196 (pks) -------------------------
+ * Fs, Qs + filtered fms (N,d), fPs (N,d,d) -> sms (N,d), sPs (N,d,d). */
+int pgps_pks_f64(pgps_ctx*, long N, int d, const double* Fs, const double* Qs, const double* fms,
+                 const double* fPs, double* sms, double* sPs);
+int pgps_pks_f32(pgps_ctx*, long N, int d, const float* Fs, const float* Qs, const float* fms,
+                 const float* fPs, float* sms, float* sPs);
+int pgps_pks_dev_f64(pgps_ctx*, long N, int d, const double* Fs, const double* Qs, const double* fms,
+                     const double* fPs, double* sms, double* sPs);
+int pgps_pks_dev_f32(pgps_ctx*, long N, int d, const float* Fs, const float* Qs, const float* fms,
+                     const float* fPs, float* sms, float* sPs);
+
+/* ---- filter + smoother: pssgp/kalman/parallel.py:199-201 (pkfs) ------------------------
+ * One fused three-launch pass.  Also returns the filtered moments and the log-likelihood
+ * (the reference's pkfs drops them; StateSpaceGP runs the filter a second time for ll,
+ * pssgp/model.py:113-117).  fms / fPs / ll may be NULL for the host entry points; the
+ * device entry points need fms and fPs (the smoother reads them back). */
+int pgps_pkfs_f64(pgps_ctx*, long N, int d, const double* P0, const double* Fs, const double* Qs,
+                  const double* H, double R, const double* ys, double* fms, double* fPs, double* sms,
+                  double* sPs, double* ll);
+int pgps_pkfs_f32(pgps_ctx*, long N, int d, const float* P0, const float* Fs, const float* Qs,
+                  const float* H, float R, const float* ys, float* fms, float* fPs, float* sms,
+                  float* sPs, double* ll);
+int pgps_pkfs_dev_f64(pgps_ctx*, long N, int d, const double* P0, const double* Fs, const double* Qs,
+                      const double* H, double R, const double* ys, double* fms, double* fPs, double* sms,
+                      double* sPs, double* ll);
+int pgps_pkfs_dev_f32(pgps_ctx*, long N, int d, const float* P0, const float* Fs, const float* Qs,
+                      const float* H, float R, const float* ys, float* fms, float* fPs, float* sms,
+                      float* sPs, double* ll);
+
+/* ---- sequential mode: pssgp/kalman/sequential.py:11-73 (kf, ks) ------------------------
+ * StateSpaceGP(parallel=False).  Host arithmetic on HOST pointers, as in the reference (its
+ * sequential mode is the CPU `tf.scan`).  No context needed.  mps / Pps (predicted moments,
+ * return_predicted=True) and ll may be NULL in kf. */
+int pgps_seq_kf_f64(long N, int d, const double* P0, const double* Fs, const double* Qs, const double* H,
+                    double R, const double* ys, double* fms, double* fPs, double* ll, double* mps, double* Pps);
+int pgps_seq_kf_f32(long N, int d, const float* P0, const float* Fs, const float* Qs, const float* H, float R,
+                    const float* ys, float* fms, float* fPs, double* ll, float* mps, float* Pps);
+int pgps_seq_ks_f64(long N, int d, const double* Fs, const double* ms, const double* Ps, const double* mps,
+                    const double* Pps, double* sms, double* sPs);
+int pgps_seq_ks_f32(long N, int d, const float* Fs, const float* ms, const float* Ps, const float* mps,
+                    const float* Pps, float* sms, float* sPs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGPS_H_ */

@@ -1,0 +1,452 @@
+// pgps_core.hip -- the C ABI of libpgps.so (include/pgps.h): context, scratch, staging and
+// dimension dispatch.  The kernels live in pgps_inst.hip (one unit per dtype x state dim).
+// No PyTorch, no TensorFlow: HIP runtime only.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "pgps_internal.h"
+
+using namespace pgps;
+
+namespace pgps {
+int ensure(pgps_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return PGPS_OK;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        ctx->hip_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        b.p = nullptr;
+        return PGPS_E_NOMEM;
+    }
+    b.cap = want;
+    return PGPS_OK;
+}
+}  // namespace pgps
+
+extern "C" int pgps_version(void) { return 100; }
+
+extern "C" const char* pgps_strerror(int code) {
+    switch (code) {
+        case PGPS_OK: return "ok";
+        case PGPS_E_INVALID: return "invalid argument";
+        case PGPS_E_UNSUPPORTED_DIM: return "state dimension not supported by the compiled kernels";
+        case PGPS_E_HIP: return "HIP runtime error";
+        case PGPS_E_NOMEM: return "out of memory";
+        case PGPS_E_NUMERIC: return "non-finite result";
+        case PGPS_E_NO_DEVICE: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int pgps_device_count(int* n) {
+    if (!n) return PGPS_E_INVALID;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *n = c;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_create(int device, pgps_ctx** out) {
+    if (!out) return PGPS_E_INVALID;
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return PGPS_E_NO_DEVICE;
+    if (device < 0 || device >= c) return PGPS_E_INVALID;
+    pgps_ctx* ctx = new (std::nothrow) pgps_ctx();
+    if (!ctx) return PGPS_E_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PGPS_E_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_destroy(pgps_ctx* ctx) {
+    if (!ctx) return PGPS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws.p) (void)hipFree(ctx->ws.p);
+    for (auto& b : ctx->st)
+        if (b.p) (void)hipFree(b.p);
+    for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_set_stream(pgps_ctx* ctx, void* s) {
+    if (!ctx) return PGPS_E_INVALID;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_synchronize(pgps_ctx* ctx) {
+    if (!ctx) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGPS_OK;
+}
+
+extern "C" int pgps_set_chunk(pgps_ctx* ctx, int c) {
+    if (!ctx || c < 0) return PGPS_E_INVALID;
+    ctx->chunk = c;
+    return PGPS_OK;
+}
+
+extern "C" const char* pgps_last_hip_error(pgps_ctx* ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
+
+extern "C" int pgps_malloc(pgps_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) { ctx->hip_err = hipGetErrorString(e); return PGPS_E_NOMEM; }
+    return PGPS_OK;
+}
+extern "C" int pgps_free(pgps_ctx* ctx, void* dptr) {
+    if (!ctx) return PGPS_E_INVALID;
+    if (dptr) HIPCHK(ctx, hipFree(dptr));
+    return PGPS_OK;
+}
+extern "C" int pgps_memcpy_h2d(pgps_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGPS_OK;
+}
+extern "C" int pgps_memcpy_d2h(pgps_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------------------------
+static const char* kKernelNames[PGPS_K_COUNT] = {"k_filter_reduce", "k_filter_apply", "k_smoother_reduce",
+                                                 "k_smoother_apply", "k_ll_finalize", "k_discretise"};
+extern "C" const char* pgps_kernel_name(int slot) {
+    return (slot >= 0 && slot < PGPS_K_COUNT) ? kKernelNames[slot] : "";
+}
+
+namespace pgps {
+int prof_flush(pgps_ctx* ctx) {
+    if (ctx->ev_used == 0) return PGPS_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].a, ctx->ev_pool[i].b));
+        ctx->prof_ms[ctx->ev_pool[i].slot] += ms;
+        ctx->prof_n[ctx->ev_pool[i].slot] += 1;
+    }
+    ctx->ev_used = 0;
+    return PGPS_OK;
+}
+
+ProfScope::ProfScope(pgps_ctx* c, int slot) : ctx(c) {
+    if (!((c->profiling >> slot) & 1u)) return;
+    if (c->ev_used == c->ev_pool.size()) {
+        if (c->ev_pool.size() >= 8192) {
+            if (prof_flush(c) != PGPS_OK) return;
+        } else {
+            pgps_ctx::EvPair p;
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            c->ev_pool.push_back(p);
+        }
+    }
+    ev = &c->ev_pool[c->ev_used++];
+    ev->slot = slot;
+    (void)hipEventRecord(ev->a, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (ev) (void)hipEventRecord(ev->b, ctx->stream);
+}
+}  // namespace pgps
+
+extern "C" int pgps_profile_enable(pgps_ctx* ctx, int on) {
+    if (!ctx) return PGPS_E_INVALID;
+    if (!on) { int rc = prof_flush(ctx); if (rc) return rc; }
+    ctx->profiling = (unsigned)on;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_profile_read(pgps_ctx* ctx, double* total_ms, long* launches, int reset) {
+    if (!ctx) return PGPS_E_INVALID;
+    int rc = prof_flush(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < PGPS_K_COUNT; ++i) {
+        if (total_ms) total_ms[i] = ctx->prof_ms[i];
+        if (launches) launches[i] = ctx->prof_n[i];
+        if (reset) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    }
+    return PGPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch geometry
+// ---------------------------------------------------------------------------------------------
+namespace pgps {
+void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks) {
+    int c = ctx->chunk;
+    if (c <= 0) {
+        // aim at ~512 workgroups (2 per CU) once the series is long enough; never less than one
+        // step per lane, and keep the spine (one entry per workgroup) at <= 1024 entries
+        const long target_blocks = 512;
+        long v = (N + (long)kBlock * target_blocks - 1) / ((long)kBlock * target_blocks);
+        if (v < 1) v = 1;
+        if (N >= (long)kBlock * 4 && v < 4) v = 4;
+        c = (int)v;
+    }
+    long nb = (N + (long)kBlock * c - 1) / ((long)kBlock * c);
+    if (nb < 1) nb = 1;
+    *Lc = c;
+    *nblocks = (int)nb;
+}
+}  // namespace pgps
+
+extern "C" int pgps_get_chunk(pgps_ctx* ctx, long N, int* Lc, int* nb) {
+    if (!ctx || N < 1 || !Lc || !nb) return PGPS_E_INVALID;
+    geometry(ctx, N, Lc, nb);
+    return PGPS_OK;
+}
+
+template <typename T>
+static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
+    switch (d) {
+        case 1: return launch_scan<T, 1>(ctx, a, mode);
+        case 2: return launch_scan<T, 2>(ctx, a, mode);
+        case 3: return launch_scan<T, 3>(ctx, a, mode);
+        case 4: return launch_scan<T, 4>(ctx, a, mode);
+        case 5: return launch_scan<T, 5>(ctx, a, mode);
+        case 6: return launch_scan<T, 6>(ctx, a, mode);
+        default: return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// device-pointer entry points
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int pkf_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
+                   const T* ys, T* fms, T* fPs, double* ll) {
+    if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs) return PGPS_E_INVALID;
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs)) return PGPS_E_INVALID;
+    ScanArgs<T> a{};
+    a.N = N; a.seg_first = 1; a.seg_last = 1;
+    a.P0 = P0; a.H = H; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys;
+    a.fms = fms; a.fPs = fPs; a.ll = ll;
+    return dispatch_scan<T>(ctx, d, a, MODE_PKF);
+}
+
+template <typename T>
+static int pks_dev(pgps_ctx* ctx, long N, int d, const T* Fs, const T* Qs, const T* fms, const T* fPs,
+                   T* sms, T* sPs) {
+    if (!ctx || N < 1 || !Fs || !Qs || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs) || !aligned16(sms) ||
+        !aligned16(sPs))
+        return PGPS_E_INVALID;
+    ScanArgs<T> a{};
+    a.N = N; a.seg_first = 1; a.seg_last = 1;
+    a.Fs = Fs; a.Qs = Qs;
+    a.fms = const_cast<T*>(fms); a.fPs = const_cast<T*>(fPs); a.sms = sms; a.sPs = sPs;
+    return dispatch_scan<T>(ctx, d, a, MODE_PKS);
+}
+
+template <typename T>
+static int pkfs_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
+                    const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {
+    if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs) || !aligned16(sms) ||
+        !aligned16(sPs))
+        return PGPS_E_INVALID;
+    ScanArgs<T> a{};
+    a.N = N; a.seg_first = 1; a.seg_last = 1;
+    a.P0 = P0; a.H = H; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys;
+    a.fms = fms; a.fPs = fPs; a.sms = sms; a.sPs = sPs; a.ll = ll;
+    return dispatch_scan<T>(ctx, d, a, MODE_PKFS);
+}
+
+template <typename T>
+static int disc_dev(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
+    if (!ctx || N < 1 || !F || !Pinf || !ts || !Fs || !Qs) return PGPS_E_INVALID;
+    switch (d) {
+        case 1: return launch_disc<T, 1>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
+        case 2: return launch_disc<T, 2>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
+        case 3: return launch_disc<T, 3>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
+        case 4: return launch_disc<T, 4>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
+        case 5: return launch_disc<T, 5>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
+        case 6: return launch_disc<T, 6>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
+        default: return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-pointer entry points (stage -> run -> copy back)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int stage_in(pgps_ctx* ctx, DevBuf& b, const T* host, size_t n, T** dev) {
+    int rc = ensure(ctx, b, n * sizeof(T));
+    if (rc) return rc;
+    *dev = (T*)b.p;
+    if (host) HIPCHK(ctx, hipMemcpyAsync(b.p, host, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return PGPS_OK;
+}
+template <typename T>
+static int stage_out(pgps_ctx* ctx, T* host, const T* dev, size_t n) {
+    if (host) HIPCHK(ctx, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return PGPS_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+template <typename T>
+static int pkf_host(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
+                    const T* ys, T* fms, T* fPs, double* ll) {
+    if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs) return PGPS_E_INVALID;
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)N, dd = (size_t)d * d;
+    T *dP0, *dFs, *dQs, *dH, *dys, *dfms, *dfPs;
+    double* dll;
+    TRY(stage_in(ctx, ctx->st[0], P0, dd, &dP0));
+    TRY(stage_in(ctx, ctx->st[1], Fs, n * dd, &dFs));
+    TRY(stage_in(ctx, ctx->st[2], Qs, n * dd, &dQs));
+    TRY(stage_in(ctx, ctx->st[3], H, (size_t)d, &dH));
+    TRY(stage_in(ctx, ctx->st[4], ys, n, &dys));
+    TRY(stage_in<T>(ctx, ctx->st[5], nullptr, n * d, &dfms));
+    TRY(stage_in<T>(ctx, ctx->st[6], nullptr, n * dd, &dfPs));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, 2, &dll));
+    TRY(pkf_dev<T>(ctx, N, d, dP0, dFs, dQs, dH, R, dys, dfms, dfPs, ll ? dll : nullptr));
+    TRY(stage_out(ctx, fms, dfms, n * d));
+    TRY(stage_out(ctx, fPs, dfPs, n * dd));
+    TRY(stage_out(ctx, ll, dll, 1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ll && !std::isfinite(*ll)) return PGPS_E_NUMERIC;
+    return PGPS_OK;
+}
+
+template <typename T>
+static int pks_host(pgps_ctx* ctx, long N, int d, const T* Fs, const T* Qs, const T* fms, const T* fPs, T* sms,
+                    T* sPs) {
+    if (!ctx || N < 1 || !Fs || !Qs || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)N, dd = (size_t)d * d;
+    T *dFs, *dQs, *dfms, *dfPs, *dsms, *dsPs;
+    TRY(stage_in(ctx, ctx->st[1], Fs, n * dd, &dFs));
+    TRY(stage_in(ctx, ctx->st[2], Qs, n * dd, &dQs));
+    TRY(stage_in(ctx, ctx->st[5], fms, n * d, &dfms));
+    TRY(stage_in(ctx, ctx->st[6], fPs, n * dd, &dfPs));
+    TRY(stage_in<T>(ctx, ctx->st[7], nullptr, n * d, &dsms));
+    TRY(stage_in<T>(ctx, ctx->st[8], nullptr, n * dd, &dsPs));
+    TRY(pks_dev<T>(ctx, N, d, dFs, dQs, dfms, dfPs, dsms, dsPs));
+    TRY(stage_out(ctx, sms, dsms, n * d));
+    TRY(stage_out(ctx, sPs, dsPs, n * dd));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGPS_OK;
+}
+
+template <typename T>
+static int pkfs_host(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
+                     const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {
+    if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !sms || !sPs) return PGPS_E_INVALID;
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)N, dd = (size_t)d * d;
+    T *dP0, *dFs, *dQs, *dH, *dys, *dfms, *dfPs, *dsms, *dsPs;
+    double* dll;
+    TRY(stage_in(ctx, ctx->st[0], P0, dd, &dP0));
+    TRY(stage_in(ctx, ctx->st[1], Fs, n * dd, &dFs));
+    TRY(stage_in(ctx, ctx->st[2], Qs, n * dd, &dQs));
+    TRY(stage_in(ctx, ctx->st[3], H, (size_t)d, &dH));
+    TRY(stage_in(ctx, ctx->st[4], ys, n, &dys));
+    TRY(stage_in<T>(ctx, ctx->st[5], nullptr, n * d, &dfms));
+    TRY(stage_in<T>(ctx, ctx->st[6], nullptr, n * dd, &dfPs));
+    TRY(stage_in<T>(ctx, ctx->st[7], nullptr, n * d, &dsms));
+    TRY(stage_in<T>(ctx, ctx->st[8], nullptr, n * dd, &dsPs));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, 2, &dll));
+    TRY(pkfs_dev<T>(ctx, N, d, dP0, dFs, dQs, dH, R, dys, dfms, dfPs, dsms, dsPs, dll));
+    TRY(stage_out(ctx, fms, dfms, n * d));
+    TRY(stage_out(ctx, fPs, dfPs, n * dd));
+    TRY(stage_out(ctx, sms, dsms, n * d));
+    TRY(stage_out(ctx, sPs, dsPs, n * dd));
+    double llh = 0.0;
+    TRY(stage_out(ctx, &llh, dll, 1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ll) *ll = llh;
+    if (!std::isfinite(llh)) return PGPS_E_NUMERIC;
+    return PGPS_OK;
+}
+
+template <typename T>
+static int disc_host(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
+    if (!ctx || N < 1 || !F || !Pinf || !ts || !Fs || !Qs) return PGPS_E_INVALID;
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)N, dd = (size_t)d * d;
+    T *dF, *dP, *dts, *dFs, *dQs;
+    TRY(stage_in(ctx, ctx->st[0], F, dd, &dF));
+    TRY(stage_in(ctx, ctx->st[3], Pinf, dd, &dP));
+    TRY(stage_in(ctx, ctx->st[4], ts, n, &dts));
+    TRY(stage_in<T>(ctx, ctx->st[1], nullptr, n * dd, &dFs));
+    TRY(stage_in<T>(ctx, ctx->st[2], nullptr, n * dd, &dQs));
+    TRY(disc_dev<T>(ctx, N, d, dF, dP, dts, t0, dFs, dQs));
+    TRY(stage_out(ctx, Fs, dFs, n * dd));
+    TRY(stage_out(ctx, Qs, dQs, n * dd));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// extern "C" surface
+// ---------------------------------------------------------------------------------------------
+#define PGPS_DEFINE(SUF, T)                                                                                          \
+    extern "C" int pgps_discretise_##SUF(pgps_ctx* c, long N, int d, const T* F, const T* P, const T* ts, T t0,     \
+                                         T* Fs, T* Qs) {                                                            \
+        return disc_host<T>(c, N, d, F, P, ts, t0, Fs, Qs);                                                         \
+    }                                                                                                                \
+    extern "C" int pgps_discretise_dev_##SUF(pgps_ctx* c, long N, int d, const T* F, const T* P, const T* ts, T t0, \
+                                             T* Fs, T* Qs) {                                                        \
+        if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;                                          \
+        return disc_dev<T>(c, N, d, F, P, ts, t0, Fs, Qs);                                                          \
+    }                                                                                                                \
+    extern "C" int pgps_pkf_##SUF(pgps_ctx* c, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H,    \
+                                  T R, const T* ys, T* fms, T* fPs, double* ll) {                                   \
+        return pkf_host<T>(c, N, d, P0, Fs, Qs, H, R, ys, fms, fPs, ll);                                            \
+    }                                                                                                                \
+    extern "C" int pgps_pkf_dev_##SUF(pgps_ctx* c, long N, int d, const T* P0, const T* Fs, const T* Qs,            \
+                                      const T* H, T R, const T* ys, T* fms, T* fPs, double* ll) {                   \
+        return pkf_dev<T>(c, N, d, P0, Fs, Qs, H, R, ys, fms, fPs, ll);                                             \
+    }                                                                                                                \
+    extern "C" int pgps_pks_##SUF(pgps_ctx* c, long N, int d, const T* Fs, const T* Qs, const T* fms,               \
+                                  const T* fPs, T* sms, T* sPs) {                                                   \
+        return pks_host<T>(c, N, d, Fs, Qs, fms, fPs, sms, sPs);                                                    \
+    }                                                                                                                \
+    extern "C" int pgps_pks_dev_##SUF(pgps_ctx* c, long N, int d, const T* Fs, const T* Qs, const T* fms,           \
+                                      const T* fPs, T* sms, T* sPs) {                                               \
+        return pks_dev<T>(c, N, d, Fs, Qs, fms, fPs, sms, sPs);                                                     \
+    }                                                                                                                \
+    extern "C" int pgps_pkfs_##SUF(pgps_ctx* c, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H,   \
+                                   T R, const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {                  \
+        return pkfs_host<T>(c, N, d, P0, Fs, Qs, H, R, ys, fms, fPs, sms, sPs, ll);                                 \
+    }                                                                                                                \
+    extern "C" int pgps_pkfs_dev_##SUF(pgps_ctx* c, long N, int d, const T* P0, const T* Fs, const T* Qs,           \
+                                       const T* H, T R, const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {  \
+        return pkfs_dev<T>(c, N, d, P0, Fs, Qs, H, R, ys, fms, fPs, sms, sPs, ll);                                  \
+    }
+
+PGPS_DEFINE(f64, double)
+PGPS_DEFINE(f32, float)

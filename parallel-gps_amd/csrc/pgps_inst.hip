@@ -1,0 +1,100 @@
+// pgps_inst.hip -- one translation unit per compiled (dtype, state dimension): the kernels of
+// pgps_kernels.hip.h / pgps_discretise.hip.h instantiated for PGPS_INST_T, PGPS_INST_D, and the
+// launch functions the C ABI dispatches to.  Split this way because the fully unrolled algebra
+// for d >= 5 takes minutes to compile; the Makefile builds the units in parallel.
+#include "pgps_discretise.hip.h"
+#include "pgps_kernels.hip.h"
+
+#ifndef PGPS_INST_T
+#error "compile with -DPGPS_INST_T=<float|double> -DPGPS_INST_D=<d>"
+#endif
+
+namespace pgps {
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+template <typename T, int D>
+static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
+    const size_t nl = (size_t)a.nlanes, nb = (size_t)a.nblocks;
+    size_t off = 0;
+    const size_t o_spine = off;  off = align_up(off + nb * Dim<D>::NFILT * sizeof(T), 256);
+    const size_t o_lpre = off;   off = align_up(off + nl * Dim<D>::NFILT * sizeof(T), 256);
+    const size_t o_sspine = off; off = align_up(off + nb * Dim<D>::NSMTH * sizeof(T), 256);
+    const size_t o_lsuf = off;   off = align_up(off + nl * Dim<D>::NSMTH * sizeof(T), 256);
+    const size_t o_ll = off;     off = align_up(off + nb * sizeof(double), 256);
+    const size_t o_status = off; off = align_up(off + 16, 256);
+    int rc = ensure(ctx, ctx->ws, off);
+    if (rc) return rc;
+    char* base = (char*)ctx->ws.p;
+    a.spine = (T*)(base + o_spine);
+    a.lpre = (T*)(base + o_lpre);
+    a.sspine = (T*)(base + o_sspine);
+    a.lsuf = (T*)(base + o_lsuf);
+    a.llpart = (double*)(base + o_ll);
+    a.status = (int*)(base + o_status);
+    return PGPS_OK;
+}
+
+template <typename T, int D>
+int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    geometry(ctx, a.N, &a.Lc, &a.nblocks);
+    a.nlanes = (long)a.nblocks * kBlock;
+    int rc = carve_workspace<T, D>(ctx, a);
+    if (rc) return rc;
+    const dim3 grid(a.nblocks), block(kBlock);
+    hipStream_t s = ctx->stream;
+    if (mode == MODE_PKF || mode == MODE_PKFS) {
+        {
+            ProfScope p(ctx, PGPS_K_FILTER_REDUCE);
+            hipLaunchKernelGGL((k_filter_reduce<T, D>), grid, block, 0, s, a);
+        }
+        if (mode == MODE_PKFS) {
+            ProfScope p(ctx, PGPS_K_FILTER_APPLY);
+            hipLaunchKernelGGL((k_filter_apply<T, D, true>), grid, block, 0, s, a);
+        } else {
+            {
+                ProfScope p(ctx, PGPS_K_FILTER_APPLY);
+                hipLaunchKernelGGL((k_filter_apply<T, D, false>), grid, block, 0, s, a);
+            }
+            if (a.ll) {
+                ProfScope p(ctx, PGPS_K_LL_FINALIZE);
+                hipLaunchKernelGGL(k_ll_finalize, dim3(1), block, 0, s, a.llpart, a.nblocks, a.ll);
+            }
+        }
+    }
+    if (mode == MODE_PKS) {
+        ProfScope p(ctx, PGPS_K_SMOOTHER_REDUCE);
+        ScanArgs<T> b = a;
+        b.ll = nullptr;
+        hipLaunchKernelGGL((k_smoother_reduce<T, D>), grid, block, 0, s, b);
+    }
+    if (mode == MODE_PKS || mode == MODE_PKFS) {
+        ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
+        ScanArgs<T> b = a;
+        if (mode == MODE_PKS) b.ll = nullptr;
+        hipLaunchKernelGGL((k_smoother_apply<T, D>), grid, block, 0, s, b);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+template <typename T, int D>
+int launch_disc(pgps_ctx* ctx, long N, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int block = 256;
+    const long grid = (N + block - 1) / block;
+    {
+        ProfScope p(ctx, PGPS_K_DISCRETISE);
+        hipLaunchKernelGGL((k_discretise<T, D>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, N, F, Pinf, ts,
+                           t0, Fs, Qs);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+template int launch_scan<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, ScanArgs<PGPS_INST_T>, Mode);
+template int launch_disc<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, long, const PGPS_INST_T*, const PGPS_INST_T*,
+                                                   const PGPS_INST_T*, PGPS_INST_T, PGPS_INST_T*, PGPS_INST_T*);
+
+}  // namespace pgps

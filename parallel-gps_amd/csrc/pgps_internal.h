@@ -1,0 +1,101 @@
+// pgps_internal.h -- context, scratch and launch plumbing shared by the C-ABI translation
+// unit (pgps_core.hip) and the per-(dtype, d) kernel translation units (pgps_inst.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pgps.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct pgps_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int chunk = 0;                      // 0 = auto
+    std::string hip_err;
+    DevBuf ws;                          // scratch of the scan kernels
+    DevBuf st[12];                      // staging buffers of the host entry points
+    unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
+    struct EvPair { hipEvent_t a, b; int slot; };
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    double prof_ms[PGPS_K_COUNT] = {0};
+    long prof_n[PGPS_K_COUNT] = {0};
+};
+
+#define HIPCHK(ctx, expr)                                                        \
+    do {                                                                         \
+        hipError_t e_ = (expr);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            (ctx)->hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);  \
+            return PGPS_E_HIP;                                                   \
+        }                                                                        \
+    } while (0)
+
+namespace pgps {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+constexpr int kWaves = kBlock / kWave;
+
+int ensure(pgps_ctx* ctx, DevBuf& b, size_t bytes);
+int prof_flush(pgps_ctx* ctx);
+void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks);
+
+// hipEvent pair around one launch when profiling is on
+struct ProfScope {
+    pgps_ctx* ctx;
+    pgps_ctx::EvPair* ev = nullptr;
+    ProfScope(pgps_ctx* c, int slot);
+    ~ProfScope();
+};
+
+template <typename T>
+struct ScanArgs {
+    long N;                 // steps in this segment
+    int Lc;                 // steps per lane
+    int nblocks;            // workgroups
+    long nlanes;            // nblocks * kBlock (stride of the field-major workspaces)
+    // segment position in the whole series (single GPU: first = last = 1)
+    int seg_first;          // step 0 of this segment is the first step of the series
+    int seg_last;           // step N-1 of this segment is the last step of the series
+    // model
+    const T* P0;            // (d, d) prior covariance              [device]
+    const T* H;             // (d,)   observation row               [device]
+    T R;                    // observation noise variance
+    // series
+    const T* Fs;            // (N, d, d)
+    const T* Qs;            // (N, d, d)
+    const T* ys;            // (N,)   NaN = missing
+    // stitching across segments (multi-GPU); unused when seg_first / seg_last
+    const T* carry_in;      // (d + d*d) filtered (m, P full) entering this segment
+    const T* halo_FQ;       // (2, d, d) F, Q of the first step of the NEXT segment
+    const T* carry_back;    // (d + d*d) smoothed (m, P full) of the first step of the NEXT segment
+    // outputs
+    T* fms; T* fPs; T* sms; T* sPs;
+    double* ll;             // scalar log-likelihood (of this segment)
+    // workspace
+    T* spine;               // (nblocks, NFILT)
+    T* lpre;                // (NFILT, nlanes)
+    T* sspine;              // (nblocks, NSMTH)
+    T* lsuf;                // (NSMTH, nlanes)
+    double* llpart;         // (nblocks,)
+    int* status;            // != 0: a non-positive innovation variance was met
+};
+
+enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS };
+
+// defined in pgps_inst.hip, one explicit instantiation per compiled (T, D)
+template <typename T, int D>
+int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
+template <typename T, int D>
+int launch_disc(pgps_ctx* ctx, long N, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);
+
+}  // namespace pgps

@@ -1,0 +1,706 @@
+// pgps_kernels.hip.h -- the parallel Kalman filter / RTS smoother scan as CDNA4 kernels.
+//
+// "lane-chunk" family: one lane owns a contiguous chunk of Lc time steps and keeps whole
+// d x d operands in registers (d <= 6); a wavefront owns 64*Lc contiguous steps, a workgroup
+// (4 wavefronts) 256*Lc.  Three launches cover filter + log-likelihood + smoother:
+//
+//   k_filter_reduce   lane-serial chunk aggregates (filt_extend), wavefront Kogge-Stone scan by
+//                     64-wide __shfl_up, cross-wave fold through LDS  ->  per-lane workgroup-local
+//                     exclusive prefixes (lpre) + one 5-tuple per workgroup (spine)
+//   k_filter_apply    every workgroup folds the spine entries to its left (tree over lanes), pushes
+//                     the carried (m, P) through each lane's local prefix (filt_apply), then runs
+//                     the cheap lane-serial Kalman recursion: writes fms / fPs, accumulates the
+//                     log-likelihood, and -- fused -- builds the smoothing elements and their
+//                     per-lane aggregates, suffix-scans them and writes lsuf + sspine
+//   k_smoother_apply  folds the sspine entries to its right, applies each lane's local suffix,
+//                     runs the lane-serial RTS recursion backwards: writes sms / sPs; workgroup 0
+//                     also reduces the per-workgroup log-likelihood partials
+//
+// Every prefix that contains the first element of the series has A = 0 (parallel.py:28), so the
+// carried state is just (m, P): only the reductions handle full 5-tuples.
+//
+// Reference: pssgp/kalman/parallel.py (pkf 121-152, pks 187-196, pkfs 199-201).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pgps_internal.h"
+#include "pgps_math.h"
+
+namespace pgps {
+
+// ---------------------------------------------------------------------------------------------
+// vector loads / stores of small contiguous records (16-byte accesses when the record allows)
+// ---------------------------------------------------------------------------------------------
+template <int BYTES>
+struct VecBytes {
+    static constexpr int W = (BYTES % 16 == 0) ? 16 : (BYTES % 8 == 0) ? 8 : 4;
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void load_rec(const T* __restrict__ p, T* out) {
+    constexpr int W = VecBytes<N * sizeof(T)>::W;
+    constexpr int PER = W / sizeof(T);
+    if constexpr (W == 16) {
+        using V = __attribute__((ext_vector_type(4))) unsigned int;
+#pragma unroll
+        for (int i = 0; i < N / PER; ++i) {
+            V v = reinterpret_cast<const V*>(p)[i];
+            T tmp[PER];
+            __builtin_memcpy(tmp, &v, 16);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) out[i * PER + j] = tmp[j];
+        }
+    } else if constexpr (W == 8 && sizeof(T) == 4) {
+        using V = __attribute__((ext_vector_type(2))) unsigned int;
+#pragma unroll
+        for (int i = 0; i < N / PER; ++i) {
+            V v = reinterpret_cast<const V*>(p)[i];
+            T tmp[PER];
+            __builtin_memcpy(tmp, &v, 8);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) out[i * PER + j] = tmp[j];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[i] = p[i];
+    }
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void store_rec(T* __restrict__ p, const T* in) {
+    constexpr int W = VecBytes<N * sizeof(T)>::W;
+    constexpr int PER = W / sizeof(T);
+    if constexpr (W == 16) {
+        using V = __attribute__((ext_vector_type(4))) unsigned int;
+#pragma unroll
+        for (int i = 0; i < N / PER; ++i) {
+            T tmp[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) tmp[j] = in[i * PER + j];
+            V v;
+            __builtin_memcpy(&v, tmp, 16);
+            reinterpret_cast<V*>(p)[i] = v;
+        }
+    } else if constexpr (W == 8 && sizeof(T) == 4) {
+        using V = __attribute__((ext_vector_type(2))) unsigned int;
+#pragma unroll
+        for (int i = 0; i < N / PER; ++i) {
+            T tmp[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) tmp[j] = in[i * PER + j];
+            V v;
+            __builtin_memcpy(&v, tmp, 8);
+            reinterpret_cast<V*>(p)[i] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = in[i];
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void sym_from_full(const T* full, T* sym) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j)
+            sym[symi<D>(i, j)] = (i == j) ? full[i * D + i] : T(0.5) * (full[i * D + j] + full[j * D + i]);
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void full_from_sym(const T* sym, T* full) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) full[i * D + j] = sym[symi<D>(i, j)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat views of the element structs (for shuffles, LDS and workspace I/O)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__device__ __forceinline__ void pack(const FiltElem<T, D>& e, T* v) {
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) v[o++] = e.A[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) v[o++] = e.b[i];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) v[o++] = e.C[i];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) v[o++] = e.J[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) v[o++] = e.eta[i];
+}
+template <typename T, int D>
+__device__ __forceinline__ void unpack(const T* v, FiltElem<T, D>& e) {
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.A[i] = v[o++];
+#pragma unroll
+    for (int i = 0; i < D; ++i) e.b[i] = v[o++];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) e.C[i] = v[o++];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) e.J[i] = v[o++];
+#pragma unroll
+    for (int i = 0; i < D; ++i) e.eta[i] = v[o++];
+}
+template <typename T, int D>
+__device__ __forceinline__ void pack(const SmthElem<T, D>& e, T* v) {
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) v[o++] = e.E[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) v[o++] = e.g[i];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) v[o++] = e.L[i];
+}
+template <typename T, int D>
+__device__ __forceinline__ void unpack(const T* v, SmthElem<T, D>& e) {
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.E[i] = v[o++];
+#pragma unroll
+    for (int i = 0; i < D; ++i) e.g[i] = v[o++];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::SYM; ++i) e.L[i] = v[o++];
+}
+
+template <typename E> struct ElemTraits;
+template <typename T, int D>
+struct ElemTraits<FiltElem<T, D>> {
+    static constexpr int N = Dim<D>::NFILT;
+    using Scalar = T;
+    __device__ static __forceinline__ void identity(FiltElem<T, D>& e) { filt_identity(e); }
+    // time-ordered combine: `a` covers the earlier steps
+    __device__ static __forceinline__ void combine(const FiltElem<T, D>& a, const FiltElem<T, D>& b, FiltElem<T, D>& o) {
+        filt_combine(a, b, o);
+    }
+};
+template <typename T, int D>
+struct ElemTraits<SmthElem<T, D>> {
+    static constexpr int N = Dim<D>::NSMTH;
+    using Scalar = T;
+    __device__ static __forceinline__ void identity(SmthElem<T, D>& e) { smth_identity(e); }
+    __device__ static __forceinline__ void combine(const SmthElem<T, D>& a, const SmthElem<T, D>& b, SmthElem<T, D>& o) {
+        smth_combine(a, b, o);
+    }
+};
+
+template <typename E>
+__device__ __forceinline__ E shfl_up_elem(const E& e, int s) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+    pack(e, v);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) v[i] = __shfl_up(v[i], s, kWave);
+    E r;
+    unpack(v, r);
+    return r;
+}
+template <typename E>
+__device__ __forceinline__ E shfl_down_elem(const E& e, int s) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+    pack(e, v);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) v[i] = __shfl_down(v[i], s, kWave);
+    E r;
+    unpack(v, r);
+    return r;
+}
+
+// strided (field-major) workspace I/O: value f of lane-slot t lives at ws[f * stride + t]
+template <typename E>
+__device__ __forceinline__ void ws_store(typename ElemTraits<E>::Scalar* ws, long stride, long t, const E& e) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+    pack(e, v);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) ws[i * stride + t] = v[i];
+}
+template <typename E>
+__device__ __forceinline__ void ws_load(const typename ElemTraits<E>::Scalar* ws, long stride, long t, E& e) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) v[i] = ws[i * stride + t];
+    unpack(v, e);
+}
+// record-major (AoS) I/O for spine entries
+template <typename E>
+__device__ __forceinline__ void rec_store(typename ElemTraits<E>::Scalar* p, const E& e) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+    pack(e, v);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) p[i] = v[i];
+}
+template <typename E>
+__device__ __forceinline__ void rec_load(const typename ElemTraits<E>::Scalar* p, E& e) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) v[i] = p[i];
+    unpack(v, e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// workgroup scans.  FORWARD: exclusive prefix over lanes (time order = lane order);
+// BACKWARD: exclusive suffix.  `lds` holds kWaves * N scalars.  Returns the exclusive value for
+// this lane in `excl` and the workgroup total in `total` (valid in every lane).
+// ---------------------------------------------------------------------------------------------
+template <typename E, bool FORWARD>
+__device__ __forceinline__ void block_scan_exclusive(const E& mine, E& excl, E& total,
+                                                     typename ElemTraits<E>::Scalar* lds) {
+    using TR = ElemTraits<E>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    E incl = mine;
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) {
+        E other = FORWARD ? shfl_up_elem(incl, s) : shfl_down_elem(incl, s);
+        const bool act = FORWARD ? (lane >= s) : (lane + s < kWave);
+        if (act) {
+            E r;
+            if (FORWARD) TR::combine(other, incl, r); else TR::combine(incl, other, r);
+            incl = r;
+        }
+    }
+    E wex = FORWARD ? shfl_up_elem(incl, 1) : shfl_down_elem(incl, 1);
+    if (FORWARD ? (lane == 0) : (lane == kWave - 1)) TR::identity(wex);
+    // wavefront totals to LDS
+    if (FORWARD ? (lane == kWave - 1) : (lane == 0)) {
+        typename TR::Scalar v[TR::N];
+        pack(incl, v);
+#pragma unroll
+        for (int i = 0; i < TR::N; ++i) lds[wave * TR::N + i] = v[i];
+    }
+    __syncthreads();
+    E acc;
+    TR::identity(acc);
+    excl = wex;
+    bool have = false;
+    if (FORWARD) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            E wt;
+            rec_load(lds + w * TR::N, wt);
+            if (w == wave && have) { E r; TR::combine(acc, wex, r); excl = r; }
+            if (have) { E r; TR::combine(acc, wt, r); acc = r; } else { acc = wt; have = true; }
+        }
+    } else {
+#pragma unroll
+        for (int w = kWaves - 1; w >= 0; --w) {
+            E wt;
+            rec_load(lds + w * TR::N, wt);
+            if (w == wave && have) { E r; TR::combine(wex, acc, r); excl = r; }
+            if (have) { E r; TR::combine(wt, acc, r); acc = r; } else { acc = wt; have = true; }
+        }
+    }
+    total = acc;
+    __syncthreads();
+}
+
+// Ordered reduction of one element per lane over the whole workgroup (lane order = time order).
+// The result is valid in every lane.
+template <typename E>
+__device__ __forceinline__ void block_reduce_ordered(const E& mine, E& total, typename ElemTraits<E>::Scalar* lds) {
+    using TR = ElemTraits<E>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    E acc = mine;
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) {
+        E other = shfl_down_elem(acc, s);
+        if ((lane & (2 * s - 1)) == 0) { E r; TR::combine(acc, other, r); acc = r; }
+    }
+    if (lane == 0) {
+        typename TR::Scalar v[TR::N];
+        pack(acc, v);
+#pragma unroll
+        for (int i = 0; i < TR::N; ++i) lds[wave * TR::N + i] = v[i];
+    }
+    __syncthreads();
+    rec_load(lds, total);
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) {
+        E wt, r;
+        rec_load(lds + w * TR::N, wt);
+        TR::combine(total, wt, r);
+        total = r;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double block_sum_double(double x, double* lds) {
+#pragma unroll
+    for (int s = kWave / 2; s > 0; s >>= 1) x += __shfl_down(x, s, kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    if (lane == 0) lds[wave] = x;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) t += lds[w];
+    __syncthreads();
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-F1: filter reduce
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void k_filter_reduce(const ScanArgs<T> a) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM;
+    using FE = FiltElem<T, D>;
+    __shared__ T lds[kWaves * Dim<D>::NFILT];
+
+    T h[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) h[i] = a.H[i];
+
+    const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long k0 = gt * a.Lc;
+    const long k1 = min(a.N, k0 + a.Lc);
+
+    FE agg;
+    filt_identity(agg);
+    if (k0 < k1) {
+        T Fn[MAT], Qn[MAT];
+        T yn;
+        load_rec<T, MAT>(a.Fs + k0 * MAT, Fn);
+        load_rec<T, MAT>(a.Qs + k0 * MAT, Qn);
+        yn = a.ys[k0];
+        for (long k = k0; k < k1; ++k) {
+            T F[MAT], Q[SYM];
+#pragma unroll
+            for (int i = 0; i < MAT; ++i) F[i] = Fn[i];
+            sym_from_full<T, D>(Qn, Q);
+            const T y = yn;
+            if (k + 1 < k1) {
+                load_rec<T, MAT>(a.Fs + (k + 1) * MAT, Fn);
+                load_rec<T, MAT>(a.Qs + (k + 1) * MAT, Qn);
+                yn = a.ys[k + 1];
+            }
+            if (k == 0 && a.seg_first) {
+                T P0f[MAT], P0[SYM];
+#pragma unroll
+                for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
+                sym_from_full<T, D>(P0f, P0);
+                filt_first(agg, P0, y, h, a.R);
+            } else {
+                filt_extend(agg, F, Q, y, h, a.R);
+            }
+        }
+    }
+    FE excl, total;
+    block_scan_exclusive<FE, true>(agg, excl, total, lds);
+    ws_store(a.lpre, a.nlanes, gt, excl);
+    if (threadIdx.x == 0) rec_store(a.spine + (long)blockIdx.x * Dim<D>::NFILT, total);
+}
+
+// Fold spine entries [lo, hi) in time order over the whole workgroup; result in every lane.
+template <typename E>
+__device__ __forceinline__ void fold_spine(const typename ElemTraits<E>::Scalar* spine, int lo, int hi, E& total,
+                                           typename ElemTraits<E>::Scalar* lds) {
+    using TR = ElemTraits<E>;
+    const int n = hi - lo;
+    const int per = (n + kBlock - 1) / kBlock;
+    E acc;
+    TR::identity(acc);
+    const int b0 = lo + (int)threadIdx.x * per;
+    const int b1 = min(hi, b0 + per);
+    bool have = false;
+    for (int b = b0; b < b1; ++b) {
+        E e;
+        rec_load(spine + (long)b * TR::N, e);
+        if (have) { E r; TR::combine(acc, e, r); acc = r; } else { acc = e; have = true; }
+    }
+    block_reduce_ordered(acc, total, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-F3: filter apply (+ log-likelihood, + fused smoothing-aggregate build when SMOOTH)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, bool SMOOTH>
+__global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT;
+    using FE = FiltElem<T, D>;
+    using SE = SmthElem<T, D>;
+    using MC = MeanCov<T, D>;
+    __shared__ T lds[kWaves * NF];
+    __shared__ double lds_ll[kWaves];
+
+    T h[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) h[i] = a.H[i];
+
+    const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long k0 = gt * a.Lc;
+    const long k1 = min(a.N, k0 + a.Lc);
+
+    // state entering this segment
+    MC s;
+    if (a.seg_first) {
+        T P0f[MAT];
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] = T(0);
+        sym_from_full<T, D>(P0f, s.P);
+    } else {
+        T Pf[MAT];
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] = a.carry_in[i];
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) Pf[i] = a.carry_in[D + i];
+        sym_from_full<T, D>(Pf, s.P);
+    }
+    // ... pushed through the workgroups to the left, then through this lane's local prefix
+    if (blockIdx.x > 0) {
+        FE left;
+        fold_spine<FE>(a.spine, 0, (int)blockIdx.x, left, lds);
+        filt_apply(s, left);
+    }
+    {
+        FE lp;
+        ws_load(a.lpre, a.nlanes, gt, lp);
+        filt_apply(s, lp);
+    }
+
+    LogLik ll;
+    SE sagg;
+    smth_identity(sagg);
+
+    if (k0 < k1) {
+        T Fn[MAT], Qn[MAT];
+        T yn;
+        load_rec<T, MAT>(a.Fs + k0 * MAT, Fn);
+        load_rec<T, MAT>(a.Qs + k0 * MAT, Qn);
+        yn = a.ys[k0];
+        MC prev = s;
+        for (long k = k0; k < k1; ++k) {
+            T F[MAT], Q[SYM];
+#pragma unroll
+            for (int i = 0; i < MAT; ++i) F[i] = Fn[i];
+            sym_from_full<T, D>(Qn, Q);
+            const T y = yn;
+            if (k + 1 < a.N) {                      // next step (the halo step k1 included)
+                if (SMOOTH || k + 1 < k1) {
+                    load_rec<T, MAT>(a.Fs + (k + 1) * MAT, Fn);
+                    load_rec<T, MAT>(a.Qs + (k + 1) * MAT, Qn);
+                }
+                if (k + 1 < k1) yn = a.ys[k + 1];
+            }
+            T mp[D], Pp[SYM], FP[MAT];
+            kf_step(s, F, Q, y, h, a.R, (k == 0) && a.seg_first, ll, mp, Pp, FP);
+            if (SMOOTH && k > k0) {                 // element of step k-1 from this step's predict
+                SE e, r;
+                smth_element(prev, mp, Pp, FP, e);
+                smth_combine(sagg, e, r);
+                sagg = r;
+            }
+            store_rec<T, D>(a.fms + k * D, s.m);
+            {
+                T Pf[MAT];
+                full_from_sym<T, D>(s.P, Pf);
+                store_rec<T, MAT>(a.fPs + k * MAT, Pf);
+            }
+            prev = s;
+        }
+        if (SMOOTH) {
+            // element of this chunk's last step: needs the predict of step k1
+            SE e, r;
+            if (k1 < a.N || !a.seg_last) {
+                T F[MAT], Qf[MAT], Q[SYM];
+                if (k1 < a.N) {
+#pragma unroll
+                    for (int i = 0; i < MAT; ++i) { F[i] = Fn[i]; Qf[i] = Qn[i]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MAT; ++i) { F[i] = a.halo_FQ[i]; Qf[i] = a.halo_FQ[MAT + i]; }
+                }
+                sym_from_full<T, D>(Qf, Q);
+                T mp[D], Pp[SYM], FP[MAT];
+                mat_vec<T, D>(F, s.m, mp);
+                predict_cov<T, D>(F, s.P, Q, FP, Pp);
+                smth_element(s, mp, Pp, FP, e);
+            } else {
+                smth_last(s, e);
+            }
+            smth_combine(sagg, e, r);
+            sagg = r;
+        }
+    }
+
+    // log-likelihood partial of this workgroup
+    {
+        const double v = -0.5 * (double(ll.count) * 1.8378770664093453 + ll.logdet + ll.quad);
+        const double t = block_sum_double(v, lds_ll);
+        if (threadIdx.x == 0) a.llpart[blockIdx.x] = t;
+    }
+
+    if (SMOOTH) {
+        SE excl, total;
+        block_scan_exclusive<SE, false>(sagg, excl, total, lds);
+        ws_store(a.lsuf, a.nlanes, gt, excl);
+        if (threadIdx.x == 0) rec_store(a.sspine + (long)blockIdx.x * Dim<D>::NSMTH, total);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-S1: smoother reduce (stand-alone pks only; pkfs gets the aggregates from k_filter_apply)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void k_smoother_reduce(const ScanArgs<T> a) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM;
+    using SE = SmthElem<T, D>;
+    using MC = MeanCov<T, D>;
+    __shared__ T lds[kWaves * Dim<D>::NSMTH];
+
+    const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long k0 = gt * a.Lc;
+    const long k1 = min(a.N, k0 + a.Lc);
+    SE sagg;
+    smth_identity(sagg);
+    for (long k = k0; k < k1; ++k) {
+        MC f;
+        T Pf[MAT];
+        load_rec<T, D>(a.fms + k * D, f.m);
+        load_rec<T, MAT>(a.fPs + k * MAT, Pf);
+        sym_from_full<T, D>(Pf, f.P);
+        SE e, r;
+        if (k + 1 < a.N || !a.seg_last) {
+            T F[MAT], Qf[MAT], Q[SYM];
+            if (k + 1 < a.N) {
+                load_rec<T, MAT>(a.Fs + (k + 1) * MAT, F);
+                load_rec<T, MAT>(a.Qs + (k + 1) * MAT, Qf);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MAT; ++i) { F[i] = a.halo_FQ[i]; Qf[i] = a.halo_FQ[MAT + i]; }
+            }
+            sym_from_full<T, D>(Qf, Q);
+            T mp[D], Pp[SYM], FP[MAT];
+            mat_vec<T, D>(F, f.m, mp);
+            predict_cov<T, D>(F, f.P, Q, FP, Pp);
+            smth_element(f, mp, Pp, FP, e);
+        } else {
+            smth_last(f, e);
+        }
+        smth_combine(sagg, e, r);
+        sagg = r;
+    }
+    SE excl, total;
+    block_scan_exclusive<SE, false>(sagg, excl, total, lds);
+    ws_store(a.lsuf, a.nlanes, gt, excl);
+    if (threadIdx.x == 0) rec_store(a.sspine + (long)blockIdx.x * Dim<D>::NSMTH, total);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-S3: smoother apply
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM, NS = Dim<D>::NSMTH;
+    using SE = SmthElem<T, D>;
+    using MC = MeanCov<T, D>;
+    __shared__ T lds[kWaves * NS];
+    __shared__ double lds_ll[kWaves];
+
+    const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long k0 = gt * a.Lc;
+    const long k1 = min(a.N, k0 + a.Lc);
+
+    // smoothed state of the first step AFTER this segment (irrelevant when seg_last: E = 0 there)
+    MC s;
+    if (a.seg_last) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] = T(0);
+#pragma unroll
+        for (int i = 0; i < SYM; ++i) s.P[i] = T(0);
+    } else {
+        T Pf[MAT];
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] = a.carry_back[i];
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) Pf[i] = a.carry_back[D + i];
+        sym_from_full<T, D>(Pf, s.P);
+    }
+    if ((int)blockIdx.x + 1 < a.nblocks) {
+        SE right;
+        fold_spine<SE>(a.sspine, (int)blockIdx.x + 1, a.nblocks, right, lds);
+        smth_apply(right, s);
+    }
+    {
+        SE ls;
+        ws_load(a.lsuf, a.nlanes, gt, ls);
+        smth_apply(ls, s);
+    }
+
+    if (k0 < k1) {
+        // step k needs (F, Q) of step k+1 and the filtered (m, P) of step k
+        T Fn[MAT], Qn[MAT], mn[D], Pn[MAT];
+        const bool end_of_series = (k1 == a.N) && a.seg_last;
+        if (k1 < a.N) {
+            load_rec<T, MAT>(a.Fs + k1 * MAT, Fn);
+            load_rec<T, MAT>(a.Qs + k1 * MAT, Qn);
+        } else if (!a.seg_last) {
+#pragma unroll
+            for (int i = 0; i < MAT; ++i) { Fn[i] = a.halo_FQ[i]; Qn[i] = a.halo_FQ[MAT + i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAT; ++i) { Fn[i] = T(0); Qn[i] = T(0); }
+        }
+        load_rec<T, D>(a.fms + (k1 - 1) * D, mn);
+        load_rec<T, MAT>(a.fPs + (k1 - 1) * MAT, Pn);
+        for (long k = k1 - 1; k >= k0; --k) {
+            T F[MAT], Q[SYM];
+            MC f;
+#pragma unroll
+            for (int i = 0; i < MAT; ++i) F[i] = Fn[i];
+            sym_from_full<T, D>(Qn, Q);
+#pragma unroll
+            for (int i = 0; i < D; ++i) f.m[i] = mn[i];
+            sym_from_full<T, D>(Pn, f.P);
+            if (k > k0) {
+                load_rec<T, MAT>(a.Fs + k * MAT, Fn);
+                load_rec<T, MAT>(a.Qs + k * MAT, Qn);
+                load_rec<T, D>(a.fms + (k - 1) * D, mn);
+                load_rec<T, MAT>(a.fPs + (k - 1) * MAT, Pn);
+            }
+            if (end_of_series && k == k1 - 1) {
+                s = f;                              // last element: (0, m_N, P_N)
+            } else {
+                T mp[D], Pp[SYM], FP[MAT];
+                mat_vec<T, D>(F, f.m, mp);
+                predict_cov<T, D>(F, f.P, Q, FP, Pp);
+                rts_step(f, mp, Pp, FP, s);
+            }
+            store_rec<T, D>(a.sms + k * D, s.m);
+            T Pf[MAT];
+            full_from_sym<T, D>(s.P, Pf);
+            store_rec<T, MAT>(a.sPs + k * MAT, Pf);
+        }
+    }
+
+    if (blockIdx.x == 0 && a.ll != nullptr) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < a.nblocks; b += kBlock) v += a.llpart[b];
+        const double t = block_sum_double(v, lds_ll);
+        if (threadIdx.x == 0) *a.ll = t;
+    }
+}
+
+// log-likelihood reduction for the filter-only entry point
+static __global__ __launch_bounds__(kBlock) void k_ll_finalize(const double* llpart, int nblocks, double* ll) {
+    __shared__ double lds_ll[kWaves];
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) v += llpart[b];
+    const double t = block_sum_double(v, lds_ll);
+    if (threadIdx.x == 0) *ll = t;
+}
+
+}  // namespace pgps

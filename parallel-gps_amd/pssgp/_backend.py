@@ -1,0 +1,274 @@
+"""ctypes binding of libpgps.so (include/pgps.h) -- the only way pssgp reaches the GPU.
+
+There is no CPU fallback: if the library is missing or no MI355X is visible the calls raise.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get("PGPS_LIB", os.path.join(_HERE, "libpgps.so"))
+
+PGPS_OK = 0
+PGPS_K_NAMES = None
+
+c_void_p, c_int, c_long, c_double, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long,
+                                              ctypes.c_double, ctypes.c_float)
+
+
+class PgpsError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        super().__init__(f"libpgps: {what} (code {code}){': ' + detail if detail else ''}")
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def _declare(lib):
+    P = c_void_p
+    lib.pgps_version.restype = c_int
+    lib.pgps_strerror.restype = ctypes.c_char_p
+    lib.pgps_strerror.argtypes = [c_int]
+    lib.pgps_last_hip_error.restype = ctypes.c_char_p
+    lib.pgps_last_hip_error.argtypes = [P]
+    lib.pgps_kernel_name.restype = ctypes.c_char_p
+    lib.pgps_kernel_name.argtypes = [c_int]
+    lib.pgps_device_count.argtypes = [ctypes.POINTER(c_int)]
+    lib.pgps_create.argtypes = [c_int, ctypes.POINTER(P)]
+    lib.pgps_destroy.argtypes = [P]
+    lib.pgps_set_stream.argtypes = [P, P]
+    lib.pgps_synchronize.argtypes = [P]
+    lib.pgps_set_chunk.argtypes = [P, c_int]
+    lib.pgps_get_chunk.argtypes = [P, c_long, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    lib.pgps_malloc.argtypes = [P, ctypes.c_size_t, ctypes.POINTER(P)]
+    lib.pgps_free.argtypes = [P, P]
+    lib.pgps_memcpy_h2d.argtypes = [P, P, P, ctypes.c_size_t]
+    lib.pgps_memcpy_d2h.argtypes = [P, P, P, ctypes.c_size_t]
+    lib.pgps_profile_enable.argtypes = [P, c_int]
+    lib.pgps_profile_read.argtypes = [P, ctypes.POINTER(c_double), ctypes.POINTER(c_long), c_int]
+    for suf, real in (("f64", c_double), ("f32", c_float)):
+        for dev in ("", "_dev"):
+            getattr(lib, f"pgps_discretise{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, real, P, P]
+            getattr(lib, f"pgps_pkf{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, real, P, P, P, P]
+            getattr(lib, f"pgps_pks{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, P, P]
+            getattr(lib, f"pgps_pkfs{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, real, P, P, P, P, P, P]
+    return lib
+
+
+def load_library():
+    """Load libpgps.so (once).  Raises if it has not been built (`python __graft_entry__.py`)."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise PgpsError(-100, "library not built", f"{_LIB_PATH} missing; run "
+                                "`make -C parallel-gps_amd/csrc` (or __graft_entry__.build())")
+            _lib = _declare(ctypes.CDLL(_LIB_PATH))
+        return _lib
+
+
+def check(ctx, code, what):
+    if code != PGPS_OK:
+        lib = load_library()
+        msg = lib.pgps_strerror(code).decode()
+        detail = lib.pgps_last_hip_error(ctx.handle).decode() if ctx is not None and code == -3 else ""
+        raise PgpsError(code, f"{what}: {msg}", detail)
+
+
+class Context:
+    """One libpgps context = one GPU + one stream + scratch.  Not thread-safe per instance."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        n = c_int(0)
+        self.lib.pgps_device_count(ctypes.byref(n))
+        if n.value <= 0:
+            raise PgpsError(-6, "no HIP device visible: the parallel path needs an MI355X (there is no CPU fallback)")
+        self.handle = c_void_p()
+        code = self.lib.pgps_create(int(device), ctypes.byref(self.handle))
+        if code != PGPS_OK:
+            raise PgpsError(code, "pgps_create: " + self.lib.pgps_strerror(code).decode())
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.pgps_destroy(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- knobs ---------------------------------------------------------------------------
+    def set_chunk(self, steps_per_lane):
+        check(self, self.lib.pgps_set_chunk(self.handle, int(steps_per_lane)), "pgps_set_chunk")
+
+    def get_chunk(self, n_steps):
+        lc, nb = c_int(0), c_int(0)
+        check(self, self.lib.pgps_get_chunk(self.handle, int(n_steps), ctypes.byref(lc), ctypes.byref(nb)),
+              "pgps_get_chunk")
+        return lc.value, nb.value
+
+    def set_stream(self, hip_stream_handle):
+        check(self, self.lib.pgps_set_stream(self.handle, c_void_p(hip_stream_handle or 0)), "pgps_set_stream")
+
+    def synchronize(self):
+        check(self, self.lib.pgps_synchronize(self.handle), "pgps_synchronize")
+
+    def profile_enable(self, mask=0x3f):
+        """mask: bit i = time every launch of kernel slot i (PGPS_K_*); 0 = off."""
+        check(self, self.lib.pgps_profile_enable(self.handle, int(mask)), "pgps_profile_enable")
+
+    def profile_read(self, reset=True):
+        k = 6
+        ms = (c_double * k)()
+        cnt = (c_long * k)()
+        check(self, self.lib.pgps_profile_read(self.handle, ms, cnt, int(bool(reset))), "pgps_profile_read")
+        return {self.lib.pgps_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(k)}
+
+    # -- raw device memory -----------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = c_void_p()
+        check(self, self.lib.pgps_malloc(self.handle, int(nbytes), ctypes.byref(p)), "pgps_malloc")
+        return p.value
+
+    def free(self, ptr):
+        check(self, self.lib.pgps_free(self.handle, c_void_p(ptr)), "pgps_free")
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self, self.lib.pgps_memcpy_h2d(self.handle, c_void_p(dptr), arr.ctypes.data_as(c_void_p), arr.nbytes),
+              "pgps_memcpy_h2d")
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(self, self.lib.pgps_memcpy_d2h(self.handle, arr.ctypes.data_as(c_void_p), c_void_p(dptr), arr.nbytes),
+              "pgps_memcpy_d2h")
+
+    # -- generic call by name ----------------------------------------------------------------
+    def call(self, name, *args):
+        check(self, getattr(self.lib, name)(self.handle, *args), name)
+
+
+_contexts = {}
+_ctx_lock = threading.Lock()
+
+
+def get_context(device=0):
+    with _ctx_lock:
+        ctx = _contexts.get(device)
+        if ctx is None:
+            ctx = _contexts[device] = Context(device)
+        return ctx
+
+
+def _suffix(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "f64", c_double
+    if dtype == np.float32:
+        return "f32", c_float
+    raise TypeError(f"unsupported dtype {dtype}; use float32 or float64")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def _prep(a, dtype, shape=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def discretise(F, Pinf, ts, t0=0.0, device=0):
+    """Fs, Qs = expm(dt F), Pinf - Fs Pinf Fs^T on the GPU (host arrays in and out)."""
+    dtype = np.asarray(ts).dtype if np.asarray(ts).dtype in (np.float32, np.float64) else np.float64
+    suf, real = _suffix(dtype)
+    F = _prep(F, dtype)
+    d = F.shape[0]
+    Pinf = _prep(Pinf, dtype, (d, d))
+    ts = _prep(ts, dtype, (-1,))
+    N = ts.shape[0]
+    Fs = np.empty((N, d, d), dtype)
+    Qs = np.empty((N, d, d), dtype)
+    get_context(device).call(f"pgps_discretise_{suf}", c_long(N), c_int(d), _ptr(F), _ptr(Pinf), _ptr(ts),
+                             real(float(t0)), _ptr(Fs), _ptr(Qs))
+    return Fs, Qs
+
+
+def _unpack_lgssm(lgssm, dtype):
+    P0, Fs, Qs, H, R = lgssm
+    Fs = _prep(Fs, dtype)
+    N, d = Fs.shape[0], Fs.shape[1]
+    return (_prep(P0, dtype, (d, d)), Fs, _prep(Qs, dtype, (N, d, d)), _prep(H, dtype, (d,)),
+            float(np.asarray(R).reshape(())), N, d)
+
+
+def _dtype_of(lgssm):
+    dt = np.asarray(lgssm[1]).dtype
+    return dt if dt in (np.float32, np.float64) else np.dtype(np.float64)
+
+
+def pkf(lgssm, observations, return_loglikelihood=False, device=0):
+    dtype = _dtype_of(lgssm)
+    suf, real = _suffix(dtype)
+    P0, Fs, Qs, H, R, N, d = _unpack_lgssm(lgssm, dtype)
+    ys = _prep(observations, dtype, (-1,))
+    if ys.shape[0] != N:
+        raise ValueError(f"observations has {ys.shape[0]} rows, the model {N} steps")
+    fms = np.empty((N, d), dtype)
+    fPs = np.empty((N, d, d), dtype)
+    ll = c_double(0.0)
+    get_context(device).call(f"pgps_pkf_{suf}", c_long(N), c_int(d), _ptr(P0), _ptr(Fs), _ptr(Qs), _ptr(H), real(R),
+                             _ptr(ys), _ptr(fms), _ptr(fPs),
+                             ctypes.cast(ctypes.byref(ll), c_void_p) if return_loglikelihood else None)
+    if return_loglikelihood:
+        return fms, fPs, np.asarray(ll.value, dtype=dtype)
+    return fms, fPs
+
+
+def pks(lgssm, ms, Ps, device=0):
+    dtype = _dtype_of(lgssm)
+    suf, _ = _suffix(dtype)
+    _, Fs, Qs, *_ = lgssm
+    Fs = _prep(Fs, dtype)
+    N, d = Fs.shape[0], Fs.shape[1]
+    Qs = _prep(Qs, dtype, (N, d, d))
+    ms = _prep(ms, dtype, (N, d))
+    Ps = _prep(Ps, dtype, (N, d, d))
+    sms = np.empty((N, d), dtype)
+    sPs = np.empty((N, d, d), dtype)
+    get_context(device).call(f"pgps_pks_{suf}", c_long(N), c_int(d), _ptr(Fs), _ptr(Qs), _ptr(ms), _ptr(Ps),
+                             _ptr(sms), _ptr(sPs))
+    return sms, sPs
+
+
+def pkfs(lgssm, observations, return_filtered=False, return_loglikelihood=False, device=0):
+    dtype = _dtype_of(lgssm)
+    suf, real = _suffix(dtype)
+    P0, Fs, Qs, H, R, N, d = _unpack_lgssm(lgssm, dtype)
+    ys = _prep(observations, dtype, (-1,))
+    if ys.shape[0] != N:
+        raise ValueError(f"observations has {ys.shape[0]} rows, the model {N} steps")
+    fms = np.empty((N, d), dtype) if return_filtered else None
+    fPs = np.empty((N, d, d), dtype) if return_filtered else None
+    sms = np.empty((N, d), dtype)
+    sPs = np.empty((N, d, d), dtype)
+    ll = c_double(0.0)
+    get_context(device).call(f"pgps_pkfs_{suf}", c_long(N), c_int(d), _ptr(P0), _ptr(Fs), _ptr(Qs), _ptr(H), real(R),
+                             _ptr(ys), _ptr(fms), _ptr(fPs), _ptr(sms), _ptr(sPs),
+                             ctypes.cast(ctypes.byref(ll), c_void_p))
+    out = (sms, sPs)
+    if return_filtered:
+        out += (fms, fPs)
+    if return_loglikelihood:
+        out += (np.asarray(ll.value, dtype=dtype),)
+    return out

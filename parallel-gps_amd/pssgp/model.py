@@ -1,0 +1,104 @@
+"""StateSpaceGP: GP regression through the state-space form of the kernel.
+
+Mirrors pssgp/model.py:58-117 of the reference: same constructor, `predict_f`,
+`maximum_log_likelihood_objective`, `training_loss`; `parallel=True` runs the HIP
+associative-scan path (csrc/), `parallel=False` the sequential host recursion.  Data and
+results are numpy arrays; hyper-parameters are plain floats (no GPflow `Parameter`s, no
+autodiff in this tier -- SURVEY.md section 8f).
+"""
+import numpy as np
+
+from . import config
+from .kalman.parallel import pkf, pkfs
+from .kalman.sequential import kf, kfs
+
+
+def _merge_sorted(a, b, *args):
+    """Merge two sorted 1-D arrays and any number of (a_x, b_x) payload pairs.
+
+    As pssgp/model.py:15-55: the shorter array is scattered into the longer at
+    arange + searchsorted(longer, shorter) (left side: on ties the shorter array's
+    point comes first).
+    """
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.ndim == b.ndim == 1
+    if a.shape[0] < b.shape[0]:
+        a, b = b, a
+        args = tuple((j, i) for i, j in args)
+    n_long, n_short = a.shape[0], b.shape[0]
+    where_short = np.arange(n_short) + np.searchsorted(a, b, side="left")
+    from_long = np.ones(n_long + n_short, dtype=bool)
+    from_long[where_short] = False
+
+    def weave(u, v):
+        u, v = np.asarray(u), np.asarray(v)
+        out = np.empty((n_long + n_short,) + u.shape[1:], dtype=np.result_type(u, v))
+        out[from_long] = u
+        out[where_short] = v
+        return out
+
+    return (weave(a, b),) + tuple(weave(i, j) for i, j in args)
+
+
+class StateSpaceGP:
+    def __init__(self, data, kernel, noise_variance=1.0, parallel=False, max_parallel=10000):
+        self.noise_variance = float(noise_variance)
+        dtype = config.default_float()
+        ts, ys = data
+        ts = np.asarray(ts, dtype=dtype)
+        ys = np.asarray(ys, dtype=dtype)
+        if ts.ndim == 1:
+            ts = ts[:, None]
+        if ys.ndim == 1:
+            ys = ys[:, None]
+        if ys.shape[1] != 1:
+            raise ValueError("only single-output observations are supported (pssgp/model.py:72)")
+        self.kernel = kernel
+        self.data = ts, ys
+        self.num_latent_gps = ys.shape[-1]
+        self.parallel = bool(parallel)
+        self.max_parallel = max_parallel
+        if not parallel:
+            self._kf = lambda ssm, y: kf(ssm, y, return_loglikelihood=True, return_predicted=False)
+            self._kfs = kfs
+        else:
+            self._kf = lambda ssm, y: pkf(ssm, y, return_loglikelihood=True, max_parallel=ts.shape[0])
+            self._kfs = lambda ssm, y: pkfs(ssm, y, max_parallel=max_parallel)
+
+    def _make_model(self, ts):
+        R = np.reshape(np.asarray(self.noise_variance, dtype=config.default_float()), (1, 1))
+        return self.kernel.get_ssm(ts, R)
+
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
+        """Posterior mean (K, 1) and variance (K, 1) at `Xnew` (pssgp/model.py:92-111):
+        merge train and query times, mark queries as missing, smooth, keep the query rows,
+        project through H."""
+        ts, ys = self.data
+        dtype = config.default_float()
+        Xnew = np.asarray(Xnew, dtype=dtype)
+        squeezed_ts = ts.reshape(-1)
+        squeezed_Xnew = Xnew.reshape(-1)
+        nan_ys = np.full((squeezed_Xnew.shape[0], ys.shape[1]), np.nan, dtype=ys.dtype)
+        all_ts, all_ys, all_flags = _merge_sorted(
+            squeezed_ts, squeezed_Xnew, (ys, nan_ys),
+            (np.zeros(squeezed_ts.shape, dtype=bool), np.ones(squeezed_Xnew.shape, dtype=bool)))
+        ssm = self._make_model(all_ts[:, None])
+        sms, sPs = self._kfs(ssm, all_ys)
+        sm, sP = sms[all_flags], sPs[all_flags]
+        H = np.asarray(ssm.H)
+        mean = sm @ H.T
+        var = np.einsum("ai,nij,aj->na", H, sP, H)
+        return mean, var
+
+    def maximum_log_likelihood_objective(self):
+        ts, Y = self.data
+        ssm = self._make_model(ts)
+        _, _, ll = self._kf(ssm, Y)
+        return ll
+
+    def log_posterior_density(self):
+        return self.maximum_log_likelihood_objective()
+
+    def training_loss(self):
+        return -self.maximum_log_likelihood_objective()

@@ -1,0 +1,77 @@
+"""Generates the golden fixtures under tests/golden/ from the CPU oracle.
+
+The reference (TensorFlow 2.6 / TFP 0.13 / GPflow 2.2.1) cannot be imported in the build
+container, so the vectors come from the oracle's DENSE GP (independent of all state-space code;
+it is what the reference's tests compare against, tests/test_gp_vs_kfs.py) and from the
+oracle's sequential Kalman restatement for the kernels the dense GP cannot pin exactly.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "parallel-gps_amd"))
+
+from oracle import np_oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def c1():
+    """BASELINE.json configs[0]: Matern-3/2, N = 4096 training points + 1024 queries, fp64."""
+    from pssgp.kernels import Matern32
+    rng = np.random.default_rng(0)
+    n, k = 4096, 1024
+    t = np.cumsum(0.05 * rng.uniform(0.5, 1.5, n))
+    var, ell, noise = 1.0, 1.0, 0.1
+    sde = Matern32(var, ell).get_sde()
+    ssm = O.get_ssm(sde, t, noise)
+    # latent from the model's own prior
+    x = np.linalg.cholesky(ssm[0]) @ rng.standard_normal(2)
+    y = np.empty(n)
+    for i in range(n):
+        Q = 0.5 * (ssm[2][i] + ssm[2][i].T)
+        w, V = np.linalg.eigh(Q)
+        x = ssm[1][i] @ x + (V * np.sqrt(np.clip(w, 0, None))) @ rng.standard_normal(2)
+        y[i] = x[0] + np.sqrt(noise) * rng.standard_normal()
+    tq = np.sort(rng.uniform(t[0], t[-1], k))
+    ll, mean, var_q = O.dense_gp(("matern32", var, ell), t, y, noise, tq)
+    np.savez_compressed(os.path.join(HERE, "c1_matern32_n4096.npz"), t=t, y=y, tq=tq, variance=var,
+                        lengthscale=ell, noise=noise, ll_dense=ll, mean_dense=mean, var_dense=var_q)
+    print("c1: ll =", ll)
+
+
+def small_d():
+    """Sequential-oracle outputs (N = 1024, 20 % missing) for d = 6 (RBF order 6, config c3's
+    kernel) and d = 5 / 6 composite kernels; stored so the GPU tests can check them without
+    recomputing, and so oracle drift is caught."""
+    from pssgp.kernels import RBF, Matern32, Matern52
+    rng = np.random.default_rng(1)
+    n = 1024
+    t = np.cumsum(0.05 * rng.uniform(0.5, 1.5, n))
+    out = {"t": t}
+    kernels = {"rbf6": RBF(1., 1., order=6, balancing_iter=10), "m32+m52": Matern32(1., 1.) + Matern52(1., 1.),
+               "m32*m52": Matern32(1., 1.) * Matern52(1., 1.)}
+    y = np.sin(0.9 * t) + 0.3 * rng.standard_normal(n)
+    y[rng.random(n) < 0.2] = np.nan
+    out["y"] = y
+    for name, k in kernels.items():
+        ssm = O.get_ssm(k.get_sde(), t, 0.1)
+        fms, fPs, ll = O.kf(ssm, y, True)
+        sms, sPs = O.kfs(ssm, y)
+        h = ssm[3].reshape(-1)
+        out[name + "/ll"] = ll
+        out[name + "/fmean"] = fms @ h
+        out[name + "/smean"] = sms @ h
+        out[name + "/svar"] = np.einsum("i,nij,j->n", h, sPs, h)
+    np.savez_compressed(os.path.join(HERE, "small_d_n1024.npz"), **out)
+    print("small_d done")
+
+
+if __name__ == "__main__":
+    c1()
+    small_d()

@@ -1,0 +1,73 @@
+"""The C-ABI library loads and exports every symbol include/pgps.h declares; error paths that
+need no GPU; the sequential (parallel=False) host mode against the oracle.  No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests.conftest import make_times, relerr, sample_series
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pssgp import _backend
+    return _backend.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "pgps.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(pgps_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_version_and_strerror(lib):
+    assert lib.pgps_version() >= 100
+    assert lib.pgps_strerror(0).decode() == "ok"
+    assert "dimension" in lib.pgps_strerror(-2).decode()
+    for i, name in enumerate(["k_filter_reduce", "k_filter_apply", "k_smoother_reduce", "k_smoother_apply",
+                              "k_ll_finalize", "k_discretise"]):
+        assert lib.pgps_kernel_name(i).decode() == name
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a GPU the parallel path must raise, not compute somewhere else."""
+    from pssgp import _backend
+    n = ctypes.c_int(-1)
+    assert lib.pgps_device_count(ctypes.byref(n)) == 0
+    if n.value > 0:
+        pytest.skip("a GPU is visible here")
+    from pssgp.kalman.parallel import pkf
+    from pssgp.kernels import Matern32
+    ssm = O.get_ssm(Matern32().get_sde(), make_times(10), 0.1)
+    with pytest.raises(_backend.PgpsError):
+        pkf(ssm, np.zeros(10))
+    h = ctypes.c_void_p()
+    assert lib.pgps_create(0, ctypes.byref(h)) == -6          # PGPS_E_NO_DEVICE
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sequential_mode_matches_oracle(dtype):
+    """kf / ks / kfs (parallel=False): host C++ in libpgps vs the numpy oracle."""
+    from pssgp.kalman.sequential import kf, kfs
+    from pssgp.kernels import Matern52, RBF
+    for k in (Matern52(1., 0.6), RBF(1., 0.8, order=8, balancing_iter=10)):
+        t = make_times(600, seed=4)
+        ssm = O.get_ssm(k.get_sde(), t, 0.1)
+        y = sample_series(ssm, seed=4, nan_frac=0.2)
+        ssm_t = tuple(np.asarray(a, dtype) for a in ssm)
+        fms, fPs, ll, mps, Pps = kf(ssm_t, y[:, None].astype(dtype), True, True)
+        sms, sPs = kfs(ssm_t, y.astype(dtype))
+        of, oP, oll = O.kf(ssm, y, True)
+        os_, osP = O.kfs(ssm, y)
+        tol = 1e-10 if dtype == np.float64 else 2e-3
+        assert relerr(fms, of) < tol and relerr(fPs, oP) < tol
+        assert relerr(sms, os_) < tol and relerr(sPs, osP) < tol
+        assert abs(float(ll) - oll) < tol * abs(oll)
