@@ -132,6 +132,38 @@ int pgps_pkfs_dev_f32(pgps_ctx*, long N, int d, const float* P0, const float* Fs
                       const float* H, float R, const float* ys, float* fms, float* fPs, float* sms,
                       float* sPs, double* ll);
 
+/* ---- one series sharded over several GPUs (contiguous time segments) -------------------
+ * No reference equivalent (the reference is single-device).  Rank r of
+ * `nranks` owns steps [r*N, (r+1)*N) -- every rank passes its own N -- and calls, in order:
+ *   1. pgps_seg_filter_reduce_dev   -> rec_f  (pgps_seg_record_len: rec_filter elements)
+ *      caller all-gathers rec_f over the ranks -> gathered_f (nranks, rec_filter)
+ *   2. pgps_seg_filter_apply_dev    -> fms, fPs, rec_s (rec_smoother elements)
+ *      caller all-gathers rec_s -> gathered_s (nranks, rec_smoother)
+ *   3. pgps_seg_smoother_apply_dev  -> sms, sPs, ll (log-likelihood of the WHOLE series)
+ * The three calls of one pass must use the same context, N and d (they share its scratch).
+ * rec_f = [segment total (A, b, C, J, eta) | F, Q of the segment's first step];
+ * rec_s = [segment total (E, g, L) | pad | the segment's log-likelihood as a double]. */
+int pgps_seg_record_len(int d, int* rec_filter, int* rec_smoother);
+int pgps_seg_filter_reduce_dev_f64(pgps_ctx*, long N, int d, int rank, int nranks, const double* P0,
+                                   const double* Fs, const double* Qs, const double* H, double R,
+                                   const double* ys, double* rec_f);
+int pgps_seg_filter_reduce_dev_f32(pgps_ctx*, long N, int d, int rank, int nranks, const float* P0,
+                                   const float* Fs, const float* Qs, const float* H, float R, const float* ys,
+                                   float* rec_f);
+int pgps_seg_filter_apply_dev_f64(pgps_ctx*, long N, int d, int rank, int nranks, const double* P0,
+                                  const double* Fs, const double* Qs, const double* H, double R,
+                                  const double* ys, const double* gathered_f, double* fms, double* fPs,
+                                  double* rec_s);
+int pgps_seg_filter_apply_dev_f32(pgps_ctx*, long N, int d, int rank, int nranks, const float* P0,
+                                  const float* Fs, const float* Qs, const float* H, float R, const float* ys,
+                                  const float* gathered_f, float* fms, float* fPs, float* rec_s);
+int pgps_seg_smoother_apply_dev_f64(pgps_ctx*, long N, int d, int rank, int nranks, const double* Fs,
+                                    const double* Qs, const double* fms, const double* fPs,
+                                    const double* gathered_s, double* sms, double* sPs, double* ll);
+int pgps_seg_smoother_apply_dev_f32(pgps_ctx*, long N, int d, int rank, int nranks, const float* Fs,
+                                    const float* Qs, const float* fms, const float* fPs, const float* gathered_s,
+                                    float* sms, float* sPs, double* ll);
+
 /* ---- sequential mode: pssgp/kalman/sequential.py:11-73 (kf, ks) ------------------------
  * StateSpaceGP(parallel=False).  Host arithmetic on HOST pointers, as in the reference (its
  * sequential mode is the CPU `tf.scan`).  No context needed.  mps / Pps (predicted moments,

@@ -450,3 +450,80 @@ static int disc_host(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, co
 
 PGPS_DEFINE(f64, double)
 PGPS_DEFINE(f32, float)
+
+// ---------------------------------------------------------------------------------------------
+// segment (multi-GPU) entry points
+// ---------------------------------------------------------------------------------------------
+extern "C" int pgps_seg_record_len(int d, int* rec_filter, int* rec_smoother) {
+    if (d < 1 || !rec_filter || !rec_smoother) return PGPS_E_INVALID;
+    *rec_filter = seg_rec_f_len(d);
+    *rec_smoother = seg_rec_s_len(d);
+    return PGPS_OK;
+}
+
+template <typename T>
+static int seg_common(pgps_ctx* ctx, long N, int d, int rank, int nranks, ScanArgs<T>& a) {
+    if (!ctx || N < 1 || rank < 0 || nranks < 1 || rank >= nranks) return PGPS_E_INVALID;
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    a.N = N;
+    a.rank = rank;
+    a.nranks = nranks;
+    return PGPS_OK;
+}
+
+template <typename T>
+static int seg_reduce(pgps_ctx* ctx, long N, int d, int rank, int nranks, const T* P0, const T* Fs, const T* Qs,
+                      const T* H, T R, const T* ys, T* rec_f) {
+    ScanArgs<T> a{};
+    TRY(seg_common<T>(ctx, N, d, rank, nranks, a));
+    if (!P0 || !Fs || !Qs || !H || !ys || !rec_f || !aligned16(Fs) || !aligned16(Qs)) return PGPS_E_INVALID;
+    a.P0 = P0; a.H = H; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys; a.rec_f = rec_f;
+    return dispatch_scan<T>(ctx, d, a, MODE_SEG_REDUCE);
+}
+
+template <typename T>
+static int seg_filter(pgps_ctx* ctx, long N, int d, int rank, int nranks, const T* P0, const T* Fs, const T* Qs,
+                      const T* H, T R, const T* ys, const T* gathered_f, T* fms, T* fPs, T* rec_s) {
+    ScanArgs<T> a{};
+    TRY(seg_common<T>(ctx, N, d, rank, nranks, a));
+    if (!P0 || !Fs || !Qs || !H || !ys || !gathered_f || !fms || !fPs || !rec_s) return PGPS_E_INVALID;
+    if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs) || !aligned16(rec_s))
+        return PGPS_E_INVALID;
+    a.P0 = P0; a.H = H; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys;
+    a.gathered_f = gathered_f; a.fms = fms; a.fPs = fPs; a.rec_s = rec_s;
+    return dispatch_scan<T>(ctx, d, a, MODE_SEG_FILTER);
+}
+
+template <typename T>
+static int seg_smoother(pgps_ctx* ctx, long N, int d, int rank, int nranks, const T* Fs, const T* Qs, const T* fms,
+                        const T* fPs, const T* gathered_s, T* sms, T* sPs, double* ll) {
+    ScanArgs<T> a{};
+    TRY(seg_common<T>(ctx, N, d, rank, nranks, a));
+    if (!Fs || !Qs || !fms || !fPs || !gathered_s || !sms || !sPs) return PGPS_E_INVALID;
+    if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs) || !aligned16(sms) ||
+        !aligned16(sPs) || !aligned16(gathered_s))
+        return PGPS_E_INVALID;
+    a.Fs = Fs; a.Qs = Qs; a.fms = const_cast<T*>(fms); a.fPs = const_cast<T*>(fPs);
+    a.gathered_s = gathered_s; a.sms = sms; a.sPs = sPs; a.ll = ll;
+    return dispatch_scan<T>(ctx, d, a, MODE_SEG_SMOOTHER);
+}
+
+#define PGPS_DEFINE_SEG(SUF, T)                                                                                      \
+    extern "C" int pgps_seg_filter_reduce_dev_##SUF(pgps_ctx* c, long N, int d, int rank, int nranks, const T* P0,   \
+                                                    const T* Fs, const T* Qs, const T* H, T R, const T* ys,         \
+                                                    T* rec_f) {                                                     \
+        return seg_reduce<T>(c, N, d, rank, nranks, P0, Fs, Qs, H, R, ys, rec_f);                                   \
+    }                                                                                                                \
+    extern "C" int pgps_seg_filter_apply_dev_##SUF(pgps_ctx* c, long N, int d, int rank, int nranks, const T* P0,    \
+                                                   const T* Fs, const T* Qs, const T* H, T R, const T* ys,          \
+                                                   const T* gathered_f, T* fms, T* fPs, T* rec_s) {                 \
+        return seg_filter<T>(c, N, d, rank, nranks, P0, Fs, Qs, H, R, ys, gathered_f, fms, fPs, rec_s);             \
+    }                                                                                                                \
+    extern "C" int pgps_seg_smoother_apply_dev_##SUF(pgps_ctx* c, long N, int d, int rank, int nranks, const T* Fs,  \
+                                                     const T* Qs, const T* fms, const T* fPs, const T* gathered_s,  \
+                                                     T* sms, T* sPs, double* ll) {                                  \
+        return seg_smoother<T>(c, N, d, rank, nranks, Fs, Qs, fms, fPs, gathered_s, sms, sPs, ll);                  \
+    }
+
+PGPS_DEFINE_SEG(f64, double)
+PGPS_DEFINE_SEG(f32, float)

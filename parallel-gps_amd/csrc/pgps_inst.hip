@@ -23,6 +23,7 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     const size_t o_lsuf = off;   off = align_up(off + nl * Dim<D>::NSMTH * sizeof(T), 256);
     const size_t o_ll = off;     off = align_up(off + nb * sizeof(double), 256);
     const size_t o_status = off; off = align_up(off + 16, 256);
+    const size_t o_seg = off;    off = align_up(off + (2 * (size_t)(D + D * D) + 2 * D * D) * sizeof(T), 256);
     int rc = ensure(ctx, ctx->ws, off);
     if (rc) return rc;
     char* base = (char*)ctx->ws.p;
@@ -32,6 +33,7 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     a.lsuf = (T*)(base + o_lsuf);
     a.llpart = (double*)(base + o_ll);
     a.status = (int*)(base + o_status);
+    a.seg_ws = (T*)(base + o_seg);
     return PGPS_OK;
 }
 
@@ -44,6 +46,37 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     if (rc) return rc;
     const dim3 grid(a.nblocks), block(kBlock);
     hipStream_t s = ctx->stream;
+    if (mode == MODE_SEG_REDUCE || mode == MODE_SEG_FILTER || mode == MODE_SEG_SMOOTHER) {
+        // one segment of a series sharded over GPUs: carry_in / halo_FQ / carry_back live in seg_ws
+        a.seg_first = (a.rank == 0);
+        a.seg_last = (a.rank == a.nranks - 1);
+        a.carry_in = a.seg_ws;
+        a.halo_FQ = a.seg_ws + (D + D * D);
+        a.carry_back = a.seg_ws + (D + D * D) + 2 * D * D;
+        const int pad = seg_rec_s_pad(D);
+        if (mode == MODE_SEG_REDUCE) {
+            {
+                ProfScope p(ctx, PGPS_K_FILTER_REDUCE);
+                hipLaunchKernelGGL((k_filter_reduce<T, D>), grid, block, 0, s, a);
+            }
+            hipLaunchKernelGGL((k_seg_filter_total<T, D>), dim3(1), block, 0, s, a);
+        } else if (mode == MODE_SEG_FILTER) {
+            hipLaunchKernelGGL((k_seg_fold_filter<T, D>), dim3(1), dim3(kWave), 0, s, a);
+            {
+                ProfScope p(ctx, PGPS_K_FILTER_APPLY);
+                hipLaunchKernelGGL((k_filter_apply<T, D, true>), grid, block, 0, s, a);
+            }
+            hipLaunchKernelGGL((k_seg_smoother_total<T, D>), dim3(1), block, 0, s, a, pad);
+        } else {
+            hipLaunchKernelGGL((k_seg_fold_smoother<T, D>), dim3(1), dim3(kWave), 0, s, a, pad);
+            ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
+            ScanArgs<T> b = a;
+            b.ll = nullptr;                 // the fold kernel wrote the series' log-likelihood
+            hipLaunchKernelGGL((k_smoother_apply<T, D>), grid, block, 0, s, b);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        return PGPS_OK;
+    }
     if (mode == MODE_PKF || mode == MODE_PKFS) {
         {
             ProfScope p(ctx, PGPS_K_FILTER_REDUCE);

@@ -88,9 +88,21 @@ struct ScanArgs {
     T* lsuf;                // (NSMTH, nlanes)
     double* llpart;         // (nblocks,)
     int* status;            // != 0: a non-positive innovation variance was met
+    // multi-GPU stitching (pgps_seg_*): records exchanged between ranks
+    int rank, nranks;
+    T* rec_f;               // out: this segment's filter record  [NFILT total | F_0 | Q_0]
+    const T* gathered_f;    // in : (nranks, REC_F) all ranks' filter records
+    T* rec_s;               // out: this segment's smoother record [NSMTH total | pad | ll partial (double)]
+    const T* gathered_s;    // in : (nranks, REC_S)
+    T* seg_ws;              // scratch: carry_in (d+d*d) | halo_FQ (2 d*d) | carry_back (d+d*d)
 };
 
-enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS };
+// record lengths (in elements of T) of the segment exchange
+inline int seg_rec_f_len(int d) { return d * d + d + d * (d + 1) + d + 2 * d * d; }
+inline int seg_rec_s_pad(int d) { int n = d * d + d + d * (d + 1) / 2; return n + (n & 1); }
+inline int seg_rec_s_len(int d) { return seg_rec_s_pad(d) + 2; }
+
+enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS, MODE_SEG_REDUCE, MODE_SEG_FILTER, MODE_SEG_SMOOTHER };
 
 // defined in pgps_inst.hip, one explicit instantiation per compiled (T, D)
 template <typename T, int D>

@@ -50,12 +50,19 @@ def _declare(lib):
     lib.pgps_memcpy_d2h.argtypes = [P, P, P, ctypes.c_size_t]
     lib.pgps_profile_enable.argtypes = [P, c_int]
     lib.pgps_profile_read.argtypes = [P, ctypes.POINTER(c_double), ctypes.POINTER(c_long), c_int]
+    lib.pgps_seg_record_len.argtypes = [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     for suf, real in (("f64", c_double), ("f32", c_float)):
         for dev in ("", "_dev"):
             getattr(lib, f"pgps_discretise{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, real, P, P]
             getattr(lib, f"pgps_pkf{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, real, P, P, P, P]
             getattr(lib, f"pgps_pks{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, P, P]
             getattr(lib, f"pgps_pkfs{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, real, P, P, P, P, P, P]
+        getattr(lib, f"pgps_seg_filter_reduce_dev_{suf}").argtypes = [P, c_long, c_int, c_int, c_int, P, P, P, P, real,
+                                                                      P, P]
+        getattr(lib, f"pgps_seg_filter_apply_dev_{suf}").argtypes = [P, c_long, c_int, c_int, c_int, P, P, P, P, real,
+                                                                     P, P, P, P, P]
+        getattr(lib, f"pgps_seg_smoother_apply_dev_{suf}").argtypes = [P, c_long, c_int, c_int, c_int, P, P, P, P, P,
+                                                                       P, P, P]
     return lib
 
 

@@ -1,0 +1,249 @@
+"""The multi-GPU (segment-sharded) path.
+
+CPU (`not gpu`):  the protocol stitched from numpy stand-ins reproduces the unsegmented oracle;
+                  the same `run_protocol` driver under torch.distributed / gloo with world_size 2.
+GPU (`gpu`):      R logical ranks on ONE MI355X -- one libpgps context (own scratch) per rank,
+                  the all-gather done by hand -- against the oracle, records checked field by field.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from oracle.segments import OracleSegment, unpack_filter_record, unpack_smoother_record
+from tests.conftest import make_times, relerr, sample_series
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem(n=700, seed=3, kernel=None):
+    from pssgp.kernels import Matern52
+    k = kernel or Matern52(1., 0.8)
+    t = make_times(n, seed=seed)
+    ssm = O.get_ssm(k.get_sde(), t, 0.1)
+    y = sample_series(ssm, seed=seed, nan_frac=0.15)
+    return ssm, y
+
+
+def _slice(ssm, lo, hi):
+    P0, Fs, Qs, H, R = ssm
+    return (P0, Fs[lo:hi], Qs[lo:hi], H, R)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_protocol_with_cpu_standins_equals_unsegmented(world):
+    from pssgp.distributed import run_protocol, split_segments
+    ssm, y = _problem()
+    fms, fPs, ll = O.pkf(ssm, y, True)
+    sms, sPs = O.pks(ssm, fms, fPs)
+    bounds = split_segments(y.size, world)
+    assert bounds[0][0] == 0 and bounds[-1][1] == y.size and all(b[1] - b[0] >= y.size // world for b in bounds)
+    segs = [OracleSegment(r, world, _slice(ssm, lo, hi), y[lo:hi]) for r, (lo, hi) in enumerate(bounds)]
+    # lock-step emulation of the collectives
+    gf = np.stack([s.phase_reduce() for s in segs])
+    gs = np.stack([s.phase_filter(gf) for s in segs])
+    for s in segs:
+        s.phase_smoother(gs)
+    assert relerr(np.concatenate([s.fms for s in segs]), fms) < 1e-11
+    assert relerr(np.concatenate([s.fPs for s in segs]), fPs) < 1e-11
+    assert relerr(np.concatenate([s.sms for s in segs]), sms) < 1e-11
+    assert relerr(np.concatenate([s.sPs for s in segs]), sPs) < 1e-11
+    assert all(abs(s.ll - ll) < 1e-11 * abs(ll) for s in segs)
+    # and through the shared driver, one rank at a time with a canned gather
+    for r, s in enumerate(segs):
+        seq = iter((gf, gs))
+        out = run_protocol(r, world, s.phase_reduce, s.phase_filter, s.phase_smoother, lambda rec: next(seq))
+        assert abs(out - ll) < 1e-11 * abs(ll)
+
+
+_GLOO_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "parallel-gps_amd"))
+from oracle import np_oracle as O
+from oracle.segments import OracleSegment
+from pssgp.distributed import run_protocol, split_segments
+from tests.test_segments import _problem, _slice
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ssm, y = _problem()
+lo, hi = split_segments(y.size, world)[rank]
+seg = OracleSegment(rank, world, _slice(ssm, lo, hi), y[lo:hi])
+
+def all_gather(rec):
+    rec = torch.from_numpy(np.ascontiguousarray(rec))
+    out = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(out, rec)
+    return torch.stack(out).numpy()
+
+ll = run_protocol(rank, world, seg.phase_reduce, seg.phase_filter, seg.phase_smoother, all_gather)
+fms, fPs, ll_ref = O.pkf(ssm, y, True)
+sms, sPs = O.pks(ssm, fms, fPs)
+err = max(np.max(np.abs(seg.fms - fms[lo:hi])), np.max(np.abs(seg.sms - sms[lo:hi])),
+          np.max(np.abs(seg.sPs - sPs[lo:hi])), abs(ll - ll_ref) / abs(ll_ref))
+dist.barrier()
+dist.destroy_process_group()
+print("RANK", rank, "ERR", err)
+sys.exit(0 if err < 1e-10 else 3)
+'''
+
+
+def test_protocol_under_gloo_world_size_2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out}"
+        assert "ERR" in out
+
+
+def test_record_lengths_match_layout():
+    from pssgp.distributed import record_lengths
+    for d in range(1, 7):
+        rf, rs, pad = record_lengths(d)
+        sym = d * (d + 1) // 2
+        assert rf == (d * d + 2 * d + 2 * sym) + 2 * d * d
+        assert pad % 2 == 0 and pad >= d * d + d + sym and rs == pad + 2
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: several logical ranks on one device
+# ------------------------------------------------------------------------------------------------
+class _Dev:
+    """Tiny device-array helper over pgps_malloc / memcpy (no torch in the GPU parity tests)."""
+
+    def __init__(self, ctx, arr=None, shape=None, dtype=np.float64):
+        self.ctx = ctx
+        if arr is not None:
+            arr = np.ascontiguousarray(arr, dtype=dtype)
+            shape = arr.shape
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = ctx.malloc(max(self.nbytes, 16))
+        if arr is not None:
+            ctx.h2d(self.ptr, arr)
+
+    def get(self):
+        out = np.empty(self.shape, self.dtype)
+        self.ctx.d2h(out, self.ptr)
+        return out
+
+    def put(self, arr):
+        self.ctx.h2d(self.ptr, np.ascontiguousarray(arr, dtype=self.dtype).reshape(self.shape))
+
+    @property
+    def p(self):
+        return ctypes.c_void_p(self.ptr)
+
+    def free(self):
+        self.ctx.free(self.ptr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dtype", [(1, np.float64), (2, np.float64), (3, np.float64), (8, np.float64),
+                                         (4, np.float32)])
+def test_segments_on_one_gpu(world, dtype):
+    from pssgp import _backend as B
+    from pssgp.distributed import record_lengths, split_segments
+    from pssgp.kernels import Matern32, Matern52
+    ssm, y = _problem(n=5000, seed=9, kernel=Matern32(1., 1.) + Matern52(1., 0.7))
+    d = ssm[1].shape[1]
+    fms, fPs, ll = O.kf(ssm, y, True)
+    sms, sPs = O.kfs(ssm, y)
+    suf, real = B._suffix(dtype)
+    rf, rs, pad = record_lengths(d)
+    bounds = split_segments(y.size, world)
+    ranks = []
+    for r, (lo, hi) in enumerate(bounds):
+        ctx = B.Context(0)
+        n = hi - lo
+        P0, Fs, Qs, H, R = _slice(ssm, lo, hi)
+        ranks.append(dict(ctx=ctx, n=n, lo=lo, hi=hi,
+                          P0=_Dev(ctx, P0, dtype=dtype), Fs=_Dev(ctx, Fs, dtype=dtype), Qs=_Dev(ctx, Qs, dtype=dtype),
+                          H=_Dev(ctx, H.reshape(-1), dtype=dtype), ys=_Dev(ctx, y[lo:hi], dtype=dtype),
+                          fms=_Dev(ctx, shape=(n, d), dtype=dtype), fPs=_Dev(ctx, shape=(n, d, d), dtype=dtype),
+                          sms=_Dev(ctx, shape=(n, d), dtype=dtype), sPs=_Dev(ctx, shape=(n, d, d), dtype=dtype),
+                          rec_f=_Dev(ctx, shape=(rf,), dtype=dtype), rec_s=_Dev(ctx, shape=(rs,), dtype=dtype),
+                          gf=_Dev(ctx, shape=(world, rf), dtype=dtype), gs=_Dev(ctx, shape=(world, rs), dtype=dtype),
+                          ll=_Dev(ctx, shape=(2,), dtype=np.float64)))
+    Rv = real(float(ssm[4].reshape(())))
+    L, I = ctypes.c_long, ctypes.c_int
+    for r, k in enumerate(ranks):
+        k["ctx"].call(f"pgps_seg_filter_reduce_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p,
+                      k["Qs"].p, k["H"].p, Rv, k["ys"].p, k["rec_f"].p)
+    gf = np.stack([k["rec_f"].get() for k in ranks])
+    # the records themselves: compare with the numpy stand-ins field by field
+    segs = [OracleSegment(r, world, _slice(ssm, lo, hi), y[lo:hi]) for r, (lo, hi) in enumerate(bounds)]
+    gf_o = np.stack([s.phase_reduce() for s in segs])
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    for r in range(world):
+        (A, b, C, J, eta), F0, Q0 = unpack_filter_record(gf[r].astype(np.float64), d)
+        (Ao, bo, Co, Jo, etao), F0o, Q0o = unpack_filter_record(gf_o[r], d)
+        assert relerr(b, bo) < tol and relerr(C, Co) < tol and relerr(F0, F0o) < tol and relerr(Q0, Q0o) < tol
+        if r > 0:       # J, eta of a prefix that holds the first element never reach an output
+            assert relerr(A, Ao) < tol and relerr(J, Jo) < tol and relerr(eta, etao) < tol
+    for r, k in enumerate(ranks):
+        k["gf"].put(gf)
+        k["ctx"].call(f"pgps_seg_filter_apply_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p,
+                      k["Qs"].p, k["H"].p, Rv, k["ys"].p, k["gf"].p, k["fms"].p, k["fPs"].p, k["rec_s"].p)
+    gs = np.stack([k["rec_s"].get() for k in ranks])
+    for r, k in enumerate(ranks):
+        k["gs"].put(gs)
+        k["ctx"].call(f"pgps_seg_smoother_apply_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["Fs"].p, k["Qs"].p,
+                      k["fms"].p, k["fPs"].p, k["gs"].p, k["sms"].p, k["sPs"].p, k["ll"].p)
+    got = {n: np.concatenate([k[n].get() for k in ranks]) for n in ("fms", "fPs", "sms", "sPs")}
+    assert relerr(got["fms"], fms) < tol and relerr(got["fPs"], fPs) < tol
+    assert relerr(got["sms"], sms) < tol and relerr(got["sPs"], sPs) < tol
+    for k in ranks:
+        assert abs(k["ll"].get()[0] - ll) < (1e-10 if dtype == np.float64 else 1e-4) * abs(ll)
+    for k in ranks:
+        k["ctx"].synchronize()
+        for v in k.values():
+            if isinstance(v, _Dev):
+                v.free()
+        k["ctx"].close()
+
+
+@pytest.mark.gpu
+def test_segmentscan_world1_with_torch():
+    """The torch.distributed driver at world_size 1 (what bench.py runs per rank), on the GPU."""
+    torch = pytest.importorskip("torch")
+    from pssgp import _backend as B
+    from pssgp.distributed import SegmentScan
+    ssm, y = _problem(n=4000, seed=2)
+    d = ssm[1].shape[1]
+    dev = torch.device("cuda", 0)
+    ctx = B.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    P0, Fs, Qs, H, ys = T(ssm[0]), T(ssm[1]), T(ssm[2]), T(ssm[3].reshape(-1)), T(y)
+    n = y.size
+    fms, sms = torch.empty((n, d), dtype=torch.float64, device=dev), torch.empty((n, d), dtype=torch.float64, device=dev)
+    fPs, sPs = torch.empty((n, d, d), dtype=torch.float64, device=dev), torch.empty((n, d, d), dtype=torch.float64, device=dev)
+    ll = torch.zeros(2, dtype=torch.float64, device=dev)
+    seg = SegmentScan(ctx, 0, 1, d, np.float64, torch_device=dev)
+    seg.pkfs(n, P0, Fs, Qs, H, 0.1, ys, fms, fPs, sms, sPs, ll)
+    torch.cuda.synchronize(dev)
+    of, oP, oll = O.kf(ssm, y, True)
+    os_, osP = O.kfs(ssm, y)
+    assert relerr(fms.cpu().numpy(), of) < 1e-9 and relerr(sms.cpu().numpy(), os_) < 1e-9
+    assert relerr(sPs.cpu().numpy(), osP) < 1e-9 and abs(ll[0].item() - oll) < 1e-10 * abs(oll)
+    ctx.close()
