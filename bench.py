@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--kernel", default="matern32", choices=["matern32", "matern52", "rbf6", "matern12"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
+    ap.add_argument("--stage", type=int, default=-1, help="LDS staging: -1 auto, 0 off, 2 / 4 steps per sub-tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="hipEvent-time every n-th launch of the dominant kernel inside the timed region")
     ap.add_argument("--nan-frac", type=float, default=0.0)
     return ap.parse_args()
 
@@ -123,6 +126,7 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     if args.chunk:
         ctx.set_chunk(args.chunk)
+    ctx.set_stage(args.stage)
 
     def dev_from(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -173,12 +177,14 @@ def main():
     torch.cuda.synchronize(dev)
     dominant = "k_smoother_apply"
     ctx.profile_read(reset=True)
-    ctx.profile_enable(1 << 3)          # hipEvents around the dominant kernel only (slot 3)
+    ctx.profile_sample(args.event_every)
+    ctx.profile_enable((1 << 3) if args.event_every > 0 else 0)   # hipEvents around the dominant kernel (slot 3)
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter()
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
@@ -191,6 +197,7 @@ def main():
         elapsed = float(tmax.item())
 
     # per-kernel breakdown (separate, untimed loop with events around every launch)
+    ctx.profile_sample(1)
     ctx.profile_enable(0x3f)
     for _ in range(min(args.steps, 50)):
         step()
@@ -228,6 +235,7 @@ def main():
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_avg_s * 1e3},
         "whole_path_effective_GBps": alg_bytes_step * n_total * args.steps / elapsed / 1e9,
         "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in breakdown.items() if v[1]},
+        "host_enqueue_ms_per_step": (t_enq - t0) / args.steps * 1e3,
         "log_likelihood": ll_val,
         "chunk": ctx.get_chunk(n_local),
     }

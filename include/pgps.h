@@ -54,6 +54,9 @@ int pgps_set_stream(pgps_ctx* ctx, void* hip_stream);
 int pgps_synchronize(pgps_ctx* ctx);
 /* Steps per lane of the scan kernels; 0 = automatic. */
 int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
+/* LDS staging of the lane-chunk kernels: -1 = automatic, 0 = off (direct global accesses),
+ * 2 or 4 = steps per lane per staged sub-tile (2: fp64 only).  Tuning / A-B knob. */
+int pgps_set_stage(pgps_ctx* ctx, int steps_per_subtile);
 int pgps_get_chunk(pgps_ctx* ctx, long n_steps, int* steps_per_lane, int* n_workgroups);
 const char* pgps_last_hip_error(pgps_ctx* ctx);
 
@@ -73,6 +76,9 @@ int pgps_memcpy_d2h(pgps_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 #define PGPS_K_COUNT 6
 /* mask: bit i set = record a hipEvent pair around every launch of slot i; 0 = off. */
 int pgps_profile_enable(pgps_ctx* ctx, int mask);
+/* Time only every n-th launch of an enabled slot (default 1): keeps the events' own cost
+ * (a few microseconds per pair) out of a throughput measurement. */
+int pgps_profile_sample(pgps_ctx* ctx, int every_n);
 /* Synchronises, then returns accumulated milliseconds and launch counts per PGPS_K_* slot
  * since the last reset (arrays of PGPS_K_COUNT). */
 int pgps_profile_read(pgps_ctx* ctx, double* total_ms, long* launches, int reset);

@@ -101,6 +101,12 @@ extern "C" int pgps_set_chunk(pgps_ctx* ctx, int c) {
     return PGPS_OK;
 }
 
+extern "C" int pgps_set_stage(pgps_ctx* ctx, int g) {
+    if (!ctx || !(g == -1 || g == 0 || g == 2 || g == 4)) return PGPS_E_INVALID;
+    ctx->stage_g = g;
+    return PGPS_OK;
+}
+
 extern "C" const char* pgps_last_hip_error(pgps_ctx* ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
 
 extern "C" int pgps_malloc(pgps_ctx* ctx, size_t bytes, void** dptr) {
@@ -153,8 +159,9 @@ int prof_flush(pgps_ctx* ctx) {
 
 ProfScope::ProfScope(pgps_ctx* c, int slot) : ctx(c) {
     if (!((c->profiling >> slot) & 1u)) return;
+    if ((c->prof_seen[slot]++ % c->prof_every) != 0) return;
     if (c->ev_used == c->ev_pool.size()) {
-        if (c->ev_pool.size() >= 8192) {
+        if (c->ev_pool.size() >= 1024) {
             if (prof_flush(c) != PGPS_OK) return;
         } else {
             pgps_ctx::EvPair p;
@@ -174,7 +181,29 @@ ProfScope::~ProfScope() {
 extern "C" int pgps_profile_enable(pgps_ctx* ctx, int on) {
     if (!ctx) return PGPS_E_INVALID;
     if (!on) { int rc = prof_flush(ctx); if (rc) return rc; }
+    if (on && ctx->ev_pool.empty()) {
+        // create the events (and exercise them once) up front: the first hipEventRecord on a fresh
+        // event allocates its signal, which can stall the queue for milliseconds
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        for (int i = 0; i < 1024; ++i) {
+            pgps_ctx::EvPair p;
+            HIPCHK(ctx, hipEventCreate(&p.a));
+            HIPCHK(ctx, hipEventCreate(&p.b));
+            p.slot = 0;
+            ctx->ev_pool.push_back(p);
+            HIPCHK(ctx, hipEventRecord(p.a, ctx->stream));
+            HIPCHK(ctx, hipEventRecord(p.b, ctx->stream));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->profiling = (unsigned)on;
+    for (int i = 0; i < PGPS_K_COUNT; ++i) ctx->prof_seen[i] = 0;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_profile_sample(pgps_ctx* ctx, int every_n) {
+    if (!ctx || every_n < 1) return PGPS_E_INVALID;
+    ctx->prof_every = every_n;
     return PGPS_OK;
 }
 
@@ -203,6 +232,7 @@ void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks) {
         long v = (N + (long)kBlock * target_blocks - 1) / ((long)kBlock * target_blocks);
         if (v < 1) v = 1;
         if (N >= (long)kBlock * 4 && v < 4) v = 4;
+        if (v > 4) v = (v + 3) / 4 * 4;     // whole LDS-staged sub-tiles (4 steps per lane)
         c = (int)v;
     }
     long nb = (N + (long)kBlock * c - 1) / ((long)kBlock * c);

@@ -37,8 +37,8 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     return PGPS_OK;
 }
 
-template <typename T, int D>
-int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
+template <typename T, int D, int G>
+static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     geometry(ctx, a.N, &a.Lc, &a.nblocks);
     a.nlanes = (long)a.nblocks * kBlock;
@@ -57,14 +57,14 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         if (mode == MODE_SEG_REDUCE) {
             {
                 ProfScope p(ctx, PGPS_K_FILTER_REDUCE);
-                hipLaunchKernelGGL((k_filter_reduce<T, D>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((k_filter_reduce<T, D, G>), grid, block, 0, s, a);
             }
             hipLaunchKernelGGL((k_seg_filter_total<T, D>), dim3(1), block, 0, s, a);
         } else if (mode == MODE_SEG_FILTER) {
             hipLaunchKernelGGL((k_seg_fold_filter<T, D>), dim3(1), dim3(kWave), 0, s, a);
             {
                 ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-                hipLaunchKernelGGL((k_filter_apply<T, D, true>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((k_filter_apply<T, D, true, G>), grid, block, 0, s, a);
             }
             hipLaunchKernelGGL((k_seg_smoother_total<T, D>), dim3(1), block, 0, s, a, pad);
         } else {
@@ -72,7 +72,7 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
             ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
             ScanArgs<T> b = a;
             b.ll = nullptr;                 // the fold kernel wrote the series' log-likelihood
-            hipLaunchKernelGGL((k_smoother_apply<T, D>), grid, block, 0, s, b);
+            hipLaunchKernelGGL((k_smoother_apply<T, D, G>), grid, block, 0, s, b);
         }
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
@@ -80,15 +80,15 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     if (mode == MODE_PKF || mode == MODE_PKFS) {
         {
             ProfScope p(ctx, PGPS_K_FILTER_REDUCE);
-            hipLaunchKernelGGL((k_filter_reduce<T, D>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((k_filter_reduce<T, D, G>), grid, block, 0, s, a);
         }
         if (mode == MODE_PKFS) {
             ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-            hipLaunchKernelGGL((k_filter_apply<T, D, true>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((k_filter_apply<T, D, true, G>), grid, block, 0, s, a);
         } else {
             {
                 ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-                hipLaunchKernelGGL((k_filter_apply<T, D, false>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((k_filter_apply<T, D, false, G>), grid, block, 0, s, a);
             }
             if (a.ll) {
                 ProfScope p(ctx, PGPS_K_LL_FINALIZE);
@@ -106,10 +106,24 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
         ScanArgs<T> b = a;
         if (mode == MODE_PKS) b.ll = nullptr;
-        hipLaunchKernelGGL((k_smoother_apply<T, D>), grid, block, 0, s, b);
+        hipLaunchKernelGGL((k_smoother_apply<T, D, G>), grid, block, 0, s, b);
     }
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
+}
+
+// G = steps per lane per LDS-staged sub-tile (0 = direct global accesses); staging exists for
+// d <= 2 only (StageCfg), G = 2 only in fp64 (a lane segment must be >= 16 bytes).
+template <typename T, int D>
+int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
+    if constexpr (D <= 2) {
+        int g = ctx->stage_g < 0 ? 4 : ctx->stage_g;
+        if (g == 4) return launch_scan_g<T, D, 4>(ctx, a, mode);
+        if constexpr (sizeof(T) == 8) {
+            if (g == 2) return launch_scan_g<T, D, 2>(ctx, a, mode);
+        }
+    }
+    return launch_scan_g<T, D, 0>(ctx, a, mode);
 }
 
 template <typename T, int D>

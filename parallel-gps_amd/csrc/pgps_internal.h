@@ -19,10 +19,13 @@ struct pgps_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int chunk = 0;                      // 0 = auto
+    int stage_g = -1;                   // LDS staging: -1 = auto, 0 = off, 2 / 4 = steps per sub-tile
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
+    int prof_every = 1;                 // time every n-th launch of an enabled slot
+    long prof_seen[PGPS_K_COUNT] = {0};
     struct EvPair { hipEvent_t a, b; int slot; };
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;

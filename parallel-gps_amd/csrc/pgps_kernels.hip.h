@@ -350,57 +350,90 @@ __device__ __forceinline__ double block_sum_double(double x, double* lds) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K-F1: filter reduce
+// Wavefront-private LDS staging: coalesced global <-> LDS, lane-owned records out of LDS.
+//
+// A lane owns Lc consecutive steps, so its records sit Lc*RECB bytes apart from its neighbour's:
+// reading them straight from global memory touches 64 different 128-byte lines per wave
+// instruction and uses 16 bytes of each (measured: the smoother pass ran at 1.7 TB/s of
+// algorithmic bytes that way, L2-request bound).  Instead the wave streams through its span in
+// sub-tiles of G steps per lane: piece q (16 bytes) of the sub-tile belongs to lane q / NV and is
+// loaded by lane q % 64 of instruction q / 64, so consecutive lanes read consecutive 16-byte
+// pieces of one lane-segment (SEG = G*RECB contiguous bytes: whole 128-byte lines for G = 4,
+// d = 2, fp64), the pieces are parked in LDS at owner*STRIDE (+16 bytes of padding per owner so
+// the owners' ds_read_b128 of their own records are bank-conflict free) and each lane then reads
+// its own G records from LDS.  Outputs take the same road back.  The next sub-tile's global loads
+// are issued into registers before the current one is computed (one sub-tile of prefetch).
+// Everything is wave-private: no workgroup barrier inside the streaming loops.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(kBlock) void k_filter_reduce(const ScanArgs<T> a) {
-    constexpr int MAT = D * D, SYM = Dim<D>::SYM;
-    using FE = FiltElem<T, D>;
-    __shared__ T lds[kWaves * Dim<D>::NFILT];
+using V4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-    T h[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) h[i] = a.H[i];
+template <int RECB, int G>
+struct StageGeom {
+    static constexpr int SEG = RECB * G;
+    static_assert(SEG % 16 == 0, "lane segment must be a whole number of 16-byte pieces");
+    static constexpr int NV = SEG / 16;
+    static constexpr int STRIDE = SEG + 16;
+    static constexpr int BYTES = kWave * STRIDE;
+};
 
-    const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
-    const long k0 = gt * a.Lc;
-    const long k1 = min(a.N, k0 + a.Lc);
-
-    FE agg;
-    filt_identity(agg);
-    if (k0 < k1) {
-        T Fn[MAT], Qn[MAT];
-        T yn;
-        load_rec<T, MAT>(a.Fs + k0 * MAT, Fn);
-        load_rec<T, MAT>(a.Qs + k0 * MAT, Qn);
-        yn = a.ys[k0];
-        for (long k = k0; k < k1; ++k) {
-            T F[MAT], Q[SYM];
-#pragma unroll
-            for (int i = 0; i < MAT; ++i) F[i] = Fn[i];
-            sym_from_full<T, D>(Qn, Q);
-            const T y = yn;
-            if (k + 1 < k1) {
-                load_rec<T, MAT>(a.Fs + (k + 1) * MAT, Fn);
-                load_rec<T, MAT>(a.Qs + (k + 1) * MAT, Qn);
-                yn = a.ys[k + 1];
-            }
-            if (k == 0 && a.seg_first) {
-                T P0f[MAT], P0[SYM];
-#pragma unroll
-                for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
-                sym_from_full<T, D>(P0f, P0);
-                filt_first(agg, P0, y, h, a.R);
-            } else {
-                filt_extend(agg, F, Q, y, h, a.R);
-            }
-        }
-    }
-    FE excl, total;
-    block_scan_exclusive<FE, true>(agg, excl, total, lds);
-    ws_store(a.lpre, a.nlanes, gt, excl);
-    if (threadIdx.x == 0) rec_store(a.spine + (long)blockIdx.x * Dim<D>::NFILT, total);
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+
+template <typename GEO>
+__device__ __forceinline__ void stage_issue(const char* __restrict__ g, long lane_pitch, V4* r) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int v = 0; v < GEO::NV; ++v) {
+        const int q = v * kWave + lane;
+        r[v] = *reinterpret_cast<const V4*>(g + (long)(q / GEO::NV) * lane_pitch + (q % GEO::NV) * 16);
+    }
+}
+template <typename GEO>
+__device__ __forceinline__ void stage_commit(char* lds, const V4* r) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int v = 0; v < GEO::NV; ++v) {
+        const int q = v * kWave + lane;
+        *reinterpret_cast<V4*>(lds + (q / GEO::NV) * GEO::STRIDE + (q % GEO::NV) * 16) = r[v];
+    }
+}
+template <typename GEO>
+__device__ __forceinline__ void stage_drain(char* __restrict__ g, long lane_pitch, const char* lds) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int v = 0; v < GEO::NV; ++v) {
+        const int q = v * kWave + lane;
+        const V4 x = *reinterpret_cast<const V4*>(lds + (q / GEO::NV) * GEO::STRIDE + (q % GEO::NV) * 16);
+        *reinterpret_cast<V4*>(g + (long)(q / GEO::NV) * lane_pitch + (q % GEO::NV) * 16) = x;
+    }
+}
+// this lane's record i of the current sub-tile
+template <typename GEO, typename T, int N>
+__device__ __forceinline__ void stage_get(const char* lds, int i, T* out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    load_rec<T, N>(reinterpret_cast<const T*>(lds + lane * GEO::STRIDE) + i * N, out);
+}
+template <typename GEO, typename T, int N>
+__device__ __forceinline__ void stage_put(char* lds, int i, const T* in) {
+    const int lane = threadIdx.x & (kWave - 1);
+    store_rec<T, N>(reinterpret_cast<T*>(lds + lane * GEO::STRIDE) + i * N, in);
+}
+
+// staging is used when a record is small (d <= 2); G = steps per lane per sub-tile
+template <typename T, int D, int G>
+struct StageCfg {
+    static constexpr bool on = (G > 0) && (D <= 2);
+    static constexpr int GG = on ? G : 4;
+    using GF = StageGeom<D * D * (int)sizeof(T), GG>;     // F, Q, P records
+    using GM = StageGeom<D * (int)sizeof(T), GG>;         // m records
+    using GY = StageGeom<(int)sizeof(T), GG>;             // y records
+    static constexpr int F1_BYTES = on ? 2 * GF::BYTES + GY::BYTES : 16;
+    static constexpr int F3_BYTES = on ? 2 * GF::BYTES + GY::BYTES + GM::BYTES : 16;
+    static constexpr int S3_BYTES = on ? 3 * GF::BYTES + GM::BYTES : 16;
+};
 
 // Fold spine entries [lo, hi) in time order over the whole workgroup; result in every lane.
 template <typename E>
@@ -422,17 +455,100 @@ __device__ __forceinline__ void fold_spine(const typename ElemTraits<E>::Scalar*
     block_reduce_ordered(acc, total, lds);
 }
 
+
 // ---------------------------------------------------------------------------------------------
-// K-F3: filter apply (+ log-likelihood, + fused smoothing-aggregate build when SMOOTH)
+// K-F1: filter reduce
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, bool SMOOTH>
-__global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
-    constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT;
+template <typename T, int D>
+__device__ __forceinline__ void filter_reduce_step(const ScanArgs<T>& a, long k, const T* F, const T* Qf, T y,
+                                                   const T* h, FiltElem<T, D>& agg) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM;
+    if (k == 0 && a.seg_first) {
+        T P0f[MAT], P0[SYM];
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
+        sym_from_full<T, D>(P0f, P0);
+        filt_first(agg, P0, y, h, a.R);
+    } else {
+        T Q[SYM];
+        sym_from_full<T, D>(Qf, Q);
+        filt_extend(agg, F, Q, y, h, a.R);
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void lane_filter_reduce_direct(const ScanArgs<T>& a, long k0, long k1, const T* h,
+                                                          FiltElem<T, D>& agg) {
+    constexpr int MAT = D * D;
+    if (k0 >= k1) return;
+    T Fn[MAT], Qn[MAT];
+    T yn;
+    load_rec<T, MAT>(a.Fs + k0 * MAT, Fn);
+    load_rec<T, MAT>(a.Qs + k0 * MAT, Qn);
+    yn = a.ys[k0];
+    for (long k = k0; k < k1; ++k) {
+        T F[MAT], Qf[MAT];
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) { F[i] = Fn[i]; Qf[i] = Qn[i]; }
+        const T y = yn;
+        if (k + 1 < k1) {
+            load_rec<T, MAT>(a.Fs + (k + 1) * MAT, Fn);
+            load_rec<T, MAT>(a.Qs + (k + 1) * MAT, Qn);
+            yn = a.ys[k + 1];
+        }
+        filter_reduce_step<T, D>(a, k, F, Qf, y, h, agg);
+    }
+}
+
+template <typename T, int D, int G>
+__device__ __forceinline__ void lane_filter_reduce_staged(const ScanArgs<T>& a, long wbase, char* lds, const T* h,
+                                                          FiltElem<T, D>& agg) {
+    using CFG = StageCfg<T, D, G>;
+    using GF = typename CFG::GF;
+    using GY = typename CFG::GY;
+    constexpr int MAT = D * D;
+    const int lane = threadIdx.x & (kWave - 1);
+    char* lF = lds;
+    char* lQ = lF + GF::BYTES;
+    char* lY = lQ + GF::BYTES;
+    const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchY = (long)a.Lc * sizeof(T);
+    const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
+    const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
+    const char* gY = reinterpret_cast<const char*>(a.ys + wbase);
+    const int S = a.Lc / G;
+    V4 rF[GF::NV], rQ[GF::NV], rY[GY::NV];
+    stage_issue<GF>(gF, pitchF, rF);
+    stage_issue<GF>(gQ, pitchF, rQ);
+    stage_issue<GY>(gY, pitchY, rY);
+    for (int s = 0; s < S; ++s) {
+        wave_lds_sync();
+        stage_commit<GF>(lF, rF);
+        stage_commit<GF>(lQ, rQ);
+        stage_commit<GY>(lY, rY);
+        if (s + 1 < S) {
+            stage_issue<GF>(gF + (long)(s + 1) * GF::SEG, pitchF, rF);
+            stage_issue<GF>(gQ + (long)(s + 1) * GF::SEG, pitchF, rQ);
+            stage_issue<GY>(gY + (long)(s + 1) * GY::SEG, pitchY, rY);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const long k = wbase + (long)lane * a.Lc + s * G + i;
+            T F[MAT], Qf[MAT], yv[1];
+            stage_get<GF, T, MAT>(lF, i, F);
+            stage_get<GF, T, MAT>(lQ, i, Qf);
+            stage_get<GY, T, 1>(lY, i, yv);
+            filter_reduce_step<T, D>(a, k, F, Qf, yv[0], h, agg);
+        }
+    }
+}
+
+template <typename T, int D, int G>
+__global__ __launch_bounds__(kBlock) void k_filter_reduce(const ScanArgs<T> a) {
     using FE = FiltElem<T, D>;
-    using SE = SmthElem<T, D>;
-    using MC = MeanCov<T, D>;
-    __shared__ T lds[kWaves * NF];
-    __shared__ double lds_ll[kWaves];
+    using CFG = StageCfg<T, D, G>;
+    __shared__ T lds[kWaves * Dim<D>::NFILT];
+    __shared__ __attribute__((aligned(16))) char stage[kWaves][CFG::F1_BYTES];
 
     T h[D];
 #pragma unroll
@@ -441,6 +557,178 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
     const long k0 = gt * a.Lc;
     const long k1 = min(a.N, k0 + a.Lc);
+    const int wave = threadIdx.x / kWave;
+    const long wbase = ((long)blockIdx.x * kBlock + wave * kWave) * a.Lc;
+
+    FE agg;
+    filt_identity(agg);
+    bool staged = false;
+    if constexpr (CFG::on) {
+        staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
+        if (staged) lane_filter_reduce_staged<T, D, G>(a, wbase, stage[wave], h, agg);
+    }
+    if (!staged) lane_filter_reduce_direct<T, D>(a, k0, k1, h, agg);
+
+    FE excl, total;
+    block_scan_exclusive<FE, true>(agg, excl, total, lds);
+    ws_store(a.lpre, a.nlanes, gt, excl);
+    if (threadIdx.x == 0) rec_store(a.spine + (long)blockIdx.x * Dim<D>::NFILT, total);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-F3: filter apply (+ log-likelihood, + fused smoothing-aggregate build when SMOOTH)
+// ---------------------------------------------------------------------------------------------
+// one step of the lane-serial Kalman pass; `prev` = filtered state of step k-1 (or the carry-in)
+template <typename T, int D, bool SMOOTH>
+__device__ __forceinline__ void filter_apply_step(const ScanArgs<T>& a, long k, long k0, const T* F, const T* Qf, T y,
+                                                  const T* h, MeanCov<T, D>& s, LogLik& ll, SmthElem<T, D>& sagg) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM;
+    T Q[SYM];
+    sym_from_full<T, D>(Qf, Q);
+    MeanCov<T, D> prev = s;
+    T mp[D], Pp[SYM], FP[MAT];
+    kf_step(s, F, Q, y, h, a.R, (k == 0) && a.seg_first, ll, mp, Pp, FP);
+    if (SMOOTH && k > k0) {                 // element of step k-1 from this step's predict
+        SmthElem<T, D> e, r;
+        smth_element(prev, mp, Pp, FP, e);
+        smth_combine(sagg, e, r);
+        sagg = r;
+    }
+}
+
+// smoothing element of a chunk's last step: needs the predict of the step after the chunk
+template <typename T, int D>
+__device__ __forceinline__ void filter_apply_tail(const ScanArgs<T>& a, long k1, const MeanCov<T, D>& s,
+                                                  SmthElem<T, D>& sagg) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM;
+    SmthElem<T, D> e, r;
+    if (k1 < a.N || !a.seg_last) {
+        T F[MAT], Qf[MAT], Q[SYM];
+        if (k1 < a.N) {
+            load_rec<T, MAT>(a.Fs + k1 * MAT, F);
+            load_rec<T, MAT>(a.Qs + k1 * MAT, Qf);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAT; ++i) { F[i] = a.halo_FQ[i]; Qf[i] = a.halo_FQ[MAT + i]; }
+        }
+        sym_from_full<T, D>(Qf, Q);
+        T mp[D], Pp[SYM], FP[MAT];
+        mat_vec<T, D>(F, s.m, mp);
+        predict_cov<T, D>(F, s.P, Q, FP, Pp);
+        smth_element(s, mp, Pp, FP, e);
+    } else {
+        smth_last(s, e);
+    }
+    smth_combine(sagg, e, r);
+    sagg = r;
+}
+
+template <typename T, int D, bool SMOOTH>
+__device__ __forceinline__ void lane_filter_apply_direct(const ScanArgs<T>& a, long k0, long k1, const T* h,
+                                                         MeanCov<T, D>& s, LogLik& ll, SmthElem<T, D>& sagg) {
+    constexpr int MAT = D * D;
+    if (k0 >= k1) return;
+    T Fn[MAT], Qn[MAT];
+    T yn;
+    load_rec<T, MAT>(a.Fs + k0 * MAT, Fn);
+    load_rec<T, MAT>(a.Qs + k0 * MAT, Qn);
+    yn = a.ys[k0];
+    for (long k = k0; k < k1; ++k) {
+        T F[MAT], Qf[MAT];
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) { F[i] = Fn[i]; Qf[i] = Qn[i]; }
+        const T y = yn;
+        if (k + 1 < k1) {
+            load_rec<T, MAT>(a.Fs + (k + 1) * MAT, Fn);
+            load_rec<T, MAT>(a.Qs + (k + 1) * MAT, Qn);
+            yn = a.ys[k + 1];
+        }
+        filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, y, h, s, ll, sagg);
+        store_rec<T, D>(a.fms + k * D, s.m);
+        T Pf[MAT];
+        full_from_sym<T, D>(s.P, Pf);
+        store_rec<T, MAT>(a.fPs + k * MAT, Pf);
+    }
+    if (SMOOTH) filter_apply_tail<T, D>(a, k1, s, sagg);
+}
+
+template <typename T, int D, bool SMOOTH, int G>
+__device__ __forceinline__ void lane_filter_apply_staged(const ScanArgs<T>& a, long wbase, char* lds, const T* h,
+                                                         MeanCov<T, D>& s, LogLik& ll, SmthElem<T, D>& sagg) {
+    using CFG = StageCfg<T, D, G>;
+    using GF = typename CFG::GF;
+    using GM = typename CFG::GM;
+    using GY = typename CFG::GY;
+    constexpr int MAT = D * D;
+    const int lane = threadIdx.x & (kWave - 1);
+    char* lF = lds;                     // F in, P out
+    char* lQ = lF + GF::BYTES;
+    char* lY = lQ + GF::BYTES;
+    char* lM = lY + GY::BYTES;          // m out
+    const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchY = (long)a.Lc * sizeof(T),
+               pitchM = (long)a.Lc * D * sizeof(T);
+    const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
+    const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
+    const char* gY = reinterpret_cast<const char*>(a.ys + wbase);
+    char* gP = reinterpret_cast<char*>(a.fPs + wbase * MAT);
+    char* gM = reinterpret_cast<char*>(a.fms + wbase * D);
+    const int S = a.Lc / G;
+    const long k0 = wbase + (long)lane * a.Lc;
+    V4 rF[GF::NV], rQ[GF::NV], rY[GY::NV];
+    stage_issue<GF>(gF, pitchF, rF);
+    stage_issue<GF>(gQ, pitchF, rQ);
+    stage_issue<GY>(gY, pitchY, rY);
+    for (int sb = 0; sb < S; ++sb) {
+        wave_lds_sync();
+        stage_commit<GF>(lF, rF);
+        stage_commit<GF>(lQ, rQ);
+        stage_commit<GY>(lY, rY);
+        if (sb + 1 < S) {
+            stage_issue<GF>(gF + (long)(sb + 1) * GF::SEG, pitchF, rF);
+            stage_issue<GF>(gQ + (long)(sb + 1) * GF::SEG, pitchF, rQ);
+            stage_issue<GY>(gY + (long)(sb + 1) * GY::SEG, pitchY, rY);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const long k = k0 + sb * G + i;
+            T F[MAT], Qf[MAT], yv[1];
+            stage_get<GF, T, MAT>(lF, i, F);
+            stage_get<GF, T, MAT>(lQ, i, Qf);
+            stage_get<GY, T, 1>(lY, i, yv);
+            filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, yv[0], h, s, ll, sagg);
+            T Pf[MAT];
+            full_from_sym<T, D>(s.P, Pf);
+            stage_put<GM, T, D>(lM, i, s.m);
+            stage_put<GF, T, MAT>(lF, i, Pf);       // F_k is dead after its predict
+        }
+        wave_lds_sync();
+        stage_drain<GM>(gM + (long)sb * GM::SEG, pitchM, lM);
+        stage_drain<GF>(gP + (long)sb * GF::SEG, pitchF, lF);
+    }
+    if (SMOOTH) filter_apply_tail<T, D>(a, k0 + a.Lc, s, sagg);
+}
+
+template <typename T, int D, bool SMOOTH, int G>
+__global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
+    constexpr int MAT = D * D, NF = Dim<D>::NFILT;
+    using FE = FiltElem<T, D>;
+    using SE = SmthElem<T, D>;
+    using MC = MeanCov<T, D>;
+    using CFG = StageCfg<T, D, G>;
+    __shared__ T lds[kWaves * NF];
+    __shared__ double lds_ll[kWaves];
+    __shared__ __attribute__((aligned(16))) char stage[kWaves][CFG::F3_BYTES];
+
+    T h[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) h[i] = a.H[i];
+
+    const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long k0 = gt * a.Lc;
+    const long k1 = min(a.N, k0 + a.Lc);
+    const int wave = threadIdx.x / kWave;
+    const long wbase = ((long)blockIdx.x * kBlock + wave * kWave) * a.Lc;
 
     // state entering this segment
     MC s;
@@ -474,67 +762,12 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     LogLik ll;
     SE sagg;
     smth_identity(sagg);
-
-    if (k0 < k1) {
-        T Fn[MAT], Qn[MAT];
-        T yn;
-        load_rec<T, MAT>(a.Fs + k0 * MAT, Fn);
-        load_rec<T, MAT>(a.Qs + k0 * MAT, Qn);
-        yn = a.ys[k0];
-        MC prev = s;
-        for (long k = k0; k < k1; ++k) {
-            T F[MAT], Q[SYM];
-#pragma unroll
-            for (int i = 0; i < MAT; ++i) F[i] = Fn[i];
-            sym_from_full<T, D>(Qn, Q);
-            const T y = yn;
-            if (k + 1 < a.N) {                      // next step (the halo step k1 included)
-                if (SMOOTH || k + 1 < k1) {
-                    load_rec<T, MAT>(a.Fs + (k + 1) * MAT, Fn);
-                    load_rec<T, MAT>(a.Qs + (k + 1) * MAT, Qn);
-                }
-                if (k + 1 < k1) yn = a.ys[k + 1];
-            }
-            T mp[D], Pp[SYM], FP[MAT];
-            kf_step(s, F, Q, y, h, a.R, (k == 0) && a.seg_first, ll, mp, Pp, FP);
-            if (SMOOTH && k > k0) {                 // element of step k-1 from this step's predict
-                SE e, r;
-                smth_element(prev, mp, Pp, FP, e);
-                smth_combine(sagg, e, r);
-                sagg = r;
-            }
-            store_rec<T, D>(a.fms + k * D, s.m);
-            {
-                T Pf[MAT];
-                full_from_sym<T, D>(s.P, Pf);
-                store_rec<T, MAT>(a.fPs + k * MAT, Pf);
-            }
-            prev = s;
-        }
-        if (SMOOTH) {
-            // element of this chunk's last step: needs the predict of step k1
-            SE e, r;
-            if (k1 < a.N || !a.seg_last) {
-                T F[MAT], Qf[MAT], Q[SYM];
-                if (k1 < a.N) {
-#pragma unroll
-                    for (int i = 0; i < MAT; ++i) { F[i] = Fn[i]; Qf[i] = Qn[i]; }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < MAT; ++i) { F[i] = a.halo_FQ[i]; Qf[i] = a.halo_FQ[MAT + i]; }
-                }
-                sym_from_full<T, D>(Qf, Q);
-                T mp[D], Pp[SYM], FP[MAT];
-                mat_vec<T, D>(F, s.m, mp);
-                predict_cov<T, D>(F, s.P, Q, FP, Pp);
-                smth_element(s, mp, Pp, FP, e);
-            } else {
-                smth_last(s, e);
-            }
-            smth_combine(sagg, e, r);
-            sagg = r;
-        }
+    bool staged = false;
+    if constexpr (CFG::on) {
+        staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
+        if (staged) lane_filter_apply_staged<T, D, SMOOTH, G>(a, wbase, stage[wave], h, s, ll, sagg);
     }
+    if (!staged) lane_filter_apply_direct<T, D, SMOOTH>(a, k0, k1, h, s, ll, sagg);
 
     // log-likelihood partial of this workgroup
     {
@@ -602,17 +835,147 @@ __global__ __launch_bounds__(kBlock) void k_smoother_reduce(const ScanArgs<T> a)
 // ---------------------------------------------------------------------------------------------
 // K-S3: smoother apply
 // ---------------------------------------------------------------------------------------------
+// one RTS step: f = filtered (m, P) of step k; (F, Qf) = transition INTO step k+1; s = smoothed k+1 -> k
 template <typename T, int D>
+__device__ __forceinline__ void smoother_apply_step(const T* F, const T* Qf, const T* mk, const T* Pkf, bool last,
+                                                    MeanCov<T, D>& s) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM;
+    MeanCov<T, D> f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) f.m[i] = mk[i];
+    sym_from_full<T, D>(Pkf, f.P);
+    if (last) {
+        s = f;                              // last element of the series: (0, m_N, P_N)
+    } else {
+        T Q[SYM], mp[D], Pp[SYM], FP[MAT];
+        sym_from_full<T, D>(Qf, Q);
+        mat_vec<T, D>(F, f.m, mp);
+        predict_cov<T, D>(F, f.P, Q, FP, Pp);
+        rts_step(f, mp, Pp, FP, s);
+    }
+}
+
+// (F, Q) of the step after a chunk: next chunk's first step, the next segment's (halo), or none
+template <typename T, int D>
+__device__ __forceinline__ void smoother_halo(const ScanArgs<T>& a, long k1, T* Fn, T* Qn) {
+    constexpr int MAT = D * D;
+    if (k1 < a.N) {
+        load_rec<T, MAT>(a.Fs + k1 * MAT, Fn);
+        load_rec<T, MAT>(a.Qs + k1 * MAT, Qn);
+    } else if (!a.seg_last) {
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) { Fn[i] = a.halo_FQ[i]; Qn[i] = a.halo_FQ[MAT + i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) { Fn[i] = T(0); Qn[i] = T(0); }
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void lane_smoother_apply_direct(const ScanArgs<T>& a, long k0, long k1, MeanCov<T, D>& s) {
+    constexpr int MAT = D * D;
+    if (k0 >= k1) return;
+    T Fn[MAT], Qn[MAT], mn[D], Pn[MAT];
+    const bool end_of_series = (k1 == a.N) && a.seg_last;
+    smoother_halo<T, D>(a, k1, Fn, Qn);
+    load_rec<T, D>(a.fms + (k1 - 1) * D, mn);
+    load_rec<T, MAT>(a.fPs + (k1 - 1) * MAT, Pn);
+    for (long k = k1 - 1; k >= k0; --k) {
+        T F[MAT], Qf[MAT], mk[D], Pk[MAT];
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) { F[i] = Fn[i]; Qf[i] = Qn[i]; Pk[i] = Pn[i]; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) mk[i] = mn[i];
+        if (k > k0) {
+            load_rec<T, MAT>(a.Fs + k * MAT, Fn);
+            load_rec<T, MAT>(a.Qs + k * MAT, Qn);
+            load_rec<T, D>(a.fms + (k - 1) * D, mn);
+            load_rec<T, MAT>(a.fPs + (k - 1) * MAT, Pn);
+        }
+        smoother_apply_step<T, D>(F, Qf, mk, Pk, end_of_series && k == k1 - 1, s);
+        store_rec<T, D>(a.sms + k * D, s.m);
+        T Pf[MAT];
+        full_from_sym<T, D>(s.P, Pf);
+        store_rec<T, MAT>(a.sPs + k * MAT, Pf);
+    }
+}
+
+template <typename T, int D, int G>
+__device__ __forceinline__ void lane_smoother_apply_staged(const ScanArgs<T>& a, long wbase, char* lds,
+                                                           MeanCov<T, D>& s) {
+    using CFG = StageCfg<T, D, G>;
+    using GF = typename CFG::GF;
+    using GM = typename CFG::GM;
+    constexpr int MAT = D * D;
+    const int lane = threadIdx.x & (kWave - 1);
+    char* lF = lds;
+    char* lQ = lF + GF::BYTES;
+    char* lP = lQ + GF::BYTES;          // P in, sP out
+    char* lM = lP + GF::BYTES;          // m in, sm out
+    const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchM = (long)a.Lc * D * sizeof(T);
+    const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
+    const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
+    const char* gP = reinterpret_cast<const char*>(a.fPs + wbase * MAT);
+    const char* gM = reinterpret_cast<const char*>(a.fms + wbase * D);
+    char* oP = reinterpret_cast<char*>(a.sPs + wbase * MAT);
+    char* oM = reinterpret_cast<char*>(a.sms + wbase * D);
+    const int S = a.Lc / G;
+    const long k1 = wbase + (long)(lane + 1) * a.Lc;
+    const bool end_of_series = (k1 == a.N) && a.seg_last;
+    T Fc[MAT], Qc[MAT];                 // transition into the step after the one being processed
+    smoother_halo<T, D>(a, k1, Fc, Qc);
+    V4 rF[GF::NV], rQ[GF::NV], rP[GF::NV], rM[GM::NV];
+    stage_issue<GF>(gF + (long)(S - 1) * GF::SEG, pitchF, rF);
+    stage_issue<GF>(gQ + (long)(S - 1) * GF::SEG, pitchF, rQ);
+    stage_issue<GF>(gP + (long)(S - 1) * GF::SEG, pitchF, rP);
+    stage_issue<GM>(gM + (long)(S - 1) * GM::SEG, pitchM, rM);
+    for (int sb = S - 1; sb >= 0; --sb) {
+        wave_lds_sync();
+        stage_commit<GF>(lF, rF);
+        stage_commit<GF>(lQ, rQ);
+        stage_commit<GF>(lP, rP);
+        stage_commit<GM>(lM, rM);
+        if (sb > 0) {
+            stage_issue<GF>(gF + (long)(sb - 1) * GF::SEG, pitchF, rF);
+            stage_issue<GF>(gQ + (long)(sb - 1) * GF::SEG, pitchF, rQ);
+            stage_issue<GF>(gP + (long)(sb - 1) * GF::SEG, pitchF, rP);
+            stage_issue<GM>(gM + (long)(sb - 1) * GM::SEG, pitchM, rM);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = G - 1; i >= 0; --i) {
+            T mk[D], Pk[MAT];
+            stage_get<GM, T, D>(lM, i, mk);
+            stage_get<GF, T, MAT>(lP, i, Pk);
+            smoother_apply_step<T, D>(Fc, Qc, mk, Pk, end_of_series && sb == S - 1 && i == G - 1, s);
+            stage_get<GF, T, MAT>(lF, i, Fc);       // transition into this step: used by step k-1
+            stage_get<GF, T, MAT>(lQ, i, Qc);
+            T Pf[MAT];
+            full_from_sym<T, D>(s.P, Pf);
+            stage_put<GM, T, D>(lM, i, s.m);
+            stage_put<GF, T, MAT>(lP, i, Pf);
+        }
+        wave_lds_sync();
+        stage_drain<GM>(oM + (long)sb * GM::SEG, pitchM, lM);
+        stage_drain<GF>(oP + (long)sb * GF::SEG, pitchF, lP);
+    }
+}
+
+template <typename T, int D, int G>
 __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM, NS = Dim<D>::NSMTH;
     using SE = SmthElem<T, D>;
     using MC = MeanCov<T, D>;
+    using CFG = StageCfg<T, D, G>;
     __shared__ T lds[kWaves * NS];
     __shared__ double lds_ll[kWaves];
+    __shared__ __attribute__((aligned(16))) char stage[kWaves][CFG::S3_BYTES];
 
     const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
     const long k0 = gt * a.Lc;
     const long k1 = min(a.N, k0 + a.Lc);
+    const int wave = threadIdx.x / kWave;
+    const long wbase = ((long)blockIdx.x * kBlock + wave * kWave) * a.Lc;
 
     // smoothed state of the first step AFTER this segment (irrelevant when seg_last: E = 0 there)
     MC s;
@@ -640,51 +1003,12 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
         smth_apply(ls, s);
     }
 
-    if (k0 < k1) {
-        // step k needs (F, Q) of step k+1 and the filtered (m, P) of step k
-        T Fn[MAT], Qn[MAT], mn[D], Pn[MAT];
-        const bool end_of_series = (k1 == a.N) && a.seg_last;
-        if (k1 < a.N) {
-            load_rec<T, MAT>(a.Fs + k1 * MAT, Fn);
-            load_rec<T, MAT>(a.Qs + k1 * MAT, Qn);
-        } else if (!a.seg_last) {
-#pragma unroll
-            for (int i = 0; i < MAT; ++i) { Fn[i] = a.halo_FQ[i]; Qn[i] = a.halo_FQ[MAT + i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MAT; ++i) { Fn[i] = T(0); Qn[i] = T(0); }
-        }
-        load_rec<T, D>(a.fms + (k1 - 1) * D, mn);
-        load_rec<T, MAT>(a.fPs + (k1 - 1) * MAT, Pn);
-        for (long k = k1 - 1; k >= k0; --k) {
-            T F[MAT], Q[SYM];
-            MC f;
-#pragma unroll
-            for (int i = 0; i < MAT; ++i) F[i] = Fn[i];
-            sym_from_full<T, D>(Qn, Q);
-#pragma unroll
-            for (int i = 0; i < D; ++i) f.m[i] = mn[i];
-            sym_from_full<T, D>(Pn, f.P);
-            if (k > k0) {
-                load_rec<T, MAT>(a.Fs + k * MAT, Fn);
-                load_rec<T, MAT>(a.Qs + k * MAT, Qn);
-                load_rec<T, D>(a.fms + (k - 1) * D, mn);
-                load_rec<T, MAT>(a.fPs + (k - 1) * MAT, Pn);
-            }
-            if (end_of_series && k == k1 - 1) {
-                s = f;                              // last element: (0, m_N, P_N)
-            } else {
-                T mp[D], Pp[SYM], FP[MAT];
-                mat_vec<T, D>(F, f.m, mp);
-                predict_cov<T, D>(F, f.P, Q, FP, Pp);
-                rts_step(f, mp, Pp, FP, s);
-            }
-            store_rec<T, D>(a.sms + k * D, s.m);
-            T Pf[MAT];
-            full_from_sym<T, D>(s.P, Pf);
-            store_rec<T, MAT>(a.sPs + k * MAT, Pf);
-        }
+    bool staged = false;
+    if constexpr (CFG::on) {
+        staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
+        if (staged) lane_smoother_apply_staged<T, D, G>(a, wbase, stage[wave], s);
     }
+    if (!staged) lane_smoother_apply_direct<T, D>(a, k0, k1, s);
 
     if (blockIdx.x == 0 && a.ll != nullptr) {
         double v = 0.0;

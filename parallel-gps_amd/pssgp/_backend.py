@@ -43,12 +43,14 @@ def _declare(lib):
     lib.pgps_set_stream.argtypes = [P, P]
     lib.pgps_synchronize.argtypes = [P]
     lib.pgps_set_chunk.argtypes = [P, c_int]
+    lib.pgps_set_stage.argtypes = [P, c_int]
     lib.pgps_get_chunk.argtypes = [P, c_long, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_malloc.argtypes = [P, ctypes.c_size_t, ctypes.POINTER(P)]
     lib.pgps_free.argtypes = [P, P]
     lib.pgps_memcpy_h2d.argtypes = [P, P, P, ctypes.c_size_t]
     lib.pgps_memcpy_d2h.argtypes = [P, P, P, ctypes.c_size_t]
     lib.pgps_profile_enable.argtypes = [P, c_int]
+    lib.pgps_profile_sample.argtypes = [P, c_int]
     lib.pgps_profile_read.argtypes = [P, ctypes.POINTER(c_double), ctypes.POINTER(c_long), c_int]
     lib.pgps_seg_record_len.argtypes = [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     for suf, real in (("f64", c_double), ("f32", c_float)):
@@ -116,6 +118,10 @@ class Context:
     def set_chunk(self, steps_per_lane):
         check(self, self.lib.pgps_set_chunk(self.handle, int(steps_per_lane)), "pgps_set_chunk")
 
+    def set_stage(self, steps_per_subtile):
+        """-1 auto, 0 direct global accesses, 2 / 4 steps per LDS-staged sub-tile."""
+        check(self, self.lib.pgps_set_stage(self.handle, int(steps_per_subtile)), "pgps_set_stage")
+
     def get_chunk(self, n_steps):
         lc, nb = c_int(0), c_int(0)
         check(self, self.lib.pgps_get_chunk(self.handle, int(n_steps), ctypes.byref(lc), ctypes.byref(nb)),
@@ -131,6 +137,9 @@ class Context:
     def profile_enable(self, mask=0x3f):
         """mask: bit i = time every launch of kernel slot i (PGPS_K_*); 0 = off."""
         check(self, self.lib.pgps_profile_enable(self.handle, int(mask)), "pgps_profile_enable")
+
+    def profile_sample(self, every_n):
+        check(self, self.lib.pgps_profile_sample(self.handle, int(every_n)), "pgps_profile_sample")
 
     def profile_read(self, reset=True):
         k = 6

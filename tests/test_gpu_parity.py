@@ -82,6 +82,30 @@ def test_chunk_size_invariance(chunk):
         ctx.set_chunk(0)
 
 
+@pytest.mark.parametrize("stage", [0, 2, 4])
+@pytest.mark.parametrize("chunk", [4, 8, 12])
+@pytest.mark.parametrize("dtype,kname", [(np.float64, "m32"), (np.float64, "m12"), (np.float32, "m32")])
+def test_lds_staged_paths(stage, chunk, dtype, kname):
+    """The coalesced global<->LDS staged path (d <= 2) against the oracle, for every sub-tile
+    size, with a ragged tail (the last wavefronts fall back to direct accesses)."""
+    from pssgp.kernels import Matern12, Matern32
+    B = _gpu()
+    ctx = B.get_context()
+    k = Matern32(1., 1.) if kname == "m32" else Matern12(1., 1.)
+    n = 256 * chunk * 3 + 64 * chunk + 17
+    t = make_times(n, seed=chunk)
+    ssm = O.get_ssm(k.get_sde(), t, 0.1)
+    y = sample_series_fast(ssm, seed=chunk, nan_frac=0.1)
+    want = _oracle_all(ssm, y)
+    try:
+        ctx.set_chunk(chunk)
+        ctx.set_stage(stage)
+        _check_all(_gpu_all(ssm, y, dtype), want, TOL64 if dtype == np.float64 else TOL32)
+    finally:
+        ctx.set_chunk(0)
+        ctx.set_stage(-1)
+
+
 def test_missing_data_patterns():
     """All observations missing, first missing, last missing, long gaps."""
     from pssgp.kernels import Matern32

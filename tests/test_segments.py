@@ -199,7 +199,9 @@ def test_segments_on_one_gpu(world, dtype):
         (Ao, bo, Co, Jo, etao), F0o, Q0o = unpack_filter_record(gf_o[r], d)
         assert relerr(b, bo) < tol and relerr(C, Co) < tol and relerr(F0, F0o) < tol and relerr(Q0, Q0o) < tol
         if r > 0:       # J, eta of a prefix that holds the first element never reach an output
-            assert relerr(A, Ao) < tol and relerr(J, Jo) < tol and relerr(eta, etao) < tol
+            # A of a long segment underflows towards 0 (the filter forgets): absolute scale 1
+            assert np.max(np.abs(A - Ao)) < tol * max(1.0, np.max(np.abs(Ao)))
+            assert relerr(J, Jo) < tol and relerr(eta, etao) < tol
     for r, k in enumerate(ranks):
         k["gf"].put(gf)
         k["ctx"].call(f"pgps_seg_filter_apply_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p,
