@@ -49,8 +49,11 @@ int pgps_device_count(int* n);
 /* Create a context on HIP device `device` (own non-blocking stream + scratch). */
 int pgps_create(int device, pgps_ctx** out);
 int pgps_destroy(pgps_ctx* ctx);
-/* Borrow an external hipStream_t (e.g. the caller's framework stream); NULL = own stream. */
+/* Launch on an external hipStream_t (e.g. the caller's framework stream).  NULL is the HIP null
+ * (default) stream, exactly as in HIP; pgps_use_own_stream goes back to the context's own
+ * non-blocking stream (the state after pgps_create). */
 int pgps_set_stream(pgps_ctx* ctx, void* hip_stream);
+int pgps_use_own_stream(pgps_ctx* ctx);
 int pgps_synchronize(pgps_ctx* ctx);
 /* Steps per lane of the scan kernels; 0 = automatic. */
 int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);

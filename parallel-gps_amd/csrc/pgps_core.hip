@@ -75,6 +75,7 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
+    if (ctx->stamps.p) (void)hipFree(ctx->stamps.p);
     for (auto& b : ctx->st)
         if (b.p) (void)hipFree(b.p);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -85,7 +86,13 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
 
 extern "C" int pgps_set_stream(pgps_ctx* ctx, void* s) {
     if (!ctx) return PGPS_E_INVALID;
-    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    ctx->stream = (hipStream_t)s;       // NULL = the HIP null (default) stream, as in HIP itself
+    return PGPS_OK;
+}
+
+extern "C" int pgps_use_own_stream(pgps_ctx* ctx) {
+    if (!ctx) return PGPS_E_INVALID;
+    ctx->stream = ctx->own_stream;
     return PGPS_OK;
 }
 
@@ -98,6 +105,15 @@ extern "C" int pgps_synchronize(pgps_ctx* ctx) {
 extern "C" int pgps_set_chunk(pgps_ctx* ctx, int c) {
     if (!ctx || c < 0) return PGPS_E_INVALID;
     ctx->chunk = c;
+    return PGPS_OK;
+}
+
+// diagnostic build only: copy the (3, nblocks, 8) stamp buffer of the last scan to the host
+extern "C" int pgps_debug_read_stamps(pgps_ctx* ctx, long long* out, long n_values) {
+    if (!ctx || !out) return PGPS_E_INVALID;
+    if (!ctx->stamps.p || (size_t)n_values * sizeof(long long) > ctx->stamps.cap) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, ctx->stamps.p, (size_t)n_values * sizeof(long long), hipMemcpyDeviceToHost));
     return PGPS_OK;
 }
 
@@ -226,13 +242,17 @@ namespace pgps {
 void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks) {
     int c = ctx->chunk;
     if (c <= 0) {
-        // aim at ~512 workgroups (2 per CU) once the series is long enough; never less than one
-        // step per lane, and keep the spine (one entry per workgroup) at <= 1024 entries
-        const long target_blocks = 512;
-        long v = (N + (long)kBlock * target_blocks - 1) / ((long)kBlock * target_blocks);
+        // 16 steps per lane (the lane-serial part then outweighs the scan trees: measured at 2^20)
+        // until that would need more than 1024 workgroups (every workgroup folds the spine entries
+        // on its side); shorter series use fewer steps per lane so the chip is still covered;
+        // multiples of 4 = whole LDS-staged sub-tiles.
+        long v = 16;
+        const long max_blocks = 1024;
+        if (N > (long)kBlock * v * max_blocks) v = (N + (long)kBlock * max_blocks - 1) / ((long)kBlock * max_blocks);
+        while (v > 4 && (long)kBlock * v * 128 > N) v /= 2;   // keep >= 128 workgroups when N allows
+        if (N < (long)kBlock * 4) v = (N + kBlock - 1) / kBlock;
         if (v < 1) v = 1;
-        if (N >= (long)kBlock * 4 && v < 4) v = 4;
-        if (v > 4) v = (v + 3) / 4 * 4;     // whole LDS-staged sub-tiles (4 steps per lane)
+        if (v > 4) v = (v + 3) / 4 * 4;
         c = (int)v;
     }
     long nb = (N + (long)kBlock * c - 1) / ((long)kBlock * c);

@@ -34,6 +34,11 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     a.llpart = (double*)(base + o_ll);
     a.status = (int*)(base + o_status);
     a.seg_ws = (T*)(base + o_seg);
+#ifdef PGPS_STAMPS
+    rc = ensure(ctx, ctx->stamps, (size_t)3 * nb * 8 * sizeof(long long));
+    if (rc) return rc;
+    a.stamps = (long long*)ctx->stamps.p;
+#endif
     return PGPS_OK;
 }
 

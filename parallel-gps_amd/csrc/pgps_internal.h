@@ -23,6 +23,7 @@ struct pgps_ctx {
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
+    DevBuf stamps;                      // diagnostic build only
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
     int prof_every = 1;                 // time every n-th launch of an enabled slot
     long prof_seen[PGPS_K_COUNT] = {0};
@@ -98,6 +99,7 @@ struct ScanArgs {
     T* rec_s;               // out: this segment's smoother record [NSMTH total | pad | ll partial (double)]
     const T* gathered_s;    // in : (nranks, REC_S)
     T* seg_ws;              // scratch: carry_in (d+d*d) | halo_FQ (2 d*d) | carry_back (d+d*d)
+    long long* stamps;      // diagnostic build only (-DPGPS_STAMPS): (3 kernels, nblocks, 8) s_memtime stamps
 };
 
 // record lengths (in elements of T) of the segment exchange

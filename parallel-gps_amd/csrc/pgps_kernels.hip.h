@@ -29,6 +29,19 @@
 
 namespace pgps {
 
+// In-kernel phase stamps: DIAGNOSTIC BUILD ONLY (make stamps).  Lane 0 of every workgroup stores
+// s_memtime at phase boundaries into a buffer nothing else reads; the shipped library compiles
+// PGPS_STAMP to nothing.
+#ifdef PGPS_STAMPS
+#define PGPS_STAMP(KERNEL, IDX)                                                                          \
+    do {                                                                                                 \
+        if (a.stamps && threadIdx.x == 0)                                                                \
+            a.stamps[((long)(KERNEL) * a.nblocks + blockIdx.x) * 8 + (IDX)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define PGPS_STAMP(KERNEL, IDX) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // vector loads / stores of small contiguous records (16-byte accesses when the record allows)
 // ---------------------------------------------------------------------------------------------
@@ -436,13 +449,13 @@ struct StageCfg {
 };
 
 // Fold spine entries [lo, hi) in time order over the whole workgroup; result in every lane.
+// Split in two so that a caller can put other global loads between the spine loads and the
+// arithmetic (loads retire in issue order: whatever is issued first is waited for first).
 template <typename E>
-__device__ __forceinline__ void fold_spine(const typename ElemTraits<E>::Scalar* spine, int lo, int hi, E& total,
-                                           typename ElemTraits<E>::Scalar* lds) {
+__device__ __forceinline__ void fold_spine_partial(const typename ElemTraits<E>::Scalar* spine, int lo, int hi, E& acc) {
     using TR = ElemTraits<E>;
     const int n = hi - lo;
     const int per = (n + kBlock - 1) / kBlock;
-    E acc;
     TR::identity(acc);
     const int b0 = lo + (int)threadIdx.x * per;
     const int b1 = min(hi, b0 + per);
@@ -452,9 +465,15 @@ __device__ __forceinline__ void fold_spine(const typename ElemTraits<E>::Scalar*
         rec_load(spine + (long)b * TR::N, e);
         if (have) { E r; TR::combine(acc, e, r); acc = r; } else { acc = e; have = true; }
     }
-    block_reduce_ordered(acc, total, lds);
 }
 
+template <typename E>
+__device__ __forceinline__ void fold_spine(const typename ElemTraits<E>::Scalar* spine, int lo, int hi, E& total,
+                                           typename ElemTraits<E>::Scalar* lds) {
+    E acc;
+    fold_spine_partial<E>(spine, lo, hi, acc);
+    block_reduce_ordered(acc, total, lds);
+}
 
 // ---------------------------------------------------------------------------------------------
 // K-F1: filter reduce
@@ -562,17 +581,21 @@ __global__ __launch_bounds__(kBlock) void k_filter_reduce(const ScanArgs<T> a) {
 
     FE agg;
     filt_identity(agg);
+    PGPS_STAMP(0, 0);
     bool staged = false;
     if constexpr (CFG::on) {
         staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
         if (staged) lane_filter_reduce_staged<T, D, G>(a, wbase, stage[wave], h, agg);
     }
     if (!staged) lane_filter_reduce_direct<T, D>(a, k0, k1, h, agg);
+    PGPS_STAMP(0, 1);
 
     FE excl, total;
     block_scan_exclusive<FE, true>(agg, excl, total, lds);
+    PGPS_STAMP(0, 2);
     ws_store(a.lpre, a.nlanes, gt, excl);
     if (threadIdx.x == 0) rec_store(a.spine + (long)blockIdx.x * Dim<D>::NFILT, total);
+    PGPS_STAMP(0, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -596,21 +619,34 @@ __device__ __forceinline__ void filter_apply_step(const ScanArgs<T>& a, long k, 
     }
 }
 
-// smoothing element of a chunk's last step: needs the predict of the step after the chunk
+// (F, Q) of the step after a chunk's last step: the next chunk's first step, the next segment's
+// first step (halo), or nothing at the end of the series.  Returns false in the last case.
 template <typename T, int D>
-__device__ __forceinline__ void filter_apply_tail(const ScanArgs<T>& a, long k1, const MeanCov<T, D>& s,
+__device__ __forceinline__ bool filter_tail_load(const ScanArgs<T>& a, long k1, T* F, T* Qf) {
+    constexpr int MAT = D * D;
+    if (k1 < a.N) {
+        load_rec<T, MAT>(a.Fs + k1 * MAT, F);
+        load_rec<T, MAT>(a.Qs + k1 * MAT, Qf);
+        return true;
+    }
+    if (!a.seg_last) {
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) { F[i] = a.halo_FQ[i]; Qf[i] = a.halo_FQ[MAT + i]; }
+        return true;
+    }
+#pragma unroll
+    for (int i = 0; i < MAT; ++i) { F[i] = T(0); Qf[i] = T(0); }
+    return false;
+}
+
+// smoothing element of a chunk's last step from the predict of the step after the chunk
+template <typename T, int D>
+__device__ __forceinline__ void filter_tail_apply(bool have_next, const T* F, const T* Qf, const MeanCov<T, D>& s,
                                                   SmthElem<T, D>& sagg) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM;
     SmthElem<T, D> e, r;
-    if (k1 < a.N || !a.seg_last) {
-        T F[MAT], Qf[MAT], Q[SYM];
-        if (k1 < a.N) {
-            load_rec<T, MAT>(a.Fs + k1 * MAT, F);
-            load_rec<T, MAT>(a.Qs + k1 * MAT, Qf);
-        } else {
-#pragma unroll
-            for (int i = 0; i < MAT; ++i) { F[i] = a.halo_FQ[i]; Qf[i] = a.halo_FQ[MAT + i]; }
-        }
+    if (have_next) {
+        T Q[SYM];
         sym_from_full<T, D>(Qf, Q);
         T mp[D], Pp[SYM], FP[MAT];
         mat_vec<T, D>(F, s.m, mp);
@@ -621,6 +657,14 @@ __device__ __forceinline__ void filter_apply_tail(const ScanArgs<T>& a, long k1,
     }
     smth_combine(sagg, e, r);
     sagg = r;
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void filter_apply_tail(const ScanArgs<T>& a, long k1, const MeanCov<T, D>& s,
+                                                  SmthElem<T, D>& sagg) {
+    T F[D * D], Qf[D * D];
+    const bool have_next = filter_tail_load<T, D>(a, k1, F, Qf);
+    filter_tail_apply<T, D>(have_next, F, Qf, s, sagg);
 }
 
 template <typename T, int D, bool SMOOTH>
@@ -652,62 +696,77 @@ __device__ __forceinline__ void lane_filter_apply_direct(const ScanArgs<T>& a, l
     if (SMOOTH) filter_apply_tail<T, D>(a, k1, s, sagg);
 }
 
+// Staged lane-serial Kalman pass.  prefetch() issues the first sub-tile's global loads (and the
+// halo step's) into registers; it is called BEFORE the workgroup folds the spine so that the
+// memory latency hides behind the fold's arithmetic.  run() streams the wave's span.
 template <typename T, int D, bool SMOOTH, int G>
-__device__ __forceinline__ void lane_filter_apply_staged(const ScanArgs<T>& a, long wbase, char* lds, const T* h,
-                                                         MeanCov<T, D>& s, LogLik& ll, SmthElem<T, D>& sagg) {
+struct FilterApplyStaged {
     using CFG = StageCfg<T, D, G>;
     using GF = typename CFG::GF;
     using GM = typename CFG::GM;
     using GY = typename CFG::GY;
-    constexpr int MAT = D * D;
-    const int lane = threadIdx.x & (kWave - 1);
-    char* lF = lds;                     // F in, P out
-    char* lQ = lF + GF::BYTES;
-    char* lY = lQ + GF::BYTES;
-    char* lM = lY + GY::BYTES;          // m out
-    const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchY = (long)a.Lc * sizeof(T),
-               pitchM = (long)a.Lc * D * sizeof(T);
-    const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
-    const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
-    const char* gY = reinterpret_cast<const char*>(a.ys + wbase);
-    char* gP = reinterpret_cast<char*>(a.fPs + wbase * MAT);
-    char* gM = reinterpret_cast<char*>(a.fms + wbase * D);
-    const int S = a.Lc / G;
-    const long k0 = wbase + (long)lane * a.Lc;
+    static constexpr int MAT = D * D;
     V4 rF[GF::NV], rQ[GF::NV], rY[GY::NV];
-    stage_issue<GF>(gF, pitchF, rF);
-    stage_issue<GF>(gQ, pitchF, rQ);
-    stage_issue<GY>(gY, pitchY, rY);
-    for (int sb = 0; sb < S; ++sb) {
-        wave_lds_sync();
-        stage_commit<GF>(lF, rF);
-        stage_commit<GF>(lQ, rQ);
-        stage_commit<GY>(lY, rY);
-        if (sb + 1 < S) {
-            stage_issue<GF>(gF + (long)(sb + 1) * GF::SEG, pitchF, rF);
-            stage_issue<GF>(gQ + (long)(sb + 1) * GF::SEG, pitchF, rQ);
-            stage_issue<GY>(gY + (long)(sb + 1) * GY::SEG, pitchY, rY);
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const long k = k0 + sb * G + i;
-            T F[MAT], Qf[MAT], yv[1];
-            stage_get<GF, T, MAT>(lF, i, F);
-            stage_get<GF, T, MAT>(lQ, i, Qf);
-            stage_get<GY, T, 1>(lY, i, yv);
-            filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, yv[0], h, s, ll, sagg);
-            T Pf[MAT];
-            full_from_sym<T, D>(s.P, Pf);
-            stage_put<GM, T, D>(lM, i, s.m);
-            stage_put<GF, T, MAT>(lF, i, Pf);       // F_k is dead after its predict
-        }
-        wave_lds_sync();
-        stage_drain<GM>(gM + (long)sb * GM::SEG, pitchM, lM);
-        stage_drain<GF>(gP + (long)sb * GF::SEG, pitchF, lF);
+    T Fh[MAT], Qh[MAT];
+    bool have_next;
+
+    __device__ __forceinline__ void prefetch(const ScanArgs<T>& a, long wbase) {
+        const int lane = threadIdx.x & (kWave - 1);
+        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchY = (long)a.Lc * sizeof(T);
+        stage_issue<GF>(reinterpret_cast<const char*>(a.Fs + wbase * MAT), pitchF, rF);
+        stage_issue<GF>(reinterpret_cast<const char*>(a.Qs + wbase * MAT), pitchF, rQ);
+        stage_issue<GY>(reinterpret_cast<const char*>(a.ys + wbase), pitchY, rY);
+        have_next = false;
+        if (SMOOTH) have_next = filter_tail_load<T, D>(a, wbase + (long)(lane + 1) * a.Lc, Fh, Qh);
     }
-    if (SMOOTH) filter_apply_tail<T, D>(a, k0 + a.Lc, s, sagg);
-}
+
+    __device__ __forceinline__ void run(const ScanArgs<T>& a, long wbase, char* lds, const T* h, MeanCov<T, D>& s,
+                                        LogLik& ll, SmthElem<T, D>& sagg) {
+        const int lane = threadIdx.x & (kWave - 1);
+        char* lF = lds;                     // F in, P out
+        char* lQ = lF + GF::BYTES;
+        char* lY = lQ + GF::BYTES;
+        char* lM = lY + GY::BYTES;          // m out
+        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchY = (long)a.Lc * sizeof(T),
+                   pitchM = (long)a.Lc * D * sizeof(T);
+        const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
+        const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
+        const char* gY = reinterpret_cast<const char*>(a.ys + wbase);
+        char* gP = reinterpret_cast<char*>(a.fPs + wbase * MAT);
+        char* gM = reinterpret_cast<char*>(a.fms + wbase * D);
+        const int S = a.Lc / G;
+        const long k0 = wbase + (long)lane * a.Lc;
+        for (int sb = 0; sb < S; ++sb) {
+            wave_lds_sync();
+            stage_commit<GF>(lF, rF);
+            stage_commit<GF>(lQ, rQ);
+            stage_commit<GY>(lY, rY);
+            if (sb + 1 < S) {
+                stage_issue<GF>(gF + (long)(sb + 1) * GF::SEG, pitchF, rF);
+                stage_issue<GF>(gQ + (long)(sb + 1) * GF::SEG, pitchF, rQ);
+                stage_issue<GY>(gY + (long)(sb + 1) * GY::SEG, pitchY, rY);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const long k = k0 + sb * G + i;
+                T F[MAT], Qf[MAT], yv[1];
+                stage_get<GF, T, MAT>(lF, i, F);
+                stage_get<GF, T, MAT>(lQ, i, Qf);
+                stage_get<GY, T, 1>(lY, i, yv);
+                filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, yv[0], h, s, ll, sagg);
+                T Pf[MAT];
+                full_from_sym<T, D>(s.P, Pf);
+                stage_put<GM, T, D>(lM, i, s.m);
+                stage_put<GF, T, MAT>(lF, i, Pf);       // F_k is dead after its predict
+            }
+            wave_lds_sync();
+            stage_drain<GM>(gM + (long)sb * GM::SEG, pitchM, lM);
+            stage_drain<GF>(gP + (long)sb * GF::SEG, pitchF, lF);
+        }
+        if (SMOOTH) filter_tail_apply<T, D>(have_next, Fh, Qh, s, sagg);
+    }
+};
 
 template <typename T, int D, bool SMOOTH, int G>
 __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
@@ -730,6 +789,18 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     const int wave = threadIdx.x / kWave;
     const long wbase = ((long)blockIdx.x * kBlock + wave * kWave) * a.Lc;
 
+    PGPS_STAMP(1, 0);
+    // small loads first (spine entries, this lane's local prefix), then the first sub-tile's
+    // prefetch: loads retire in order, so the fold below only waits for what it needs
+    FE left_part, lp;
+    if (blockIdx.x > 0) fold_spine_partial<FE>(a.spine, 0, (int)blockIdx.x, left_part);
+    ws_load(a.lpre, a.nlanes, gt, lp);
+    bool staged = false;
+    FilterApplyStaged<T, D, SMOOTH, CFG::GG> st;
+    if constexpr (CFG::on) {
+        staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
+        if (staged) st.prefetch(a, wbase);
+    }
     // state entering this segment
     MC s;
     if (a.seg_first) {
@@ -750,31 +821,29 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     // ... pushed through the workgroups to the left, then through this lane's local prefix
     if (blockIdx.x > 0) {
         FE left;
-        fold_spine<FE>(a.spine, 0, (int)blockIdx.x, left, lds);
+        block_reduce_ordered(left_part, left, lds);
         filt_apply(s, left);
     }
-    {
-        FE lp;
-        ws_load(a.lpre, a.nlanes, gt, lp);
-        filt_apply(s, lp);
-    }
+    PGPS_STAMP(1, 1);
+    filt_apply(s, lp);
+    PGPS_STAMP(1, 2);
 
     LogLik ll;
     SE sagg;
     smth_identity(sagg);
-    bool staged = false;
     if constexpr (CFG::on) {
-        staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
-        if (staged) lane_filter_apply_staged<T, D, SMOOTH, G>(a, wbase, stage[wave], h, s, ll, sagg);
+        if (staged) st.run(a, wbase, stage[wave], h, s, ll, sagg);
     }
     if (!staged) lane_filter_apply_direct<T, D, SMOOTH>(a, k0, k1, h, s, ll, sagg);
+    PGPS_STAMP(1, 3);
 
     // log-likelihood partial of this workgroup
     {
-        const double v = -0.5 * (double(ll.count) * 1.8378770664093453 + ll.logdet + ll.quad);
+        const double v = ll.value();
         const double t = block_sum_double(v, lds_ll);
         if (threadIdx.x == 0) a.llpart[blockIdx.x] = t;
     }
+    PGPS_STAMP(1, 4);
 
     if (SMOOTH) {
         SE excl, total;
@@ -782,6 +851,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
         ws_store(a.lsuf, a.nlanes, gt, excl);
         if (threadIdx.x == 0) rec_store(a.sspine + (long)blockIdx.x * Dim<D>::NSMTH, total);
     }
+    PGPS_STAMP(1, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -900,66 +970,75 @@ __device__ __forceinline__ void lane_smoother_apply_direct(const ScanArgs<T>& a,
     }
 }
 
+// Staged lane-serial RTS pass (sub-tiles in reverse); prefetch() as in FilterApplyStaged.
 template <typename T, int D, int G>
-__device__ __forceinline__ void lane_smoother_apply_staged(const ScanArgs<T>& a, long wbase, char* lds,
-                                                           MeanCov<T, D>& s) {
+struct SmootherApplyStaged {
     using CFG = StageCfg<T, D, G>;
     using GF = typename CFG::GF;
     using GM = typename CFG::GM;
-    constexpr int MAT = D * D;
-    const int lane = threadIdx.x & (kWave - 1);
-    char* lF = lds;
-    char* lQ = lF + GF::BYTES;
-    char* lP = lQ + GF::BYTES;          // P in, sP out
-    char* lM = lP + GF::BYTES;          // m in, sm out
-    const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchM = (long)a.Lc * D * sizeof(T);
-    const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
-    const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
-    const char* gP = reinterpret_cast<const char*>(a.fPs + wbase * MAT);
-    const char* gM = reinterpret_cast<const char*>(a.fms + wbase * D);
-    char* oP = reinterpret_cast<char*>(a.sPs + wbase * MAT);
-    char* oM = reinterpret_cast<char*>(a.sms + wbase * D);
-    const int S = a.Lc / G;
-    const long k1 = wbase + (long)(lane + 1) * a.Lc;
-    const bool end_of_series = (k1 == a.N) && a.seg_last;
-    T Fc[MAT], Qc[MAT];                 // transition into the step after the one being processed
-    smoother_halo<T, D>(a, k1, Fc, Qc);
+    static constexpr int MAT = D * D;
     V4 rF[GF::NV], rQ[GF::NV], rP[GF::NV], rM[GM::NV];
-    stage_issue<GF>(gF + (long)(S - 1) * GF::SEG, pitchF, rF);
-    stage_issue<GF>(gQ + (long)(S - 1) * GF::SEG, pitchF, rQ);
-    stage_issue<GF>(gP + (long)(S - 1) * GF::SEG, pitchF, rP);
-    stage_issue<GM>(gM + (long)(S - 1) * GM::SEG, pitchM, rM);
-    for (int sb = S - 1; sb >= 0; --sb) {
-        wave_lds_sync();
-        stage_commit<GF>(lF, rF);
-        stage_commit<GF>(lQ, rQ);
-        stage_commit<GF>(lP, rP);
-        stage_commit<GM>(lM, rM);
-        if (sb > 0) {
-            stage_issue<GF>(gF + (long)(sb - 1) * GF::SEG, pitchF, rF);
-            stage_issue<GF>(gQ + (long)(sb - 1) * GF::SEG, pitchF, rQ);
-            stage_issue<GF>(gP + (long)(sb - 1) * GF::SEG, pitchF, rP);
-            stage_issue<GM>(gM + (long)(sb - 1) * GM::SEG, pitchM, rM);
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int i = G - 1; i >= 0; --i) {
-            T mk[D], Pk[MAT];
-            stage_get<GM, T, D>(lM, i, mk);
-            stage_get<GF, T, MAT>(lP, i, Pk);
-            smoother_apply_step<T, D>(Fc, Qc, mk, Pk, end_of_series && sb == S - 1 && i == G - 1, s);
-            stage_get<GF, T, MAT>(lF, i, Fc);       // transition into this step: used by step k-1
-            stage_get<GF, T, MAT>(lQ, i, Qc);
-            T Pf[MAT];
-            full_from_sym<T, D>(s.P, Pf);
-            stage_put<GM, T, D>(lM, i, s.m);
-            stage_put<GF, T, MAT>(lP, i, Pf);
-        }
-        wave_lds_sync();
-        stage_drain<GM>(oM + (long)sb * GM::SEG, pitchM, lM);
-        stage_drain<GF>(oP + (long)sb * GF::SEG, pitchF, lP);
+    T Fc[MAT], Qc[MAT];                 // transition into the step after the one being processed
+
+    __device__ __forceinline__ void prefetch(const ScanArgs<T>& a, long wbase) {
+        const int lane = threadIdx.x & (kWave - 1);
+        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchM = (long)a.Lc * D * sizeof(T);
+        const int S = a.Lc / G;
+        stage_issue<GF>(reinterpret_cast<const char*>(a.Fs + wbase * MAT) + (long)(S - 1) * GF::SEG, pitchF, rF);
+        stage_issue<GF>(reinterpret_cast<const char*>(a.Qs + wbase * MAT) + (long)(S - 1) * GF::SEG, pitchF, rQ);
+        stage_issue<GF>(reinterpret_cast<const char*>(a.fPs + wbase * MAT) + (long)(S - 1) * GF::SEG, pitchF, rP);
+        stage_issue<GM>(reinterpret_cast<const char*>(a.fms + wbase * D) + (long)(S - 1) * GM::SEG, pitchM, rM);
+        smoother_halo<T, D>(a, wbase + (long)(lane + 1) * a.Lc, Fc, Qc);
     }
-}
+
+    __device__ __forceinline__ void run(const ScanArgs<T>& a, long wbase, char* lds, MeanCov<T, D>& s) {
+        const int lane = threadIdx.x & (kWave - 1);
+        char* lF = lds;
+        char* lQ = lF + GF::BYTES;
+        char* lP = lQ + GF::BYTES;          // P in, sP out
+        char* lM = lP + GF::BYTES;          // m in, sm out
+        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchM = (long)a.Lc * D * sizeof(T);
+        const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
+        const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
+        const char* gP = reinterpret_cast<const char*>(a.fPs + wbase * MAT);
+        const char* gM = reinterpret_cast<const char*>(a.fms + wbase * D);
+        char* oP = reinterpret_cast<char*>(a.sPs + wbase * MAT);
+        char* oM = reinterpret_cast<char*>(a.sms + wbase * D);
+        const int S = a.Lc / G;
+        const long k1 = wbase + (long)(lane + 1) * a.Lc;
+        const bool end_of_series = (k1 == a.N) && a.seg_last;
+        for (int sb = S - 1; sb >= 0; --sb) {
+            wave_lds_sync();
+            stage_commit<GF>(lF, rF);
+            stage_commit<GF>(lQ, rQ);
+            stage_commit<GF>(lP, rP);
+            stage_commit<GM>(lM, rM);
+            if (sb > 0) {
+                stage_issue<GF>(gF + (long)(sb - 1) * GF::SEG, pitchF, rF);
+                stage_issue<GF>(gQ + (long)(sb - 1) * GF::SEG, pitchF, rQ);
+                stage_issue<GF>(gP + (long)(sb - 1) * GF::SEG, pitchF, rP);
+                stage_issue<GM>(gM + (long)(sb - 1) * GM::SEG, pitchM, rM);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int i = G - 1; i >= 0; --i) {
+                T mk[D], Pk[MAT];
+                stage_get<GM, T, D>(lM, i, mk);
+                stage_get<GF, T, MAT>(lP, i, Pk);
+                smoother_apply_step<T, D>(Fc, Qc, mk, Pk, end_of_series && sb == S - 1 && i == G - 1, s);
+                stage_get<GF, T, MAT>(lF, i, Fc);       // transition into this step: used by step k-1
+                stage_get<GF, T, MAT>(lQ, i, Qc);
+                T Pf[MAT];
+                full_from_sym<T, D>(s.P, Pf);
+                stage_put<GM, T, D>(lM, i, s.m);
+                stage_put<GF, T, MAT>(lP, i, Pf);
+            }
+            wave_lds_sync();
+            stage_drain<GM>(oM + (long)sb * GM::SEG, pitchM, lM);
+            stage_drain<GF>(oP + (long)sb * GF::SEG, pitchF, lP);
+        }
+    }
+};
 
 template <typename T, int D, int G>
 __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) {
@@ -977,6 +1056,16 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
     const int wave = threadIdx.x / kWave;
     const long wbase = ((long)blockIdx.x * kBlock + wave * kWave) * a.Lc;
 
+    PGPS_STAMP(2, 0);
+    SE right_part, ls;
+    if ((int)blockIdx.x + 1 < a.nblocks) fold_spine_partial<SE>(a.sspine, (int)blockIdx.x + 1, a.nblocks, right_part);
+    ws_load(a.lsuf, a.nlanes, gt, ls);
+    bool staged = false;
+    SmootherApplyStaged<T, D, CFG::GG> st;
+    if constexpr (CFG::on) {
+        staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
+        if (staged) st.prefetch(a, wbase);
+    }
     // smoothed state of the first step AFTER this segment (irrelevant when seg_last: E = 0 there)
     MC s;
     if (a.seg_last) {
@@ -994,21 +1083,18 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
     }
     if ((int)blockIdx.x + 1 < a.nblocks) {
         SE right;
-        fold_spine<SE>(a.sspine, (int)blockIdx.x + 1, a.nblocks, right, lds);
+        block_reduce_ordered(right_part, right, lds);
         smth_apply(right, s);
     }
-    {
-        SE ls;
-        ws_load(a.lsuf, a.nlanes, gt, ls);
-        smth_apply(ls, s);
-    }
+    PGPS_STAMP(2, 1);
+    smth_apply(ls, s);
+    PGPS_STAMP(2, 2);
 
-    bool staged = false;
     if constexpr (CFG::on) {
-        staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
-        if (staged) lane_smoother_apply_staged<T, D, G>(a, wbase, stage[wave], s);
+        if (staged) st.run(a, wbase, stage[wave], s);
     }
     if (!staged) lane_smoother_apply_direct<T, D>(a, k0, k1, s);
+    PGPS_STAMP(2, 3);
 
     if (blockIdx.x == 0 && a.ll != nullptr) {
         double v = 0.0;

@@ -431,10 +431,25 @@ PGPS_HD void filt_apply(MeanCov<T, D>& s, const FiltElem<T, D>& e2) {
 // P0 directly (parallel.py:24-30) while the likelihood term uses F0 P0 F0^T + Q0
 // (parallel.py:136-141).  Outputs mp, Pp (the predicted moments) for the smoother element.
 // ------------------------------------------------------------------------------------
+// Log-likelihood accumulator.  sum_k log s2_k is kept as a product of mantissas plus an exponent
+// count (frexp is two cheap instructions on the GPU; an fp64 log is ~80): one log at the end.
 struct LogLik {
     double quad = 0.0;      // sum (y - mu)^2 / s2
-    double logdet = 0.0;    // sum log s2
+    double mant = 1.0;      // product of the mantissas of s2, renormalised to [0.5, 1) every step
+    long long expo = 0;     // sum of the binary exponents of s2
     long long count = 0;    // number of observed steps
+
+    PGPS_HD void add(double r, double S) {
+        quad += r * r / S;
+        int e;
+        mant = std::frexp(mant * S, &e);
+        expo += e;
+        count += 1;
+    }
+    PGPS_HD double value() const {
+        const double logdet = std::log(mant) + double(expo) * 0.6931471805599453;
+        return -0.5 * (double(count) * 1.8378770664093453 + logdet + quad);
+    }
 };
 
 template <typename T, int D>
@@ -449,10 +464,7 @@ PGPS_HD void kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, cons
 #pragma unroll
     for (int i = 0; i < D; ++i) { S += h[i] * u[i]; mu += h[i] * mp[i]; }
     if (obs) {
-        const double r = double(y) - double(mu);
-        ll.quad += r * r / double(S);
-        ll.logdet += std::log(double(S));
-        ll.count += 1;
+        ll.add(double(y) - double(mu), double(S));
     }
     if (first) {
         // update straight from the prior (s holds m0 = 0, P0)

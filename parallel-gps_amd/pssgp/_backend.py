@@ -41,6 +41,7 @@ def _declare(lib):
     lib.pgps_create.argtypes = [c_int, ctypes.POINTER(P)]
     lib.pgps_destroy.argtypes = [P]
     lib.pgps_set_stream.argtypes = [P, P]
+    lib.pgps_use_own_stream.argtypes = [P]
     lib.pgps_synchronize.argtypes = [P]
     lib.pgps_set_chunk.argtypes = [P, c_int]
     lib.pgps_set_stage.argtypes = [P, c_int]
@@ -129,7 +130,11 @@ class Context:
         return lc.value, nb.value
 
     def set_stream(self, hip_stream_handle):
+        """Launch on an external hipStream_t (an integer handle; 0 / None = the HIP null stream)."""
         check(self, self.lib.pgps_set_stream(self.handle, c_void_p(hip_stream_handle or 0)), "pgps_set_stream")
+
+    def use_own_stream(self):
+        check(self, self.lib.pgps_use_own_stream(self.handle), "pgps_use_own_stream")
 
     def synchronize(self):
         check(self, self.lib.pgps_synchronize(self.handle), "pgps_synchronize")

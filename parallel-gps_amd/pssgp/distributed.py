@@ -25,6 +25,13 @@ import ctypes
 
 import numpy as np
 
+# NOTE: import this module (or torch) BEFORE the first libpgps context is created: PyTorch-ROCm ships
+# its own HIP runtime and both libraries must share one copy of it in the process.
+try:
+    import torch as _torch  # noqa: F401
+except Exception:  # torch is only needed by SegmentScan
+    _torch = None
+
 
 def record_lengths(d):
     """(rec_filter, rec_smoother, smoother pad) in scalars -- must match pgps_seg_record_len."""

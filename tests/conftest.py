@@ -4,6 +4,15 @@ import sys
 import numpy as np
 import pytest
 
+# PyTorch-ROCm bundles its own HIP/HSA runtime.  A process that uses both torch and libpgps must
+# load torch FIRST so that libpgps' libamdhip64 dependency resolves to the copy already in the
+# process (two HSA runtimes in one process = "No HIP GPUs are available").  Only the multi-GPU
+# driver tests and bench.py use torch; the product library itself does not.
+try:  # pragma: no cover
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "parallel-gps_amd")):
     if p not in sys.path:

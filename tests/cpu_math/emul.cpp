@@ -100,7 +100,7 @@ static int run(long N, int Lc, int W, const T* P0f, const T* Fs, const T* Qs, co
             prev = cur;
         }
     }
-    *ll_out = -0.5 * (ll.count * 1.8378770664093453 + ll.logdet + ll.quad);
+    *ll_out = ll.value();
     // phase 4: suffix scan of smoothing aggregates
     sincl = sagg;
     for (long g0 = 0; g0 < nth; g0 += W) {

@@ -1,0 +1,47 @@
+"""Phase breakdown of the three scan kernels from the diagnostic build (make -C parallel-gps_amd/csrc stamps).
+Run on the GPU box:  PGPS_LIB=parallel-gps_amd/pssgp/libpgps_stamps.so python tools/stamps.py [chunk] [stage]"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("PGPS_LIB", os.path.join(ROOT, "parallel-gps_amd", "pssgp", "libpgps_stamps.so"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "parallel-gps_amd"))
+import numpy as np
+from pssgp import _backend as B
+from pssgp.kernels import Matern32
+
+chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+stage = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+n, d = 1 << 20, 2
+ctx = B.Context(0)
+ctx.set_chunk(chunk); ctx.set_stage(stage)
+sde = Matern32(1., 1.).get_sde()
+rng = np.random.default_rng(0)
+ts = np.cumsum(0.05 * rng.uniform(0.5, 1.5, n))
+Fs, Qs = B.discretise(sde.F, sde.P0, ts, 0.0)
+ys = rng.standard_normal(n)
+def dev(a):
+    a = np.ascontiguousarray(a, dtype=np.float64); p = ctx.malloc(a.nbytes); ctx.h2d(p, a); return p
+P0, F_, Q_, H, Y = dev(sde.P0), dev(Fs), dev(Qs), dev(sde.H.reshape(-1)), dev(ys)
+fms, fPs, sms, sPs, ll = (ctx.malloc(n * d * 8), ctx.malloc(n * d * d * 8), ctx.malloc(n * d * 8),
+                          ctx.malloc(n * d * d * 8), ctx.malloc(16))
+P = ctypes.c_void_p
+for it in range(5):
+    ctx.call("pgps_pkfs_dev_f64", ctypes.c_long(n), ctypes.c_int(d), P(P0), P(F_), P(Q_), P(H), ctypes.c_double(0.1),
+             P(Y), P(fms), P(fPs), P(sms), P(sPs), P(ll))
+ctx.synchronize()
+lc, nb = ctx.get_chunk(n)
+buf = np.zeros((3, nb, 8), dtype=np.int64)
+ctx.lib.pgps_debug_read_stamps.argtypes = [P, P, ctypes.c_long]
+B.check(ctx, ctx.lib.pgps_debug_read_stamps(ctx.handle, buf.ctypes.data_as(P), buf.size), "read_stamps")
+names = {0: ["lane-serial reduce", "block scan", "store lpre/spine"],
+         1: ["fold spine (prologue)", "lpre load+apply", "lane-serial KF+smooth-agg", "ll reduce", "suffix scan+store"],
+         2: ["fold sspine (prologue)", "lsuf load+apply", "lane-serial RTS"]}
+print(f"chunk {lc}, {nb} workgroups, stage {stage}; s_memtime ticks are 100 MHz-domain? printing raw ticks and share")
+for k, kn in enumerate(["k_filter_reduce", "k_filter_apply", "k_smoother_apply"]):
+    st = buf[k]
+    nph = len(names[k])
+    dur = np.diff(st[:, :nph + 1], axis=1).astype(np.float64)
+    tot = dur.sum(axis=1)
+    span = st[:, nph].max() - st[:, 0].min()
+    print(f"{kn}: median workgroup total {np.median(tot):.0f} ticks; first-start to last-end {span} ticks")
+    for i, nm in enumerate(names[k]):
+        print(f"    {nm:32s} median {np.median(dur[:, i]):9.0f}  max {dur[:, i].max():9.0f}  share {np.median(dur[:, i]) / np.median(tot):5.1%}")
