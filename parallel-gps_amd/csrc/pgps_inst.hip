@@ -118,7 +118,7 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
 }
 
 // G = steps per lane per LDS-staged sub-tile (0 = direct global accesses); staging exists for
-// d <= 2 only (StageCfg), G = 2 only in fp64 (a lane segment must be >= 16 bytes).
+// d <= 3 only (StageCfg), G = 2 only in fp64 (a lane segment must be >= 16 bytes).
 template <typename T, int D>
 int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     if constexpr (D <= 2) {
@@ -127,6 +127,10 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         if constexpr (sizeof(T) == 8) {
             if (g == 2) return launch_scan_g<T, D, 2>(ctx, a, mode);
         }
+    } else if constexpr (D == 3) {
+        // 144-byte lane segments: 2 steps of 72-byte fp64 records or 4 steps of 36-byte fp32 ones
+        constexpr int g3 = (sizeof(T) == 8) ? 2 : 4;
+        if (ctx->stage_g != 0) return launch_scan_g<T, D, g3>(ctx, a, mode);
     }
     return launch_scan_g<T, D, 0>(ctx, a, mode);
 }

@@ -435,10 +435,11 @@ __device__ __forceinline__ void stage_put(char* lds, int i, const T* in) {
     store_rec<T, N>(reinterpret_cast<T*>(lds + lane * GEO::STRIDE) + i * N, in);
 }
 
-// staging is used when a record is small (d <= 2); G = steps per lane per sub-tile
+// staging is used when a record is small: d <= 2, and d = 3 with 144-byte lane segments
+// (fp64 G = 2, fp32 G = 4); G = steps per lane per sub-tile
 template <typename T, int D, int G>
 struct StageCfg {
-    static constexpr bool on = (G > 0) && (D <= 2);
+    static constexpr bool on = (G > 0) && (D <= 2 || (D == 3 && G * (int)sizeof(T) == 16));
     static constexpr int GG = on ? G : 4;
     using GF = StageGeom<D * D * (int)sizeof(T), GG>;     // F, Q, P records
     using GM = StageGeom<D * (int)sizeof(T), GG>;         // m records
@@ -716,8 +717,10 @@ struct FilterApplyStaged {
         stage_issue<GF>(reinterpret_cast<const char*>(a.Fs + wbase * MAT), pitchF, rF);
         stage_issue<GF>(reinterpret_cast<const char*>(a.Qs + wbase * MAT), pitchF, rQ);
         stage_issue<GY>(reinterpret_cast<const char*>(a.ys + wbase), pitchY, rY);
+        // the halo step of lane l is the first step of lane l+1: after the first sub-tile is in LDS
+        // it is fetched from there (run()); only the wave's last lane reads global memory
         have_next = false;
-        if (SMOOTH) have_next = filter_tail_load<T, D>(a, wbase + (long)(lane + 1) * a.Lc, Fh, Qh);
+        if (SMOOTH && lane == kWave - 1) have_next = filter_tail_load<T, D>(a, wbase + (long)kWave * a.Lc, Fh, Qh);
     }
 
     __device__ __forceinline__ void run(const ScanArgs<T>& a, long wbase, char* lds, const T* h, MeanCov<T, D>& s,
@@ -747,6 +750,12 @@ struct FilterApplyStaged {
                 stage_issue<GY>(gY + (long)(sb + 1) * GY::SEG, pitchY, rY);
             }
             wave_lds_sync();
+            if (SMOOTH && sb == 0 && lane < kWave - 1) {
+                // record 0 of the next lane = this lane's halo step
+                load_rec<T, MAT>(reinterpret_cast<const T*>(lF + (lane + 1) * GF::STRIDE), Fh);
+                load_rec<T, MAT>(reinterpret_cast<const T*>(lQ + (lane + 1) * GF::STRIDE), Qh);
+                have_next = true;
+            }
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const long k = k0 + sb * G + i;

@@ -84,14 +84,15 @@ def test_chunk_size_invariance(chunk):
 
 @pytest.mark.parametrize("stage", [0, 2, 4])
 @pytest.mark.parametrize("chunk", [4, 8, 12])
-@pytest.mark.parametrize("dtype,kname", [(np.float64, "m32"), (np.float64, "m12"), (np.float32, "m32")])
+@pytest.mark.parametrize("dtype,kname", [(np.float64, "m32"), (np.float64, "m12"), (np.float32, "m32"),
+                                         (np.float64, "m52"), (np.float32, "m52")])
 def test_lds_staged_paths(stage, chunk, dtype, kname):
     """The coalesced global<->LDS staged path (d <= 2) against the oracle, for every sub-tile
     size, with a ragged tail (the last wavefronts fall back to direct accesses)."""
-    from pssgp.kernels import Matern12, Matern32
+    from pssgp.kernels import Matern12, Matern32, Matern52
     B = _gpu()
     ctx = B.get_context()
-    k = Matern32(1., 1.) if kname == "m32" else Matern12(1., 1.)
+    k = {"m32": Matern32(1., 1.), "m12": Matern12(1., 1.), "m52": Matern52(1., 1.)}[kname]
     n = 256 * chunk * 3 + 64 * chunk + 17
     t = make_times(n, seed=chunk)
     ssm = O.get_ssm(k.get_sde(), t, 0.1)
