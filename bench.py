@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2n", type=int, default=20, help="log2 of the steps per GPU (default 20 = config c2)")
-    ap.add_argument("--kernel", default="matern32", choices=["matern32", "matern52", "rbf6", "matern12"])
+    ap.add_argument("--kernel", default="matern32",
+                    choices=["matern32", "matern52", "rbf6", "matern12", "c5", "rbf15", "periodic10"])
+    ap.add_argument("--family", type=int, default=0, help="0 auto, 1 lane-chunk, 2 wave-cooperative kernels")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
     ap.add_argument("--stage", type=int, default=-1, help="LDS staging: -1 auto, 0 off, 2 / 4 steps per sub-tile")
@@ -56,10 +58,15 @@ def parse():
 
 
 def make_kernel(name):
-    from pssgp.kernels import Matern12, Matern32, Matern52, RBF
+    from pssgp.kernels import Matern12, Matern32, Matern52, RBF, Periodic, SquaredExponential
     return {"matern12": lambda: Matern12(1.0, 1.0), "matern32": lambda: Matern32(1.0, 1.0),
             "matern52": lambda: Matern52(1.0, 1.0),
-            "rbf6": lambda: RBF(1.0, 1.0, order=6, balancing_iter=10)}[name]()
+            "rbf6": lambda: RBF(1.0, 1.0, order=6, balancing_iter=10),
+            # BASELINE config c5: quasi-periodic (Periodic * Matern32) + Matern52, d = 11
+            "c5": lambda: Periodic(SquaredExponential(1.0, 1.0), period=1.0, order=1) * Matern32(1.0, 1.0)
+            + Matern52(1.0, 1.0),
+            "rbf15": lambda: RBF(1.0, 1.0, order=15, balancing_iter=10),
+            "periodic10": lambda: Periodic(SquaredExponential(1.0, 1.0), period=1.0, order=10)}[name]()
 
 
 def sample_prior_observations(P0, Fs, Qs, H, R, rng):
@@ -132,6 +139,7 @@ def main():
     if args.chunk:
         ctx.set_chunk(args.chunk)
     ctx.set_stage(args.stage)
+    ctx.set_family(args.family)
 
     def dev_from(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)

@@ -17,7 +17,8 @@
  *   - return value 0 = PGPS_OK, negative = error (pgps_strerror); nothing throws across the
  *     ABI; outputs are undefined after an error.
  *   - one call in flight per context; contexts are independent (one per GPU / per thread).
- *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels.
+ *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels, up to PGPS_MAX_DIM the
+ *     wave-cooperative ones (pkf, pkfs; stand-alone pks, discretise and the segment calls: d <= 6).
  *   - NaN in `ys` marks a missing observation (parallel.py:42,86-95).
  */
 #ifndef PGPS_H_
@@ -38,7 +39,8 @@ extern "C" {
 #define PGPS_E_NUMERIC (-5)         /* non-finite result (reference: TF raises on CPU, NaNs on GPU) */
 #define PGPS_E_NO_DEVICE (-6)       /* no HIP device visible */
 
-#define PGPS_MAX_DIM_LANE 6
+#define PGPS_MAX_DIM_LANE 6   /* lane-chunk kernels: one lane holds whole d x d operands */
+#define PGPS_MAX_DIM 32       /* wave-cooperative kernels: operands in LDS, 64 lanes share each operation */
 
 typedef struct pgps_ctx pgps_ctx;
 
@@ -57,6 +59,9 @@ int pgps_use_own_stream(pgps_ctx* ctx);
 int pgps_synchronize(pgps_ctx* ctx);
 /* Steps per lane of the scan kernels; 0 = automatic. */
 int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
+/* Kernel family: 0 = automatic (lane-chunk for d <= PGPS_MAX_DIM_LANE, else wave-cooperative),
+ * 1 = lane-chunk, 2 = wave-cooperative.  Tuning / test knob. */
+int pgps_set_family(pgps_ctx* ctx, int family);
 /* LDS staging of the lane-chunk kernels: -1 = automatic, 0 = off (direct global accesses),
  * 2 or 4 = steps per lane per staged sub-tile (2: fp64 only).  Tuning / A-B knob. */
 int pgps_set_stage(pgps_ctx* ctx, int steps_per_subtile);

@@ -117,6 +117,12 @@ extern "C" int pgps_debug_read_stamps(pgps_ctx* ctx, long long* out, long n_valu
     return PGPS_OK;
 }
 
+extern "C" int pgps_set_family(pgps_ctx* ctx, int family) {
+    if (!ctx || family < 0 || family > 2) return PGPS_E_INVALID;
+    ctx->family = family;
+    return PGPS_OK;
+}
+
 extern "C" int pgps_set_stage(pgps_ctx* ctx, int g) {
     if (!ctx || !(g == -1 || g == 0 || g == 2 || g == 4)) return PGPS_E_INVALID;
     ctx->stage_g = g;
@@ -270,6 +276,7 @@ extern "C" int pgps_get_chunk(pgps_ctx* ctx, long N, int* Lc, int* nb) {
 
 template <typename T>
 static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
+    if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_scan_wc<T>(ctx, a, d, mode);
     switch (d) {
         case 1: return launch_scan<T, 1>(ctx, a, mode);
         case 2: return launch_scan<T, 2>(ctx, a, mode);
@@ -290,7 +297,7 @@ template <typename T>
 static int pkf_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
                    const T* ys, T* fms, T* fPs, double* ll) {
     if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs) return PGPS_E_INVALID;
-    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs)) return PGPS_E_INVALID;
     ScanArgs<T> a{};
     a.N = N; a.seg_first = 1; a.seg_last = 1;
@@ -303,7 +310,7 @@ template <typename T>
 static int pks_dev(pgps_ctx* ctx, long N, int d, const T* Fs, const T* Qs, const T* fms, const T* fPs,
                    T* sms, T* sPs) {
     if (!ctx || N < 1 || !Fs || !Qs || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
-    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs) || !aligned16(sms) ||
         !aligned16(sPs))
         return PGPS_E_INVALID;
@@ -318,7 +325,7 @@ template <typename T>
 static int pkfs_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
                     const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {
     if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
-    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs) || !aligned16(sms) ||
         !aligned16(sPs))
         return PGPS_E_INVALID;
@@ -332,6 +339,7 @@ static int pkfs_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, cons
 template <typename T>
 static int disc_dev(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
     if (!ctx || N < 1 || !F || !Pinf || !ts || !Fs || !Qs) return PGPS_E_INVALID;
+    if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_disc_wc<T>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
     switch (d) {
         case 1: return launch_disc<T, 1>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
         case 2: return launch_disc<T, 2>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
@@ -366,7 +374,7 @@ template <typename T>
 static int pkf_host(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
                     const T* ys, T* fms, T* fPs, double* ll) {
     if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs) return PGPS_E_INVALID;
-    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)N, dd = (size_t)d * d;
     T *dP0, *dFs, *dQs, *dH, *dys, *dfms, *dfPs;
@@ -392,7 +400,7 @@ template <typename T>
 static int pks_host(pgps_ctx* ctx, long N, int d, const T* Fs, const T* Qs, const T* fms, const T* fPs, T* sms,
                     T* sPs) {
     if (!ctx || N < 1 || !Fs || !Qs || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
-    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)N, dd = (size_t)d * d;
     T *dFs, *dQs, *dfms, *dfPs, *dsms, *dsPs;
@@ -413,7 +421,7 @@ template <typename T>
 static int pkfs_host(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
                      const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {
     if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !sms || !sPs) return PGPS_E_INVALID;
-    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)N, dd = (size_t)d * d;
     T *dP0, *dFs, *dQs, *dH, *dys, *dfms, *dfPs, *dsms, *dsPs;
@@ -444,7 +452,7 @@ static int pkfs_host(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, con
 template <typename T>
 static int disc_host(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
     if (!ctx || N < 1 || !F || !Pinf || !ts || !Fs || !Qs) return PGPS_E_INVALID;
-    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)N, dd = (size_t)d * d;
     T *dF, *dP, *dts, *dFs, *dQs;
@@ -470,7 +478,7 @@ static int disc_host(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, co
     }                                                                                                                \
     extern "C" int pgps_discretise_dev_##SUF(pgps_ctx* c, long N, int d, const T* F, const T* P, const T* ts, T t0, \
                                              T* Fs, T* Qs) {                                                        \
-        if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;                                          \
+        if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;                                               \
         return disc_dev<T>(c, N, d, F, P, ts, t0, Fs, Qs);                                                          \
     }                                                                                                                \
     extern "C" int pgps_pkf_##SUF(pgps_ctx* c, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H,    \
@@ -514,7 +522,7 @@ extern "C" int pgps_seg_record_len(int d, int* rec_filter, int* rec_smoother) {
 template <typename T>
 static int seg_common(pgps_ctx* ctx, long N, int d, int rank, int nranks, ScanArgs<T>& a) {
     if (!ctx || N < 1 || rank < 0 || nranks < 1 || rank >= nranks) return PGPS_E_INVALID;
-    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     a.N = N;
     a.rank = rank;
     a.nranks = nranks;

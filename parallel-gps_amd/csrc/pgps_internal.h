@@ -20,6 +20,7 @@ struct pgps_ctx {
     hipStream_t stream = nullptr;
     int chunk = 0;                      // 0 = auto
     int stage_g = -1;                   // LDS staging: -1 = auto, 0 = off, 2 / 4 = steps per sub-tile
+    int family = 0;                     // 0 = auto (lane-chunk for d <= 6, else wave-cooperative), 1 = lane, 2 = wave
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
@@ -112,6 +113,12 @@ enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS, MODE_SEG_REDUCE, MODE_SEG_FILTER, MOD
 // defined in pgps_inst.hip, one explicit instantiation per compiled (T, D)
 template <typename T, int D>
 int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
+// wave-cooperative family (pgps_wc.hip): runtime state dimension, 1 <= d <= 32
+template <typename T>
+int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);
+template <typename T>
+int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);
+
 template <typename T, int D>
 int launch_disc(pgps_ctx* ctx, long N, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);
 

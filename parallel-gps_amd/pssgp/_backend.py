@@ -45,6 +45,7 @@ def _declare(lib):
     lib.pgps_synchronize.argtypes = [P]
     lib.pgps_set_chunk.argtypes = [P, c_int]
     lib.pgps_set_stage.argtypes = [P, c_int]
+    lib.pgps_set_family.argtypes = [P, c_int]
     lib.pgps_get_chunk.argtypes = [P, c_long, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_malloc.argtypes = [P, ctypes.c_size_t, ctypes.POINTER(P)]
     lib.pgps_free.argtypes = [P, P]
@@ -122,6 +123,10 @@ class Context:
     def set_stage(self, steps_per_subtile):
         """-1 auto, 0 direct global accesses, 2 / 4 steps per LDS-staged sub-tile."""
         check(self, self.lib.pgps_set_stage(self.handle, int(steps_per_subtile)), "pgps_set_stage")
+
+    def set_family(self, family):
+        """0 auto, 1 lane-chunk kernels (d <= 6), 2 wave-cooperative kernels (any d <= 32)."""
+        check(self, self.lib.pgps_set_family(self.handle, int(family)), "pgps_set_family")
 
     def get_chunk(self, n_steps):
         lc, nb = c_int(0), c_int(0)
