@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
     ap.add_argument("--stage", type=int, default=-1, help="LDS staging: -1 auto, 0 off, 2 / 4 steps per sub-tile")
+    ap.add_argument("--force-segments", action="store_true",
+                    help="run the multi-GPU segment protocol even at one GPU (measures its overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-every", type=int, default=8,
                     help="hipEvent-time every n-th launch of the dominant kernel inside the timed region")
@@ -169,7 +171,7 @@ def main():
     sPs = torch.empty((n_local, d, d), dtype=dtype_t, device=dev)
     ll_d = torch.zeros((2,), dtype=torch.float64, device=dev)
 
-    if world == 1:
+    if world == 1 and not args.force_segments:
         def step():
             ctx.call(f"pgps_pkfs_dev_{suf}", ctypes.c_long(n_local), ctypes.c_int(d), P(P0_d), P(Fs_d), P(Qs_d),
                      P(H_d), real(noise), P(ys_d), P(fms), P(fPs), P(sms), P(sPs), P(ll_d))

@@ -66,18 +66,17 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
             }
             hipLaunchKernelGGL((k_seg_filter_total<T, D>), dim3(1), block, 0, s, a);
         } else if (mode == MODE_SEG_FILTER) {
-            hipLaunchKernelGGL((k_seg_fold_filter<T, D>), dim3(1), dim3(kWave), 0, s, a);
+            // halo step of this segment = first step of the next rank, straight out of its record
+            if (!a.seg_last)
+                a.halo_FQ = a.gathered_f + (long)(a.rank + 1) * seg_rec_f_len(D) + Dim<D>::NFILT;
             {
                 ProfScope p(ctx, PGPS_K_FILTER_APPLY);
                 hipLaunchKernelGGL((k_filter_apply<T, D, true, G>), grid, block, 0, s, a);
             }
             hipLaunchKernelGGL((k_seg_smoother_total<T, D>), dim3(1), block, 0, s, a, pad);
         } else {
-            hipLaunchKernelGGL((k_seg_fold_smoother<T, D>), dim3(1), dim3(kWave), 0, s, a, pad);
             ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
-            ScanArgs<T> b = a;
-            b.ll = nullptr;                 // the fold kernel wrote the series' log-likelihood
-            hipLaunchKernelGGL((k_smoother_apply<T, D, G>), grid, block, 0, s, b);
+            hipLaunchKernelGGL((k_smoother_apply<T, D, G>), grid, block, 0, s, a);
         }
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;

@@ -820,12 +820,24 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
         for (int i = 0; i < D; ++i) s.m[i] = T(0);
         sym_from_full<T, D>(P0f, s.P);
     } else {
-        T Pf[MAT];
+        // a later segment of a series sharded over GPUs: the prior pushed through the totals of the
+        // ranks to the left (every lane folds the <= nranks-1 gathered records itself: no extra launch)
+        T P0f[MAT];
 #pragma unroll
-        for (int i = 0; i < D; ++i) s.m[i] = a.carry_in[i];
+        for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
 #pragma unroll
-        for (int i = 0; i < MAT; ++i) Pf[i] = a.carry_in[D + i];
-        sym_from_full<T, D>(Pf, s.P);
+        for (int i = 0; i < D; ++i) s.m[i] = T(0);
+        sym_from_full<T, D>(P0f, s.P);
+        const int REC = NF + 2 * MAT;
+        for (int r = 0; r < a.rank; ++r) {
+            FE e;
+            rec_load(a.gathered_f + (long)r * REC, e);
+            filt_apply(s, e);
+        }
+    }
+    if (!a.seg_last && blockIdx.x == 0 && threadIdx.x < 2 * MAT) {
+        // keep the next segment's first (F, Q) for the smoother launch of this pass
+        a.seg_ws[(D + MAT) + threadIdx.x] = a.halo_FQ[threadIdx.x];
     }
     // ... pushed through the workgroups to the left, then through this lane's local prefix
     if (blockIdx.x > 0) {
@@ -1083,12 +1095,18 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
 #pragma unroll
         for (int i = 0; i < SYM; ++i) s.P[i] = T(0);
     } else {
-        T Pf[MAT];
+        // smoothed state of the next segment's first step = fold of the totals of the ranks to the right
+        // (the last one has E = 0)
 #pragma unroll
-        for (int i = 0; i < D; ++i) s.m[i] = a.carry_back[i];
+        for (int i = 0; i < D; ++i) s.m[i] = T(0);
 #pragma unroll
-        for (int i = 0; i < MAT; ++i) Pf[i] = a.carry_back[D + i];
-        sym_from_full<T, D>(Pf, s.P);
+        for (int i = 0; i < SYM; ++i) s.P[i] = T(0);
+        const int REC = (NS + (NS & 1)) + 2;
+        for (int r = a.nranks - 1; r > a.rank; --r) {
+            SE e;
+            rec_load(a.gathered_s + (long)r * REC, e);
+            smth_apply(e, s);
+        }
     }
     if ((int)blockIdx.x + 1 < a.nblocks) {
         SE right;
@@ -1107,7 +1125,14 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
 
     if (blockIdx.x == 0 && a.ll != nullptr) {
         double v = 0.0;
-        for (int b = threadIdx.x; b < a.nblocks; b += kBlock) v += a.llpart[b];
+        if (a.gathered_s != nullptr) {
+            // sharded series: every rank's partial rides in its smoother record
+            const int REC = (NS + (NS & 1)) + 2;
+            for (int r = threadIdx.x; r < a.nranks; r += kBlock)
+                v += *reinterpret_cast<const double*>(a.gathered_s + (long)r * REC + (REC - 2));
+        } else {
+            for (int b = threadIdx.x; b < a.nblocks; b += kBlock) v += a.llpart[b];
+        }
         const double t = block_sum_double(v, lds_ll);
         if (threadIdx.x == 0) *a.ll = t;
     }
@@ -1141,39 +1166,6 @@ __global__ __launch_bounds__(kBlock) void k_seg_filter_total(const ScanArgs<T> a
     }
 }
 
-// carry_in = prior pushed through the totals of ranks 0..rank-1; halo = (F_0, Q_0) of rank+1
-template <typename T, int D>
-__global__ void k_seg_fold_filter(const ScanArgs<T> a) {
-    constexpr int MAT = D * D, NF = Dim<D>::NFILT;
-    const int REC = NF + 2 * MAT;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    MeanCov<T, D> s;
-    T P0f[MAT];
-#pragma unroll
-    for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
-#pragma unroll
-    for (int i = 0; i < D; ++i) s.m[i] = T(0);
-    sym_from_full<T, D>(P0f, s.P);
-    for (int r = 0; r < a.rank; ++r) {
-        FiltElem<T, D> e;
-        rec_load(a.gathered_f + (long)r * REC, e);
-        filt_apply(s, e);
-    }
-    T* carry_in = a.seg_ws;
-    T* halo = a.seg_ws + (D + MAT);
-    T Pf[MAT];
-    full_from_sym<T, D>(s.P, Pf);
-#pragma unroll
-    for (int i = 0; i < D; ++i) carry_in[i] = s.m[i];
-#pragma unroll
-    for (int i = 0; i < MAT; ++i) carry_in[D + i] = Pf[i];
-    if (a.rank + 1 < a.nranks) {
-        const T* nxt = a.gathered_f + (long)(a.rank + 1) * REC + NF;
-#pragma unroll
-        for (int i = 0; i < 2 * MAT; ++i) halo[i] = nxt[i];
-    }
-}
-
 // smoother record of this segment: [fold of the local sspine | pad | ll partial (double)]
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock) void k_seg_smoother_total(const ScanArgs<T> a, int pad_len) {
@@ -1189,37 +1181,6 @@ __global__ __launch_bounds__(kBlock) void k_seg_smoother_total(const ScanArgs<T>
     if (threadIdx.x == 0) {
         rec_store(a.rec_s, total);
         *reinterpret_cast<double*>(a.rec_s + pad_len) = t;
-    }
-}
-
-// carry_back = smoothed state of the first step of rank+1 (fold of the totals of the ranks to
-// the right; the last one has E = 0);  ll = sum of all ranks' partials
-template <typename T, int D>
-__global__ void k_seg_fold_smoother(const ScanArgs<T> a, int pad_len) {
-    constexpr int MAT = D * D;
-    const int REC = pad_len + 2;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    MeanCov<T, D> s;
-#pragma unroll
-    for (int i = 0; i < D; ++i) s.m[i] = T(0);
-#pragma unroll
-    for (int i = 0; i < Dim<D>::SYM; ++i) s.P[i] = T(0);
-    for (int r = a.nranks - 1; r > a.rank; --r) {
-        SmthElem<T, D> e;
-        rec_load(a.gathered_s + (long)r * REC, e);
-        smth_apply(e, s);
-    }
-    T* carry_back = a.seg_ws + (D + MAT) + 2 * MAT;
-    T Pf[MAT];
-    full_from_sym<T, D>(s.P, Pf);
-#pragma unroll
-    for (int i = 0; i < D; ++i) carry_back[i] = s.m[i];
-#pragma unroll
-    for (int i = 0; i < MAT; ++i) carry_back[D + i] = Pf[i];
-    if (a.ll != nullptr) {
-        double t = 0.0;
-        for (int r = 0; r < a.nranks; ++r) t += *reinterpret_cast<const double*>(a.gathered_s + (long)r * REC + pad_len);
-        *a.ll = t;
     }
 }
 

@@ -46,9 +46,14 @@ __device__ __forceinline__ T wave_sum(T x) {
 }
 
 // ---- entry-parallel helpers (all 64 lanes; operands in LDS unless noted) -----------------------
-#define WC_FOR_ENTRIES(d)                                             \
+// (i, j) walks this lane's entries e = lane, lane + 64, ... of a d x d matrix without dividing per entry
+__device__ __forceinline__ void wc_advance(int d, int& i, int& j) {
+    j += 64;
+    while (j >= d) { j -= d; ++i; }
+}
+#define WC_FOR_ENTRIES(d)                                                     \
     for (int e_ = lane_id(), i = e_ / (d), j = e_ - i * (d); e_ < (d) * (d); \
-         e_ += 64, j += 64, i += j / (d), j %= (d))
+         e_ += 64, wc_advance((d), i, j))
 
 template <typename T>
 __device__ __forceinline__ void mat_copy(int d, const T* A, T* C) {
@@ -73,15 +78,25 @@ __device__ __forceinline__ void vec_zero(int d, T* c) {
 
 // C = op(A) op(B) (+ Add).  MODE 0: A B, 1: A B^T, 2: A^T B.  C must not alias A or B.
 template <typename T, int MODE>
-__device__ __forceinline__ void mm(int d, const T* A, const T* B, T* C, const T* Add = nullptr) {
+__device__ __forceinline__ void mm(int d, const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
+                                   const T* __restrict__ Add = nullptr) {
     WC_FOR_ENTRIES(d) {
-        T acc = Add ? Add[i * d + j] : T(0);
-        for (int k = 0; k < d; ++k) {
-            const T a = (MODE == 2) ? A[k * d + i] : A[i * d + k];
-            const T b = (MODE == 1) ? B[j * d + k] : B[k * d + j];
-            acc += a * b;
+        T acc0 = Add ? Add[i * d + j] : T(0), acc1 = T(0);
+        const T* pa = (MODE == 2) ? A + i : A + i * d;
+        const T* pb = (MODE == 1) ? B + j * d : B + j;
+        const int sa = (MODE == 2) ? d : 1, sb = (MODE == 1) ? 1 : d;
+        int k = 0;
+#pragma unroll 2
+        for (; k + 4 <= d; k += 4) {        // four independent LDS reads per operand in flight
+            const T a0 = pa[(k + 0) * sa], a1 = pa[(k + 1) * sa], a2 = pa[(k + 2) * sa], a3 = pa[(k + 3) * sa];
+            const T b0 = pb[(k + 0) * sb], b1 = pb[(k + 1) * sb], b2 = pb[(k + 2) * sb], b3 = pb[(k + 3) * sb];
+            acc0 += a0 * b0;
+            acc1 += a1 * b1;
+            acc0 += a2 * b2;
+            acc1 += a3 * b3;
         }
-        C[i * d + j] = acc;
+        for (; k < d; ++k) acc0 += pa[k * sa] * pb[k * sb];
+        C[i * d + j] = acc0 + acc1;
     }
 }
 
@@ -99,12 +114,25 @@ __device__ __forceinline__ void symmetrise(int d, T* C) {
 
 // y = A x (TRANS = false) or A^T x; optional add; y must not alias x
 template <typename T, bool TRANS>
-__device__ __forceinline__ void mv(int d, const T* A, const T* x, T* y, const T* add = nullptr) {
+__device__ __forceinline__ void mv(int d, const T* __restrict__ A, const T* __restrict__ x, T* __restrict__ y,
+                                   const T* __restrict__ add = nullptr) {
     const int i = lane_id();
     if (i < d) {
-        T acc = add ? add[i] : T(0);
-        for (int k = 0; k < d; ++k) acc += (TRANS ? A[k * d + i] : A[i * d + k]) * x[k];
-        y[i] = acc;
+        T acc0 = add ? add[i] : T(0), acc1 = T(0);
+        const T* pa = TRANS ? A + i : A + i * d;
+        const int sa = TRANS ? d : 1;
+        int k = 0;
+#pragma unroll 2
+        for (; k + 4 <= d; k += 4) {
+            const T a0 = pa[(k + 0) * sa], a1 = pa[(k + 1) * sa], a2 = pa[(k + 2) * sa], a3 = pa[(k + 3) * sa];
+            const T x0 = x[k], x1 = x[k + 1], x2 = x[k + 2], x3 = x[k + 3];
+            acc0 += a0 * x0;
+            acc1 += a1 * x1;
+            acc0 += a2 * x2;
+            acc1 += a3 * x3;
+        }
+        for (; k < d; ++k) acc0 += pa[k * sa] * x[k];
+        y[i] = acc0 + acc1;
     }
 }
 
