@@ -42,11 +42,12 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     return PGPS_OK;
 }
 
-template <typename T, int D, int G>
+template <typename T, int D, int G, bool NT>
 static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     geometry(ctx, a.N, &a.Lc, &a.nblocks);
     a.nlanes = (long)a.nblocks * kBlock;
+    a.nt = NT ? 1 : 0;
     int rc = carve_workspace<T, D>(ctx, a);
     if (rc) return rc;
     const dim3 grid(a.nblocks), block(kBlock);
@@ -71,12 +72,12 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
                 a.halo_FQ = a.gathered_f + (long)(a.rank + 1) * seg_rec_f_len(D) + Dim<D>::NFILT;
             {
                 ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-                hipLaunchKernelGGL((k_filter_apply<T, D, true, G>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((k_filter_apply<T, D, true, G, NT>), grid, block, 0, s, a);
             }
             hipLaunchKernelGGL((k_seg_smoother_total<T, D>), dim3(1), block, 0, s, a, pad);
         } else {
             ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
-            hipLaunchKernelGGL((k_smoother_apply<T, D, G>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((k_smoother_apply<T, D, G, NT>), grid, block, 0, s, a);
         }
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
@@ -88,11 +89,11 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         }
         if (mode == MODE_PKFS) {
             ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-            hipLaunchKernelGGL((k_filter_apply<T, D, true, G>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((k_filter_apply<T, D, true, G, NT>), grid, block, 0, s, a);
         } else {
             {
                 ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-                hipLaunchKernelGGL((k_filter_apply<T, D, false, G>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((k_filter_apply<T, D, false, G, NT>), grid, block, 0, s, a);
             }
             if (a.ll) {
                 ProfScope p(ctx, PGPS_K_LL_FINALIZE);
@@ -110,7 +111,7 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
         ScanArgs<T> b = a;
         if (mode == MODE_PKS) b.ll = nullptr;
-        hipLaunchKernelGGL((k_smoother_apply<T, D, G>), grid, block, 0, s, b);
+        hipLaunchKernelGGL((k_smoother_apply<T, D, G, NT>), grid, block, 0, s, b);
     }
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
@@ -118,20 +119,31 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
 
 // G = steps per lane per LDS-staged sub-tile (0 = direct global accesses); staging exists for
 // d <= 3 only (StageCfg), G = 2 only in fp64 (a lane segment must be >= 16 bytes).
+template <typename T, int D, int G>
+static int launch_scan_nt(pgps_ctx* ctx, const ScanArgs<T>& a, Mode mode) {
+    // streaming (non-temporal) output stores once one pass -- (7d^2+3d+1) scalars per step -- is well
+    // beyond the 256 MiB Infinity Cache: -12 % on the smoother pass at N = 2^24, +5 % at 2^20
+    const bool nt = (double)a.N * (7 * D * D + 3 * D + 1) * sizeof(T) > 512.0 * 1024 * 1024;
+    if constexpr (G > 0) {
+        if (nt) return launch_scan_g<T, D, G, true>(ctx, a, mode);
+    }
+    return launch_scan_g<T, D, G, false>(ctx, a, mode);
+}
+
 template <typename T, int D>
 int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     if constexpr (D <= 2) {
         int g = ctx->stage_g < 0 ? 4 : ctx->stage_g;
-        if (g == 4) return launch_scan_g<T, D, 4>(ctx, a, mode);
+        if (g == 4) return launch_scan_nt<T, D, 4>(ctx, a, mode);
         if constexpr (sizeof(T) == 8) {
-            if (g == 2) return launch_scan_g<T, D, 2>(ctx, a, mode);
+            if (g == 2) return launch_scan_nt<T, D, 2>(ctx, a, mode);
         }
     } else if constexpr (D == 3) {
         // 144-byte lane segments: 2 steps of 72-byte fp64 records or 4 steps of 36-byte fp32 ones
         constexpr int g3 = (sizeof(T) == 8) ? 2 : 4;
-        if (ctx->stage_g != 0) return launch_scan_g<T, D, g3>(ctx, a, mode);
+        if (ctx->stage_g != 0) return launch_scan_nt<T, D, g3>(ctx, a, mode);
     }
-    return launch_scan_g<T, D, 0>(ctx, a, mode);
+    return launch_scan_nt<T, D, 0>(ctx, a, mode);
 }
 
 template <typename T, int D>

@@ -100,6 +100,7 @@ struct ScanArgs {
     T* rec_s;               // out: this segment's smoother record [NSMTH total | pad | ll partial (double)]
     const T* gathered_s;    // in : (nranks, REC_S)
     T* seg_ws;              // scratch: carry_in (d+d*d) | halo_FQ (2 d*d) | carry_back (d+d*d)
+    int nt;                 // streaming stores for the outputs (pass larger than the Infinity Cache)
     long long* stamps;      // diagnostic build only (-DPGPS_STAMPS): (3 kernels, nblocks, 8) s_memtime stamps
 };
 
