@@ -197,6 +197,7 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     dominant = "k_smoother_apply"
+    empty_pair_ms = ctx.profile_calibrate()
     ctx.profile_read(reset=True)
     ctx.profile_sample(args.event_every)
     ctx.profile_enable((1 << 3) if args.event_every > 0 else 0)   # hipEvents around the dominant kernel (slot 3)
@@ -235,10 +236,24 @@ def main():
 
     # ---- roofline of the dominant kernel -----------------------------------------------------
     dom_ms, dom_n = prof[dominant]
-    dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
+    # the events are stamped by hipExtLaunchKernelGGL with the dispatch's own start / end timestamps
+    # (the clock rocprofv3's kernel trace reads), so no event-packet overhead is included
+    dom_raw_ms = dom_ms / max(dom_n, 1)
+    dom_avg_s = max(dom_raw_ms, 1e-9) * 1e-3
     dom_bytes = (4 * d * d + 2 * d) * w * n_local          # smoother: reads Fs,Qs,fms,fPs; writes sms,sPs
     achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     alg_bytes_step = (7 * d * d + 3 * d + 1) * w
+    # HBM-side bytes per launch of the dominant kernel from the committed PMC profile of this workload
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            tj = json.load(fh)
+        key = f"{args.kernel}_{suf}_log2n{args.log2n}"
+        if world == 1 and key in tj and not args.chunk and args.stage < 0 and args.family == 0:
+            traffic = tj[key][dominant]["traffic_bytes"]
+            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE)"
+    except Exception:
+        pass
 
     out = {
         "metric": "timesteps/sec (filter+smooth+log-lik)",
@@ -258,8 +273,10 @@ def main():
                    "steps_per_gpu": n_local, "state_dim": d,
                    "parallelism": "1 GPU" if world == 1 else f"{world} contiguous time segments, 2 RCCL all-gathers"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_avg_s * 1e3},
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_avg_s * 1e3,
+                     "launches_timed": dom_n, "empty_event_pair_ms": empty_pair_ms},
         "whole_path_effective_GBps": alg_bytes_step * n_total * args.steps / elapsed / 1e9,
         "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in breakdown.items() if v[1]},
         "host_enqueue_ms_per_step": (t_enq - t0) / args.steps * 1e3,

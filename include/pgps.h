@@ -87,6 +87,8 @@ int pgps_profile_enable(pgps_ctx* ctx, int mask);
 /* Time only every n-th launch of an enabled slot (default 1): keeps the events' own cost
  * (a few microseconds per pair) out of a throughput measurement. */
 int pgps_profile_sample(pgps_ctx* ctx, int every_n);
+/* Mean elapsed milliseconds of an empty hipEvent pair on the context's stream. */
+int pgps_profile_calibrate(pgps_ctx* ctx, double* empty_pair_ms);
 /* Synchronises, then returns accumulated milliseconds and launch counts per PGPS_K_* slot
  * since the last reset (arrays of PGPS_K_COUNT). */
 int pgps_profile_read(pgps_ctx* ctx, double* total_ms, long* launches, int reset);

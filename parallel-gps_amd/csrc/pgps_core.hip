@@ -179,24 +179,21 @@ int prof_flush(pgps_ctx* ctx) {
     return PGPS_OK;
 }
 
-ProfScope::ProfScope(pgps_ctx* c, int slot) : ctx(c) {
-    if (!((c->profiling >> slot) & 1u)) return;
-    if ((c->prof_seen[slot]++ % c->prof_every) != 0) return;
+pgps_ctx::EvPair* prof_acquire(pgps_ctx* c, int slot) {
+    if (!((c->profiling >> slot) & 1u)) return nullptr;
+    if ((c->prof_seen[slot]++ % c->prof_every) != 0) return nullptr;
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 1024) {
-            if (prof_flush(c) != PGPS_OK) return;
+            if (prof_flush(c) != PGPS_OK) return nullptr;
         } else {
             pgps_ctx::EvPair p;
-            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
             c->ev_pool.push_back(p);
         }
     }
-    ev = &c->ev_pool[c->ev_used++];
+    pgps_ctx::EvPair* ev = &c->ev_pool[c->ev_used++];
     ev->slot = slot;
-    (void)hipEventRecord(ev->a, c->stream);
-}
-ProfScope::~ProfScope() {
-    if (ev) (void)hipEventRecord(ev->b, ctx->stream);
+    return ev;
 }
 }  // namespace pgps
 
@@ -220,6 +217,30 @@ extern "C" int pgps_profile_enable(pgps_ctx* ctx, int on) {
     }
     ctx->profiling = (unsigned)on;
     for (int i = 0; i < PGPS_K_COUNT; ++i) ctx->prof_seen[i] = 0;
+    return PGPS_OK;
+}
+
+// mean elapsed time of an EMPTY hipEvent pair on the context's stream: what a pair adds to the
+// duration it brackets (subtract it to compare with a profiler's pure kernel time)
+extern "C" int pgps_profile_calibrate(pgps_ctx* ctx, double* empty_pair_ms) {
+    if (!ctx || !empty_pair_ms) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipEvent_t a, b;
+    HIPCHK(ctx, hipEventCreate(&a));
+    HIPCHK(ctx, hipEventCreate(&b));
+    double acc = 0.0;
+    const int reps = 64;
+    for (int i = 0; i < reps + 8; ++i) {
+        HIPCHK(ctx, hipEventRecord(a, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(b, ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(b));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, a, b));
+        if (i >= 8) acc += ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *empty_pair_ms = acc / reps;
     return PGPS_OK;
 }
 

@@ -61,57 +61,37 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         a.carry_back = a.seg_ws + (D + D * D) + 2 * D * D;
         const int pad = seg_rec_s_pad(D);
         if (mode == MODE_SEG_REDUCE) {
-            {
-                ProfScope p(ctx, PGPS_K_FILTER_REDUCE);
-                hipLaunchKernelGGL((k_filter_reduce<T, D, G>), grid, block, 0, s, a);
-            }
+            timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_filter_reduce<T, D, G>, grid, block, 0, a);
             hipLaunchKernelGGL((k_seg_filter_total<T, D>), dim3(1), block, 0, s, a);
         } else if (mode == MODE_SEG_FILTER) {
             // halo step of this segment = first step of the next rank, straight out of its record
             if (!a.seg_last)
                 a.halo_FQ = a.gathered_f + (long)(a.rank + 1) * seg_rec_f_len(D) + Dim<D>::NFILT;
-            {
-                ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-                hipLaunchKernelGGL((k_filter_apply<T, D, true, G, NT>), grid, block, 0, s, a);
-            }
+            timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, true, G, NT>, grid, block, 0, a);
             hipLaunchKernelGGL((k_seg_smoother_total<T, D>), dim3(1), block, 0, s, a, pad);
-        } else {
-            ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
-            hipLaunchKernelGGL((k_smoother_apply<T, D, G, NT>), grid, block, 0, s, a);
-        }
+        } else timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_smoother_apply<T, D, G, NT>, grid, block, 0, a);
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
     }
     if (mode == MODE_PKF || mode == MODE_PKFS) {
-        {
-            ProfScope p(ctx, PGPS_K_FILTER_REDUCE);
-            hipLaunchKernelGGL((k_filter_reduce<T, D, G>), grid, block, 0, s, a);
-        }
-        if (mode == MODE_PKFS) {
-            ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-            hipLaunchKernelGGL((k_filter_apply<T, D, true, G, NT>), grid, block, 0, s, a);
-        } else {
-            {
-                ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-                hipLaunchKernelGGL((k_filter_apply<T, D, false, G, NT>), grid, block, 0, s, a);
-            }
+        timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_filter_reduce<T, D, G>, grid, block, 0, a);
+        if (mode == MODE_PKFS) timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, true, G, NT>, grid, block, 0, a); else {
+            timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, false, G, NT>, grid, block, 0, a);
             if (a.ll) {
-                ProfScope p(ctx, PGPS_K_LL_FINALIZE);
-                hipLaunchKernelGGL(k_ll_finalize, dim3(1), block, 0, s, a.llpart, a.nblocks, a.ll);
+                timed_launch(ctx, PGPS_K_LL_FINALIZE, k_ll_finalize, dim3(1), block, 0, (const double*)a.llpart, a.nblocks,
+                             a.ll);
             }
         }
     }
     if (mode == MODE_PKS) {
-        ProfScope p(ctx, PGPS_K_SMOOTHER_REDUCE);
         ScanArgs<T> b = a;
         b.ll = nullptr;
-        hipLaunchKernelGGL((k_smoother_reduce<T, D>), grid, block, 0, s, b);
+        timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, k_smoother_reduce<T, D>, grid, block, 0, b);
     }
     if (mode == MODE_PKS || mode == MODE_PKFS) {
-        ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
         ScanArgs<T> b = a;
         if (mode == MODE_PKS) b.ll = nullptr;
-        hipLaunchKernelGGL((k_smoother_apply<T, D, G, NT>), grid, block, 0, s, b);
+        timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_smoother_apply<T, D, G, NT>, grid, block, 0, b);
     }
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
@@ -151,11 +131,8 @@ int launch_disc(pgps_ctx* ctx, long N, const T* F, const T* Pinf, const T* ts, T
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int block = 256;
     const long grid = (N + block - 1) / block;
-    {
-        ProfScope p(ctx, PGPS_K_DISCRETISE);
-        hipLaunchKernelGGL((k_discretise<T, D>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, N, F, Pinf, ts,
-                           t0, Fs, Qs);
-    }
+    timed_launch(ctx, PGPS_K_DISCRETISE, k_discretise<T, D>, dim3((unsigned)grid), dim3(block), 0, N, F, Pinf, ts, t0, Fs,
+                 Qs);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <string>
 #include <vector>
@@ -54,13 +55,10 @@ int ensure(pgps_ctx* ctx, DevBuf& b, size_t bytes);
 int prof_flush(pgps_ctx* ctx);
 void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks);
 
-// hipEvent pair around one launch when profiling is on
-struct ProfScope {
-    pgps_ctx* ctx;
-    pgps_ctx::EvPair* ev = nullptr;
-    ProfScope(pgps_ctx* c, int slot);
-    ~ProfScope();
-};
+// Per-kernel timing: when the launch is sampled (pgps_profile_enable / _sample) the kernel goes out
+// through hipExtLaunchKernelGGL, which stamps the two events with the dispatch's own start / end
+// timestamps (the same clock rocprofv3's kernel trace reads), not with separate event packets.
+pgps_ctx::EvPair* prof_acquire(pgps_ctx* ctx, int slot);
 
 template <typename T>
 struct ScanArgs {
@@ -108,6 +106,14 @@ struct ScanArgs {
 inline int seg_rec_f_len(int d) { return d * d + d + d * (d + 1) + d + 2 * d * d; }
 inline int seg_rec_s_pad(int d) { int n = d * d + d + d * (d + 1) / 2; return n + (n & 1); }
 inline int seg_rec_s_len(int d) { return seg_rec_s_pad(d) + 2; }
+
+template <typename... KArgs, typename... Args>
+inline void timed_launch(pgps_ctx* ctx, int slot, void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned shmem,
+                         Args... args) {
+    pgps_ctx::EvPair* ev = prof_acquire(ctx, slot);
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, ev->a, ev->b, 0, KArgs(args)...);
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, KArgs(args)...);
+}
 
 enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS, MODE_SEG_REDUCE, MODE_SEG_FILTER, MODE_SEG_SMOOTHER };
 

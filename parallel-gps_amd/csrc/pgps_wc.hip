@@ -921,32 +921,20 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     WC_ATTR((wc_scarry3<T>), l_scarry3);
     WC_ATTR((wc_smooth1<T>), l_smooth1);
 #undef WC_ATTR
-    hipStream_t s = ctx->stream;
     const dim3 blk(64), g1((unsigned)a.nchunk), g2((unsigned)a.ngroup);
-    {
-        ProfScope p(ctx, PGPS_K_FILTER_REDUCE);
-        hipLaunchKernelGGL((wc_reduce1<T>), g1, blk, bytes(l_reduce1), s, a);
-        hipLaunchKernelGGL((wc_reduce2<T>), g2, blk, bytes(l_reduce2), s, a);
-        hipLaunchKernelGGL((wc_carry3<T>), dim3(1), blk, bytes(l_carry3), s, a);
-    }
+    timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T>, g1, blk, (unsigned)bytes(l_reduce1), a);
+    timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce2<T>, g2, blk, (unsigned)bytes(l_reduce2), a);
+    timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_carry3<T>, dim3(1), blk, (unsigned)bytes(l_carry3), a);
     if (mode == MODE_PKFS) {
-        {
-            ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-            hipLaunchKernelGGL((wc_apply1<T, true>), g1, blk, bytes(l_apply1), s, a);
-        }
-        ProfScope p(ctx, PGPS_K_SMOOTHER_APPLY);
-        hipLaunchKernelGGL((wc_sreduce2<T>), g2, blk, bytes(l_sred2), s, a);
-        hipLaunchKernelGGL((wc_scarry3<T>), dim3(1), blk, bytes(l_scarry3), s, a);
-        hipLaunchKernelGGL((wc_smooth1<T>), g1, blk, bytes(l_smooth1), s, a);
+        timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, true>, g1, blk, (unsigned)bytes(l_apply1), a);
+        timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_sreduce2<T>, g2, blk, (unsigned)bytes(l_sred2), a);
+        timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_scarry3<T>, dim3(1), blk, (unsigned)bytes(l_scarry3), a);
+        timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_smooth1<T>, g1, blk, (unsigned)bytes(l_smooth1), a);
     } else {
-        {
-            ProfScope p(ctx, PGPS_K_FILTER_APPLY);
-            hipLaunchKernelGGL((wc_apply1<T, false>), g1, blk, bytes(l_apply1), s, a);
-        }
-        if (a.ll) {
-            ProfScope p(ctx, PGPS_K_LL_FINALIZE);
-            hipLaunchKernelGGL(wc::wc_ll_finalize, dim3(1), blk, 0, s, a.llpart, a.nchunk, a.ll);
-        }
+        timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, false>, g1, blk, (unsigned)bytes(l_apply1), a);
+        if (a.ll)
+            timed_launch(ctx, PGPS_K_LL_FINALIZE, wc::wc_ll_finalize, dim3(1), blk, 0u, (const double*)a.llpart,
+                         (long)a.nchunk, a.ll);
     }
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
@@ -961,11 +949,8 @@ int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, cons
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(wc::wc_discretise<T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long grid = (N + spw - 1) / spw;
-    {
-        ProfScope p(ctx, PGPS_K_DISCRETISE);
-        hipLaunchKernelGGL((wc::wc_discretise<T>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, N, d, spw, F, Pinf,
-                           ts, t0, Fs, Qs);
-    }
+    timed_launch(ctx, PGPS_K_DISCRETISE, wc::wc_discretise<T>, dim3((unsigned)grid), dim3(64), (unsigned)lds, N, d, spw,
+                 F, Pinf, ts, t0, Fs, Qs);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

@@ -53,6 +53,7 @@ def _declare(lib):
     lib.pgps_memcpy_d2h.argtypes = [P, P, P, ctypes.c_size_t]
     lib.pgps_profile_enable.argtypes = [P, c_int]
     lib.pgps_profile_sample.argtypes = [P, c_int]
+    lib.pgps_profile_calibrate.argtypes = [P, ctypes.POINTER(c_double)]
     lib.pgps_profile_read.argtypes = [P, ctypes.POINTER(c_double), ctypes.POINTER(c_long), c_int]
     lib.pgps_seg_record_len.argtypes = [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     for suf, real in (("f64", c_double), ("f32", c_float)):
@@ -150,6 +151,12 @@ class Context:
 
     def profile_sample(self, every_n):
         check(self, self.lib.pgps_profile_sample(self.handle, int(every_n)), "pgps_profile_sample")
+
+    def profile_calibrate(self):
+        """Mean elapsed ms of an empty hipEvent pair (the pair's own contribution to a timing)."""
+        v = c_double(0.0)
+        check(self, self.lib.pgps_profile_calibrate(self.handle, ctypes.byref(v)), "pgps_profile_calibrate")
+        return v.value
 
     def profile_read(self, reset=True):
         k = 6
