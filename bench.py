@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
     ap.add_argument("--stage", type=int, default=-1, help="LDS staging: -1 auto, 0 off, 2 / 4 steps per sub-tile")
+    ap.add_argument("--single-pass", type=int, default=-1,
+                    help="single-pass (look-back) filter kernel: -1 auto, 0 off (three launches), 1 on")
     ap.add_argument("--force-segments", action="store_true",
                     help="run the multi-GPU segment protocol even at one GPU (measures its overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,6 +144,7 @@ def main():
         ctx.set_chunk(args.chunk)
     ctx.set_stage(args.stage)
     ctx.set_family(args.family)
+    ctx.set_single_pass(args.single_pass, 0)
 
     def dev_from(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)

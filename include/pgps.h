@@ -59,6 +59,9 @@ int pgps_use_own_stream(pgps_ctx* ctx);
 int pgps_synchronize(pgps_ctx* ctx);
 /* Steps per lane of the scan kernels; 0 = automatic. */
 int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
+/* Single-pass filter kernel (d <= 2, 16 steps per lane, whole series on one GPU): mode -1 = automatic,
+ * 0 = off (three-launch reduce-then-scan), 1 = on; window = tiles per look-back window (1..256, 0 = keep). */
+int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
 /* Kernel family: 0 = automatic (lane-chunk for d <= PGPS_MAX_DIM_LANE, else wave-cooperative),
  * 1 = lane-chunk, 2 = wave-cooperative.  Tuning / test knob. */
 int pgps_set_family(pgps_ctx* ctx, int family);

@@ -117,6 +117,13 @@ extern "C" int pgps_debug_read_stamps(pgps_ctx* ctx, long long* out, long n_valu
     return PGPS_OK;
 }
 
+extern "C" int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window) {
+    if (!ctx || mode < -1 || mode > 1 || window < 0 || window > 256) return PGPS_E_INVALID;
+    ctx->single_pass = mode;
+    if (window > 0) ctx->lookback_window = window;
+    return PGPS_OK;
+}
+
 extern "C" int pgps_set_family(pgps_ctx* ctx, int family) {
     if (!ctx || family < 0 || family > 2) return PGPS_E_INVALID;
     ctx->family = family;

@@ -24,6 +24,8 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     const size_t o_ll = off;     off = align_up(off + nb * sizeof(double), 256);
     const size_t o_status = off; off = align_up(off + 16, 256);
     const size_t o_seg = off;    off = align_up(off + (2 * (size_t)(D + D * D) + 2 * D * D) * sizeof(T), 256);
+    const size_t o_flags = off;  off = align_up(off + (nb + 4) * sizeof(int), 256);       // ticket + flags
+    const size_t o_incl = off;   off = align_up(off + nb * Dim<D>::NMP * sizeof(T), 256);
     int rc = ensure(ctx, ctx->ws, off);
     if (rc) return rc;
     char* base = (char*)ctx->ws.p;
@@ -34,6 +36,9 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     a.llpart = (double*)(base + o_ll);
     a.status = (int*)(base + o_status);
     a.seg_ws = (T*)(base + o_seg);
+    a.ticket = (int*)(base + o_flags);
+    a.flags = a.ticket + 4;
+    a.incl = (T*)(base + o_incl);
 #ifdef PGPS_STAMPS
     rc = ensure(ctx, ctx->stamps, (size_t)3 * nb * 8 * sizeof(long long));
     if (rc) return rc;
@@ -72,6 +77,31 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         } else timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_smoother_apply<T, D, G, NT>, grid, block, 0, a);
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
+    }
+    if constexpr (G == 4 && D <= 2) {
+        // single-pass filter: whole series on this GPU, 16 steps per lane (they live in registers).
+        // Off by default: measured 55 us against 52 us for reduce + apply at N = 2^20 (with one wave per
+        // SIMD the memory-bound phase A and the compute-bound phase B of a workgroup do not overlap,
+        // and 128 fp64 of chunk data spill to AGPRs); it is kept as a tested option.
+        const bool want = ctx->single_pass < 0 ? false : ctx->single_pass != 0;
+        if (want && (mode == MODE_PKF || mode == MODE_PKFS) && a.Lc == 16) {
+            a.win = ctx->lookback_window < 1 ? 1 : (ctx->lookback_window > kBlock ? kBlock : ctx->lookback_window);
+            HIPCHK(ctx, hipMemsetAsync(a.ticket, 0, ((size_t)a.nblocks + 4) * sizeof(int), s));
+            if (mode == MODE_PKFS) {
+                timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_single<T, D, true, 16, NT>, grid, block, 0, a);
+            } else {
+                timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_single<T, D, false, 16, NT>, grid, block, 0, a);
+                if (a.ll)
+                    timed_launch(ctx, PGPS_K_LL_FINALIZE, k_ll_finalize, dim3(1), block, 0, (const double*)a.llpart,
+                                 a.nblocks, a.ll);
+            }
+            if (mode == MODE_PKFS) {
+                ScanArgs<T> b = a;
+                timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_smoother_apply<T, D, G, NT>, grid, block, 0, b);
+            }
+            HIPCHK(ctx, hipGetLastError());
+            return PGPS_OK;
+        }
     }
     if (mode == MODE_PKF || mode == MODE_PKFS) {
         timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_filter_reduce<T, D, G>, grid, block, 0, a);

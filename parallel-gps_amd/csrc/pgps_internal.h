@@ -21,6 +21,8 @@ struct pgps_ctx {
     hipStream_t stream = nullptr;
     int chunk = 0;                      // 0 = auto
     int stage_g = -1;                   // LDS staging: -1 = auto, 0 = off, 2 / 4 = steps per sub-tile
+    int single_pass = -1;               // single-pass filter kernel: -1 = auto, 0 = off, 1 = on
+    int lookback_window = 256;          // tiles per look-back window (<= 256; small values are for tests)
     int family = 0;                     // 0 = auto (lane-chunk for d <= 6, else wave-cooperative), 1 = lane, 2 = wave
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
@@ -99,6 +101,11 @@ struct ScanArgs {
     const T* gathered_s;    // in : (nranks, REC_S)
     T* seg_ws;              // scratch: carry_in (d+d*d) | halo_FQ (2 d*d) | carry_back (d+d*d)
     int nt;                 // streaming stores for the outputs (pass larger than the Infinity Cache)
+    // single-pass filter (k_filter_single): inter-workgroup look-back state, zeroed before every launch
+    int* ticket;            // dynamic tile counter
+    int* flags;             // (nblocks,) 0 = nothing, 1 = aggregate published, 2 = inclusive prefix published
+    T* incl;                // (nblocks, d + d(d+1)/2) inclusive (m, P) of the window-closing tiles
+    int win;                // look-back window (tiles); <= kBlock
     long long* stamps;      // diagnostic build only (-DPGPS_STAMPS): (3 kernels, nblocks, 8) s_memtime stamps
 };
 

@@ -880,6 +880,243 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// K-FS: single-pass filter.  k_filter_reduce and k_filter_apply in ONE launch for d <= 2:
+//   phase A  the lane streams its LC steps through LDS into REGISTERS and reduces them (filt_extend);
+//            workgroup scan -> per-lane exclusive prefix (stays in registers) + workgroup total
+//   hand-off the total is published (agent-scope atomic stores, drained, then a flag); the workgroup
+//            waits for the totals of the tiles to its left inside its look-back window and for the
+//            inclusive prefix that closes the previous window, folds them (same tree as fold_spine)
+//   phase B  lane-serial Kalman pass over the SAME registers -> fms, fPs, ll, smoothing aggregates
+// so Fs, Qs, ys are read once (k_filter_reduce's 72 B/step pass, the lpre round trip and a kernel
+// boundary disappear).  Tiles are handed out by an atomic ticket, so a tile only ever waits for
+// tiles that are already running: no assumption about dispatch order or residency.  The window
+// scheme is fixed (tile t folds tiles [W*floor(t/W), t) onto the inclusive prefix of tile
+// W*floor(t/W)-1), so the combine order -- and the result, bit for bit -- does not depend on timing.
+// Inter-workgroup visibility follows the CDNA4 hand-off rules (cdna_hip_programming.md G16): every
+// handed-off byte is written by ONE lane with agent-scope atomic (sc1, write-through) stores, that
+// lane drains its stores (s_waitcnt vmcnt(0)) before the agent-scope flag store; consumers poll the
+// flag relaxed at agent scope, take ONE agent acquire, and read the payload with agent-scope atomic
+// loads only.  Every spin is bounded (status word) so a protocol error cannot hang the GPU.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void pub_store(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T pub_load(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool wait_flag(const int* f, int want, int* status) {
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 22)) {          // ~ a second: give up loudly instead of hanging the GPU
+            atomicOr(status, 2);
+            return false;
+        }
+    }
+    return true;
+}
+
+template <typename T, int D, bool SMOOTH, int LC, bool NT>
+__global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT, NMP = Dim<D>::NMP, G = 4, S = LC / G;
+    using FE = FiltElem<T, D>;
+    using SE = SmthElem<T, D>;
+    using MC = MeanCov<T, D>;
+    using CFG = StageCfg<T, D, G>;
+    using GF = typename CFG::GF;
+    using GM = typename CFG::GM;
+    using GY = typename CFG::GY;
+    static_assert(CFG::on && LC % G == 0, "single-pass filter: staged dims only, whole sub-tiles");
+    __shared__ T lds[kWaves * NF];
+    __shared__ double lds_ll[kWaves];
+    __shared__ int s_tile;
+    __shared__ T s_base[NMP];
+    __shared__ __attribute__((aligned(16))) char stage[kWaves][CFG::F3_BYTES];
+
+    if (threadIdx.x == 0) s_tile = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    const int tile = s_tile;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+
+    T h[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) h[i] = a.H[i];
+
+    const long gt = (long)tile * kBlock + threadIdx.x;
+    const long k0 = gt * LC;
+    const long k1 = min(a.N, k0 + LC);
+    const long wbase = ((long)tile * kBlock + wave * kWave) * LC;
+    const bool staged = (wbase + (long)kWave * LC <= a.N);
+    char* lF = stage[wave];
+    char* lQ = lF + GF::BYTES;
+    char* lY = lQ + GF::BYTES;
+    char* lM = lY + GY::BYTES;
+    const long pitchF = (long)LC * MAT * sizeof(T), pitchY = (long)LC * sizeof(T), pitchM = (long)LC * D * sizeof(T);
+
+    // ---- phase A: stream the chunk into registers and reduce it --------------------------------
+    T Freg[LC][MAT], Qreg[LC][SYM];       // Q kept as its symmetric part: 3 instead of 4 values at d = 2
+    T yreg[LC];
+    T Fh[MAT], Qh[MAT];
+    bool have_next = false;
+    FE agg;
+    filt_identity(agg);
+    if (staged) {
+        const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
+        const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
+        const char* gY = reinterpret_cast<const char*>(a.ys + wbase);
+        V4 rF[GF::NV], rQ[GF::NV], rY[GY::NV];
+        stage_issue<GF>(gF, pitchF, rF);
+        stage_issue<GF>(gQ, pitchF, rQ);
+        stage_issue<GY>(gY, pitchY, rY);
+        if (SMOOTH && lane == kWave - 1) have_next = filter_tail_load<T, D>(a, wbase + (long)kWave * LC, Fh, Qh);
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) {
+            wave_lds_sync();
+            stage_commit<GF>(lF, rF);
+            stage_commit<GF>(lQ, rQ);
+            stage_commit<GY>(lY, rY);
+            if (sb + 1 < S) {
+                stage_issue<GF>(gF + (long)(sb + 1) * GF::SEG, pitchF, rF);
+                stage_issue<GF>(gQ + (long)(sb + 1) * GF::SEG, pitchF, rQ);
+                stage_issue<GY>(gY + (long)(sb + 1) * GY::SEG, pitchY, rY);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                T yv[1], Qf[MAT];
+                stage_get<GF, T, MAT>(lF, i, Freg[sb * G + i]);
+                stage_get<GF, T, MAT>(lQ, i, Qf);
+                stage_get<GY, T, 1>(lY, i, yv);
+                yreg[sb * G + i] = yv[0];
+                sym_from_full<T, D>(Qf, Qreg[sb * G + i]);
+                filter_reduce_step<T, D>(a, k0 + sb * G + i, Freg[sb * G + i], Qf, yv[0], h, agg);
+            }
+        }
+    } else {
+        lane_filter_reduce_direct<T, D>(a, k0, k1, h, agg);
+    }
+    FE excl, total;
+    block_scan_exclusive<FE, true>(agg, excl, total, lds);
+
+    // ---- hand-off: publish this tile's total, collect the carry from the left ---------------------
+    if (threadIdx.x == 0) {
+        T v[NF];
+        pack(total, v);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) pub_store(a.spine + (long)tile * NF + i, v[i]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.flags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int w0 = (tile / a.win) * a.win;
+    FE mine;
+    filt_identity(mine);
+    bool got = true;
+    {
+        const int idx = w0 + (int)threadIdx.x;
+        if (idx < tile) got = wait_flag(a.flags + idx, 1, a.status);
+        if (threadIdx.x == 0 && w0 > 0) got = wait_flag(a.flags + (w0 - 1), 2, a.status) && got;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (idx < tile && got) {
+            T v[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) v[i] = pub_load(a.spine + (long)idx * NF + i);
+            unpack(v, mine);
+        }
+        if (threadIdx.x == 0) {
+            if (w0 > 0) {
+#pragma unroll
+                for (int i = 0; i < NMP; ++i) s_base[i] = pub_load(a.incl + (long)(w0 - 1) * NMP + i);
+            } else {
+                T P0f[MAT], P0s[SYM];
+#pragma unroll
+                for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
+                sym_from_full<T, D>(P0f, P0s);
+#pragma unroll
+                for (int i = 0; i < D; ++i) s_base[i] = T(0);
+#pragma unroll
+                for (int i = 0; i < SYM; ++i) s_base[D + i] = P0s[i];
+            }
+        }
+    }
+    FE left;
+    block_reduce_ordered(mine, left, lds);          // (its barriers also publish s_base)
+    MC s;
+#pragma unroll
+    for (int i = 0; i < D; ++i) s.m[i] = s_base[i];
+#pragma unroll
+    for (int i = 0; i < SYM; ++i) s.P[i] = s_base[D + i];
+    filt_apply(s, left);                            // filtered state entering this tile
+    if ((tile + 1) % a.win == 0 && tile + 1 < a.nblocks && threadIdx.x == 0) {
+        // this tile closes a window: its inclusive prefix is the base of the next one
+        MC inc = s;
+        filt_apply(inc, total);
+#pragma unroll
+        for (int i = 0; i < D; ++i) pub_store(a.incl + (long)tile * NMP + i, inc.m[i]);
+#pragma unroll
+        for (int i = 0; i < SYM; ++i) pub_store(a.incl + (long)tile * NMP + D + i, inc.P[i]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.flags + tile, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    filt_apply(s, excl);                            // ... and this lane's chunk
+
+    // ---- phase B: lane-serial Kalman pass over the registers ---------------------------------------
+    LogLik ll;
+    SE sagg;
+    smth_identity(sagg);
+    if (staged) {
+        if (SMOOTH && lane < kWave - 1) have_next = true;
+        if (SMOOTH) {
+            // halo step of lane l = first step of lane l+1 (its registers); the last lane loaded its own
+            T Q0f[MAT];
+            full_from_sym<T, D>(Qreg[0], Q0f);
+#pragma unroll
+            for (int i = 0; i < MAT; ++i) {
+                const T f = __shfl_down(Freg[0][i], 1, kWave), q = __shfl_down(Q0f[i], 1, kWave);
+                if (lane < kWave - 1) { Fh[i] = f; Qh[i] = q; }
+            }
+        }
+        char* gP = reinterpret_cast<char*>(a.fPs + wbase * MAT);
+        char* gM = reinterpret_cast<char*>(a.fms + wbase * D);
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) {
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                T Qf[MAT];
+                full_from_sym<T, D>(Qreg[sb * G + i], Qf);
+                filter_apply_step<T, D, SMOOTH>(a, k0 + sb * G + i, k0, Freg[sb * G + i], Qf, yreg[sb * G + i], h, s, ll,
+                                                sagg);
+                T Pf[MAT];
+                full_from_sym<T, D>(s.P, Pf);
+                stage_put<GM, T, D>(lM, i, s.m);
+                stage_put<GF, T, MAT>(lF, i, Pf);
+            }
+            wave_lds_sync();
+            stage_drain<GM, NT>(gM + (long)sb * GM::SEG, pitchM, lM);
+            stage_drain<GF, NT>(gP + (long)sb * GF::SEG, pitchF, lF);
+        }
+        if (SMOOTH) filter_tail_apply<T, D>(have_next, Fh, Qh, s, sagg);
+    } else {
+        lane_filter_apply_direct<T, D, SMOOTH>(a, k0, k1, h, s, ll, sagg);
+    }
+
+    {
+        const double v = ll.value();
+        const double t = block_sum_double(v, lds_ll);
+        if (threadIdx.x == 0) a.llpart[tile] = t;
+    }
+    if (SMOOTH) {
+        SE sexcl, stotal;
+        block_scan_exclusive<SE, false>(sagg, sexcl, stotal, lds);
+        ws_store(a.lsuf, a.nlanes, gt, sexcl);
+        if (threadIdx.x == 0) rec_store(a.sspine + (long)tile * Dim<D>::NSMTH, stotal);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K-S1: smoother reduce (stand-alone pks only; pkfs gets the aggregates from k_filter_apply)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>

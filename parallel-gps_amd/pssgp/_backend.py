@@ -46,6 +46,7 @@ def _declare(lib):
     lib.pgps_set_chunk.argtypes = [P, c_int]
     lib.pgps_set_stage.argtypes = [P, c_int]
     lib.pgps_set_family.argtypes = [P, c_int]
+    lib.pgps_set_single_pass.argtypes = [P, c_int, c_int]
     lib.pgps_get_chunk.argtypes = [P, c_long, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_malloc.argtypes = [P, ctypes.c_size_t, ctypes.POINTER(P)]
     lib.pgps_free.argtypes = [P, P]
@@ -124,6 +125,10 @@ class Context:
     def set_stage(self, steps_per_subtile):
         """-1 auto, 0 direct global accesses, 2 / 4 steps per LDS-staged sub-tile."""
         check(self, self.lib.pgps_set_stage(self.handle, int(steps_per_subtile)), "pgps_set_stage")
+
+    def set_single_pass(self, mode=-1, window=0):
+        """Single-pass filter kernel: -1 auto, 0 off, 1 on; window = look-back window in tiles (0 = keep)."""
+        check(self, self.lib.pgps_set_single_pass(self.handle, int(mode), int(window)), "pgps_set_single_pass")
 
     def set_family(self, family):
         """0 auto, 1 lane-chunk kernels (d <= 6), 2 wave-cooperative kernels (any d <= 32)."""

@@ -107,6 +107,41 @@ def test_lds_staged_paths(stage, chunk, dtype, kname):
         ctx.set_stage(-1)
 
 
+@pytest.mark.parametrize("window", [1, 3, 256])
+@pytest.mark.parametrize("dtype,kname", [(np.float64, "m32"), (np.float32, "m32"), (np.float64, "m12")])
+def test_single_pass_filter_lookback(window, dtype, kname):
+    """The single-pass filter kernel (workgroups hand their totals to each other inside one launch)
+    against the oracle and against the three-launch path, with tiny look-back windows so that the
+    window-closing inclusive-prefix hand-off is exercised, plus a ragged tail."""
+    from pssgp.kernels import Matern12, Matern32
+    B = _gpu()
+    ctx = B.get_context()
+    k = Matern32(1., 1.) if kname == "m32" else Matern12(1., 1.)
+    n = 256 * 16 * 7 + 64 * 16 + 5          # 8 tiles, the last one ragged
+    t = make_times(n, seed=window)
+    ssm = O.get_ssm(k.get_sde(), t, 0.1)
+    y = sample_series_fast(ssm, seed=window, nan_frac=0.1)
+    from oracle import c_oracle as C
+    cf, cP, cs, csP, cll = C.kfs(ssm, y)
+    want = dict(fms=cf, fPs=cP, sms=cs, sPs=csP, ll=np.array([cll]))
+    try:
+        ctx.set_chunk(16)
+        ctx.set_single_pass(1, window)
+        got = _gpu_all(ssm, y, dtype)
+        _check_all(got, want, TOL64 if dtype == np.float64 else TOL32)
+        again = _gpu_all(ssm, y, dtype)
+        for name in got:
+            assert np.array_equal(got[name], again[name]), name      # timing-independent combine order
+        ctx.set_single_pass(0, 0)
+        ref = _gpu_all(ssm, y, dtype)
+        tol = 1e-12 if dtype == np.float64 else 1e-4
+        for name in got:
+            assert relerr(got[name], ref[name]) < tol, name
+    finally:
+        ctx.set_chunk(0)
+        ctx.set_single_pass(-1, 256)
+
+
 def test_missing_data_patterns():
     """All observations missing, first missing, last missing, long gaps."""
     from pssgp.kernels import Matern32
