@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
     ap.add_argument("--stage", type=int, default=-1, help="LDS staging: -1 auto, 0 off, 2 / 4 steps per sub-tile")
+    ap.add_argument("--path", default="lgssm", choices=["lgssm", "fused", "fused-ll"],
+                    help="lgssm: pkfs on resident Fs/Qs/ys (the reference's pkf/pks contract); fused: pgps_gp on "
+                         "resident ts/ys (discretisation inside the scan); fused-ll: log-likelihood only")
     ap.add_argument("--single-pass", type=int, default=-1,
                     help="single-pass (look-back) filter kernel: -1 auto, 0 off (three launches), 1 on")
     ap.add_argument("--force-segments", action="store_true",
@@ -174,7 +177,23 @@ def main():
     sPs = torch.empty((n_local, d, d), dtype=dtype_t, device=dev)
     ll_d = torch.zeros((2,), dtype=torch.float64, device=dev)
 
-    if world == 1 and not args.force_segments:
+    if args.path != "lgssm":
+        form = _backend.nilpotent_form(sde.F)
+        if form is None or world != 1:
+            raise SystemExit("--path fused needs a Matern kernel (d <= 3) and one GPU")
+        lam, N1, N2 = form
+        Pinf_h = np.ascontiguousarray(sde.P0, np.float64)
+        H_h = np.ascontiguousarray(np.asarray(sde.H, np.float64).reshape(-1))
+        HP = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+        null = ctypes.c_void_p(0)
+        full = args.path == "fused"
+
+        def step():
+            ctx.call(f"pgps_gp_dev_{suf}", ctypes.c_long(n_local), ctypes.c_int(d), ctypes.c_double(lam), HP(N1), HP(N2),
+                     HP(Pinf_h), HP(H_h), ctypes.c_double(noise), P(ts_d), ctypes.c_double(t_prev), P(ys_d),
+                     P(fms) if full else null, P(fPs) if full else null, P(sms) if full else null,
+                     P(sPs) if full else null, P(ll_d))
+    elif world == 1 and not args.force_segments:
         def step():
             ctx.call(f"pgps_pkfs_dev_{suf}", ctypes.c_long(n_local), ctypes.c_int(d), P(P0_d), P(Fs_d), P(Qs_d),
                      P(H_d), real(noise), P(ys_d), P(fms), P(fPs), P(sms), P(sPs), P(ll_d))
@@ -199,11 +218,12 @@ def main():
     for _ in range(min(args.warmup, 10)):
         step()
     torch.cuda.synchronize(dev)
-    dominant = "k_smoother_apply"
+    dominant = "k_smoother_apply" if args.path != "fused-ll" else "k_filter_apply"
     empty_pair_ms = ctx.profile_calibrate()
     ctx.profile_read(reset=True)
     ctx.profile_sample(args.event_every)
-    ctx.profile_enable((1 << 3) if args.event_every > 0 else 0)   # hipEvents around the dominant kernel (slot 3)
+    dom_slot = 3 if dominant == "k_smoother_apply" else 1
+    ctx.profile_enable((1 << dom_slot) if args.event_every > 0 else 0)   # time the dominant kernel's launches
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize(dev)
@@ -271,6 +291,7 @@ def main():
         "vs_baseline": None,
         "dtype": suf,
         "data": "synthetic",
+        "path": args.path,
         "config": {"workload": f"{args.kernel} state-dim {d}, N=2^{args.log2n} steps per GPU "
                                f"({n_total} total), {suf}, irregular times, prior-sampled observations",
                    "steps_per_gpu": n_local, "state_dim": d,
@@ -287,6 +308,38 @@ def main():
         "log_likelihood": ll_val,
         "chunk": ctx.get_chunk(n_local),
     }
+
+    # ---- the same workload through the fused entry point (ts, ys resident; Fs / Qs never read) ------------
+    if rank == 0 and world == 1 and args.path == "lgssm" and _backend.nilpotent_form(sde.F) is not None:
+        lam, N1, N2 = _backend.nilpotent_form(sde.F)
+        Pinf_h = np.ascontiguousarray(sde.P0, np.float64)
+        H_h = np.ascontiguousarray(np.asarray(sde.H, np.float64).reshape(-1))
+        HP = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+        null = ctypes.c_void_p(0)
+
+        def gp_step(full):
+            ctx.call(f"pgps_gp_dev_{suf}", ctypes.c_long(n_local), ctypes.c_int(d), ctypes.c_double(lam), HP(N1), HP(N2),
+                     HP(Pinf_h), HP(H_h), ctypes.c_double(noise), P(ts_d), ctypes.c_double(t_prev), P(ys_d),
+                     P(fms) if full else null, P(fPs) if full else null, P(sms) if full else null,
+                     P(sPs) if full else null, P(ll_d))
+
+        fused = {}
+        for name, full in (("filter+smooth+log-lik", True), ("log-lik only", False)):
+            for _ in range(10):
+                gp_step(full)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(min(args.steps, 100)):
+                gp_step(full)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / min(args.steps, 100)
+            fused[name] = {"ms_per_step": ms, "timesteps_per_s": n_local / ms * 1e3,
+                           "log_likelihood": float(ll_d[0].item())}
+        fused["note"] = ("pgps_gp_dev: discretisation fused into the scan kernels, inputs are (ts, ys) only; "
+                         "GPU-event time, not part of `value`")
+        out["fused_path"] = fused
 
     # ---- CPU baseline: the oracle's C restatement of the reference's sequential path ----------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -305,11 +358,11 @@ def main():
                                          f"(oracle/kalman_seq.c), median of {reps} runs"}
         # the checker also checks: GPU result vs the sequential oracle on the benchmarked arrays
         cf, cP, cs, csP, cll = res
-        out["parity_vs_cpu_oracle"] = {
-            "ll_rel": abs(ll_val - cll) / abs(cll),
-            "smoothed_mean_rel": float(np.max(np.abs(sms.cpu().numpy() - cs)) / np.max(np.abs(cs))),
-            "smoothed_cov_rel": float(np.max(np.abs(sPs.cpu().numpy() - csP)) / np.max(np.abs(csP))),
-        }
+        out["parity_vs_cpu_oracle"] = {"ll_rel": abs(ll_val - cll) / abs(cll)}
+        if args.path != "fused-ll":
+            out["parity_vs_cpu_oracle"].update({
+                "smoothed_mean_rel": float(np.max(np.abs(sms.cpu().numpy() - cs)) / np.max(np.abs(cs))),
+                "smoothed_cov_rel": float(np.max(np.abs(sPs.cpu().numpy() - csP)) / np.max(np.abs(csP)))})
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

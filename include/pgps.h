@@ -151,6 +151,30 @@ int pgps_pkfs_dev_f32(pgps_ctx*, long N, int d, const float* P0, const float* Fs
                       const float* H, float R, const float* ys, float* fms, float* fPs, float* sms,
                       float* sPs, double* ll);
 
+/* ---- fused path: times and observations in, posterior and log-likelihood out ------------------
+ * Replaces the chain  _get_ssm (pssgp/kernels/base.py:29-47) -> pkf / pkfs (parallel.py:121-201) that
+ * StateSpaceGP runs (pssgp/model.py:92-117) for SDEs whose drift is  F = -lam I + N  with N
+ * nilpotent (every Matern kernel; d <= 3):  Fs[k] = exp(-lam dt)(I + dt N1 + dt^2 N2), N1 = N,
+ * N2 = N^2/2, and Qs[k] = Pinf - Fs[k] Pinf Fs[k]^T are formed in registers inside the scan kernels,
+ * so a pass reads (t, y) instead of the (N, d, d) arrays.  The small model (lam, N1, N2 (may be NULL
+ * for d <= 2), Pinf (d,d), H (d)) is always passed from HOST memory; ts, ys and the outputs are
+ * device pointers for pgps_gp_dev_* and host pointers for pgps_gp_*.
+ *   fms/fPs == NULL and sms/sPs == NULL : log-likelihood only (nothing is written per step)
+ *   sms/sPs == NULL                     : filter (pkf with return_loglikelihood=True)
+ *   all given                           : filter + smoother (pkfs) + log-likelihood. */
+int pgps_gp_dev_f64(pgps_ctx*, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                    const double* H, double R, const double* ts, double t0, const double* ys, double* fms,
+                    double* fPs, double* sms, double* sPs, double* ll);
+int pgps_gp_dev_f32(pgps_ctx*, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                    const double* H, double R, const float* ts, double t0, const float* ys, float* fms, float* fPs,
+                    float* sms, float* sPs, double* ll);
+int pgps_gp_f64(pgps_ctx*, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                const double* H, double R, const double* ts, double t0, const double* ys, double* fms, double* fPs,
+                double* sms, double* sPs, double* ll);
+int pgps_gp_f32(pgps_ctx*, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                const double* H, double R, const float* ts, double t0, const float* ys, float* fms, float* fPs,
+                float* sms, float* sPs, double* ll);
+
 /* ---- one series sharded over several GPUs (contiguous time segments) -------------------
  * No reference equivalent (the reference is single-device).  Rank r of
  * `nranks` owns steps [r*N, (r+1)*N) -- every rank passes its own N -- and calls, in order:

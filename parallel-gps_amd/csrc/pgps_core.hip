@@ -613,3 +613,86 @@ static int seg_smoother(pgps_ctx* ctx, long N, int d, int rank, int nranks, cons
 
 PGPS_DEFINE_SEG(f64, double)
 PGPS_DEFINE_SEG(f32, float)
+
+// ---------------------------------------------------------------------------------------------
+// fused-discretisation ("gp") entry points
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int gp_dev(pgps_ctx* ctx, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                  const double* H, double R, const T* ts, double t0, const T* ys, T* fms, T* fPs, T* sms, T* sPs,
+                  double* ll) {
+    if (!ctx || N < 1 || !N1 || !Pinf || !H || !ts || !ys) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    if ((fms == nullptr) != (fPs == nullptr) || (sms == nullptr) != (sPs == nullptr)) return PGPS_E_INVALID;
+    if (sms && !fms) return PGPS_E_INVALID;             // the smoother reads the filtered moments back
+    if (!fms && !ll) return PGPS_E_INVALID;
+    if ((fms && (!aligned16(fms) || !aligned16(fPs))) || (sms && (!aligned16(sms) || !aligned16(sPs))))
+        return PGPS_E_INVALID;
+    GpArgs<T> g{};
+    g.s.N = N;
+    g.s.R = (T)R;
+    g.s.ys = ys;
+    g.s.fms = fms; g.s.fPs = fPs; g.s.sms = sms; g.s.sPs = sPs; g.s.ll = ll;
+    g.m.lam = lam;
+    for (int i = 0; i < 9; ++i) { g.m.N1[i] = 0; g.m.N2[i] = 0; g.m.Pinf[i] = 0; }
+    for (int i = 0; i < d * d; ++i) { g.m.N1[i] = N1[i]; g.m.N2[i] = N2 ? N2[i] : 0.0; g.m.Pinf[i] = Pinf[i]; }
+    for (int i = 0; i < 3; ++i) g.m.H[i] = i < d ? (T)H[i] : T(0);
+    g.m.ts = ts;
+    g.m.t_prev = (T)t0;
+    switch (d) {
+        case 1: return launch_gp<T, 1>(ctx, g, fms != nullptr, sms != nullptr);
+        case 2: return launch_gp<T, 2>(ctx, g, fms != nullptr, sms != nullptr);
+        case 3: return launch_gp<T, 3>(ctx, g, fms != nullptr, sms != nullptr);
+        default: return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
+
+template <typename T>
+static int gp_host(pgps_ctx* ctx, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                   const double* H, double R, const T* ts, double t0, const T* ys, T* fms, T* fPs, T* sms, T* sPs,
+                   double* ll) {
+    if (!ctx || N < 1 || !ts || !ys) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)N, dd = (size_t)d * d;
+    const bool wf = fms || fPs || sms || sPs, wsm = sms || sPs;
+    T *dts, *dys, *dfms = nullptr, *dfPs = nullptr, *dsms = nullptr, *dsPs = nullptr;
+    double* dll;
+    TRY(stage_in(ctx, ctx->st[4], ys, n, &dys));
+    TRY(stage_in(ctx, ctx->st[10], ts, n, &dts));
+    if (wf) {
+        TRY(stage_in<T>(ctx, ctx->st[5], nullptr, n * d, &dfms));
+        TRY(stage_in<T>(ctx, ctx->st[6], nullptr, n * dd, &dfPs));
+    }
+    if (wsm) {
+        TRY(stage_in<T>(ctx, ctx->st[7], nullptr, n * d, &dsms));
+        TRY(stage_in<T>(ctx, ctx->st[8], nullptr, n * dd, &dsPs));
+    }
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, 2, &dll));
+    TRY(gp_dev<T>(ctx, N, d, lam, N1, N2, Pinf, H, R, dts, t0, dys, dfms, dfPs, dsms, dsPs, dll));
+    if (fms) TRY(stage_out(ctx, fms, dfms, n * d));
+    if (fPs) TRY(stage_out(ctx, fPs, dfPs, n * dd));
+    if (sms) TRY(stage_out(ctx, sms, dsms, n * d));
+    if (sPs) TRY(stage_out(ctx, sPs, dsPs, n * dd));
+    double llh = 0.0;
+    TRY(stage_out(ctx, &llh, dll, 1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ll) *ll = llh;
+    if (!std::isfinite(llh)) return PGPS_E_NUMERIC;
+    return PGPS_OK;
+}
+
+#define PGPS_DEFINE_GP(SUF, T)                                                                                       \
+    extern "C" int pgps_gp_dev_##SUF(pgps_ctx* c, long N, int d, double lam, const double* N1, const double* N2,     \
+                                     const double* Pinf, const double* H, double R, const T* ts, double t0,         \
+                                     const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {                     \
+        return gp_dev<T>(c, N, d, lam, N1, N2, Pinf, H, R, ts, t0, ys, fms, fPs, sms, sPs, ll);                     \
+    }                                                                                                                \
+    extern "C" int pgps_gp_##SUF(pgps_ctx* c, long N, int d, double lam, const double* N1, const double* N2,         \
+                                 const double* Pinf, const double* H, double R, const T* ts, double t0, const T* ys, \
+                                 T* fms, T* fPs, T* sms, T* sPs, double* ll) {                                      \
+        return gp_host<T>(c, N, d, lam, N1, N2, Pinf, H, R, ts, t0, ys, fms, fPs, sms, sPs, ll);                    \
+    }
+
+PGPS_DEFINE_GP(f64, double)
+PGPS_DEFINE_GP(f32, float)

@@ -3,6 +3,7 @@
 // launch functions the C ABI dispatches to.  Split this way because the fully unrolled algebra
 // for d >= 5 takes minutes to compile; the Makefile builds the units in parallel.
 #include "pgps_discretise.hip.h"
+#include "pgps_fused.hip.h"
 #include "pgps_kernels.hip.h"
 
 #ifndef PGPS_INST_T
@@ -167,6 +168,48 @@ int launch_disc(pgps_ctx* ctx, long N, const T* F, const T* Pinf, const T* ts, T
     return PGPS_OK;
 }
 
+// ---- fused-discretisation ("gp") launches: d <= 3 ------------------------------------------------------
+template <typename T, int D, bool NT>
+static int launch_gp_nt(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed) {
+    ScanArgs<T>& a = g.s;
+    const dim3 grid(a.nblocks), block(kBlock);
+    timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_gp_reduce<T, D>, grid, block, 0, g);
+    if (want_smoothed) {
+        timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_apply<T, D, true, NT>, grid, block, 0, g);
+        timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_gp_smooth<T, D, NT>, grid, block, 0, g);
+    } else {
+        (void)want_filtered;
+        timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_apply<T, D, false, NT>, grid, block, 0, g);
+        if (a.ll)
+            timed_launch(ctx, PGPS_K_LL_FINALIZE, k_ll_finalize, dim3(1), block, 0, (const double*)a.llpart, a.nblocks,
+                         a.ll);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+template <typename T, int D>
+int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed) {
+    if constexpr (D <= 3) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        ScanArgs<T>& a = g.s;
+        geometry(ctx, a.N, &a.Lc, &a.nblocks);
+        a.nlanes = (long)a.nblocks * kBlock;
+        a.seg_first = 1;
+        a.seg_last = 1;
+        int rc = carve_workspace<T, D>(ctx, a);
+        if (rc) return rc;
+        // bytes one pass moves: t, y in; (d^2 + d) filtered out and back in, (d^2 + d) smoothed out
+        const double pass = (double)a.N * (2 + 3 * (D * D + D)) * sizeof(T);
+        if (pass > 512.0 * 1024 * 1024) return launch_gp_nt<T, D, true>(ctx, g, want_filtered, want_smoothed);
+        return launch_gp_nt<T, D, false>(ctx, g, want_filtered, want_smoothed);
+    } else {
+        (void)ctx; (void)g; (void)want_filtered; (void)want_smoothed;
+        return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
+
+template int launch_gp<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, GpArgs<PGPS_INST_T>, int, int);
 template int launch_scan<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, ScanArgs<PGPS_INST_T>, Mode);
 template int launch_disc<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, long, const PGPS_INST_T*, const PGPS_INST_T*,
                                                    const PGPS_INST_T*, PGPS_INST_T, PGPS_INST_T*, PGPS_INST_T*);

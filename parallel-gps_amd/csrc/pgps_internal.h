@@ -122,6 +122,26 @@ inline void timed_launch(pgps_ctx* ctx, int slot, void (*kernel)(KArgs...), dim3
     else hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, KArgs(args)...);
 }
 
+template <typename T>
+struct GpModel {
+    double lam;             // F = -lam I + N
+    double N1[9];           // N            (d x d, row-major, d <= 3)
+    double N2[9];           // N^2 / 2      (zero for d <= 2)
+    double Pinf[9];         // stationary covariance = P0
+    T H[3];
+    const T* ts;            // (N,) time stamps                     [device]
+    T t_prev;               // time before the first step (t0)
+};
+
+template <typename T>
+struct GpArgs {
+    ScanArgs<T> s;          // N, geometry, ys, R, outputs, scratch (Fs, Qs, P0, H unused)
+    GpModel<T> m;
+};
+
+template <typename T, int D>
+int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed);
+
 enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS, MODE_SEG_REDUCE, MODE_SEG_FILTER, MODE_SEG_SMOOTHER };
 
 // defined in pgps_inst.hip, one explicit instantiation per compiled (T, D)

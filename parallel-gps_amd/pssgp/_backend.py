@@ -63,6 +63,9 @@ def _declare(lib):
             getattr(lib, f"pgps_pkf{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, real, P, P, P, P]
             getattr(lib, f"pgps_pks{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, P, P]
             getattr(lib, f"pgps_pkfs{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, real, P, P, P, P, P, P]
+        for dev in ("", "_dev"):
+            getattr(lib, f"pgps_gp{dev}_{suf}").argtypes = [P, c_long, c_int, c_double, P, P, P, P, c_double, P, c_double,
+                                                            P, P, P, P, P, P]
         getattr(lib, f"pgps_seg_filter_reduce_dev_{suf}").argtypes = [P, c_long, c_int, c_int, c_int, P, P, P, P, real,
                                                                       P, P]
         getattr(lib, f"pgps_seg_filter_apply_dev_{suf}").argtypes = [P, c_long, c_int, c_int, c_int, P, P, P, P, real,
@@ -309,4 +312,58 @@ def pkfs(lgssm, observations, return_filtered=False, return_loglikelihood=False,
         out += (fms, fPs)
     if return_loglikelihood:
         out += (np.asarray(ll.value, dtype=dtype),)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# fused path: discretisation inside the scan kernels (SDEs with F = -lam I + N, N nilpotent, d <= 3)
+# ----------------------------------------------------------------------------------------------
+def nilpotent_form(F, tol=1e-9):
+    """(lam, N1, N2) with F = -lam I + N, N^d = 0, N1 = N, N2 = N^2 / 2 -- or None if F is not of
+    that form (it is for every Matern kernel, balanced or not) or d > 3."""
+    F = np.asarray(F, dtype=np.float64)
+    d = F.shape[0]
+    if d > 3:
+        return None
+    lam = -float(np.trace(F)) / d
+    N = F + lam * np.eye(d)
+    Np = np.linalg.matrix_power(N, d)
+    scale = max(1.0, float(np.max(np.abs(F)))) ** d
+    if not np.all(np.abs(Np) <= tol * scale) or lam <= 0:
+        return None
+    return lam, np.ascontiguousarray(N), np.ascontiguousarray(0.5 * (N @ N))
+
+
+def gp(form, Pinf, H, R, ts, ys, t0=0.0, want_filtered=False, want_smoothed=False, device=0):
+    """Fused filter (+ smoother) + log-likelihood straight from times and observations.
+
+    Returns a dict with "ll" and, on request, "fms", "fPs", "sms", "sPs" (host numpy arrays)."""
+    lam, N1, N2 = form
+    ts_a = np.asarray(ts)
+    dtype = ts_a.dtype if ts_a.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+    suf, _ = _suffix(dtype)
+    ts_a = _prep(ts_a, dtype, (-1,))
+    ys_a = _prep(ys, dtype, (-1,))
+    N = ts_a.shape[0]
+    if ys_a.shape[0] != N:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {N} steps")
+    d = N1.shape[0]
+    Pinf = _prep(Pinf, np.float64, (d, d))
+    H = _prep(H, np.float64, (d,))
+    want_filtered = want_filtered or want_smoothed
+    out = {}
+    fms = np.empty((N, d), dtype) if want_filtered else None
+    fPs = np.empty((N, d, d), dtype) if want_filtered else None
+    sms = np.empty((N, d), dtype) if want_smoothed else None
+    sPs = np.empty((N, d, d), dtype) if want_smoothed else None
+    ll = c_double(0.0)
+    get_context(device).call(f"pgps_gp_{suf}", c_long(N), c_int(d), c_double(lam), _ptr(_prep(N1, np.float64)),
+                             _ptr(_prep(N2, np.float64)), _ptr(Pinf), _ptr(H), c_double(float(R)), _ptr(ts_a),
+                             c_double(float(t0)), _ptr(ys_a), _ptr(fms), _ptr(fPs), _ptr(sms), _ptr(sPs),
+                             ctypes.cast(ctypes.byref(ll), c_void_p))
+    out["ll"] = np.asarray(ll.value, dtype=dtype)
+    if want_filtered:
+        out["fms"], out["fPs"] = fms, fPs
+    if want_smoothed:
+        out["sms"], out["sPs"] = sms, sPs
     return out

@@ -66,6 +66,22 @@ class StateSpaceGP:
             self._kf = lambda ssm, y: pkf(ssm, y, return_loglikelihood=True, max_parallel=ts.shape[0])
             self._kfs = lambda ssm, y: pkfs(ssm, y, max_parallel=max_parallel)
 
+    def _fused_form(self):
+        """(sde, (lam, N1, N2)) when the kernel's SDE has the closed-form discretisation the fused HIP
+        path uses (F = -lam I + N, N nilpotent, d <= 3: the Matern family), else None."""
+        if not self.parallel:
+            return None
+        from . import _backend
+        sde = self.kernel.get_sde()
+        form = _backend.nilpotent_form(sde.F)
+        if form is None:
+            return None
+        F, P0 = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64)
+        LQL = np.asarray(sde.L, np.float64) @ np.atleast_2d(np.asarray(sde.Q, np.float64)) @ np.asarray(sde.L, np.float64).T
+        if np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) > 1e-8 * max(1.0, float(np.max(np.abs(LQL)))):
+            return None
+        return sde, form
+
     def _make_model(self, ts):
         R = np.reshape(np.asarray(self.noise_variance, dtype=config.default_float()), (1, 1))
         return self.kernel.get_ssm(ts, R)
@@ -83,16 +99,31 @@ class StateSpaceGP:
         all_ts, all_ys, all_flags = _merge_sorted(
             squeezed_ts, squeezed_Xnew, (ys, nan_ys),
             (np.zeros(squeezed_ts.shape, dtype=bool), np.ones(squeezed_Xnew.shape, dtype=bool)))
-        ssm = self._make_model(all_ts[:, None])
-        sms, sPs = self._kfs(ssm, all_ys)
+        fused = self._fused_form()
+        if fused is not None:
+            # times and observations straight into the scan kernels (Fs / Qs never materialised)
+            from . import _backend
+            sde, form = fused
+            res = _backend.gp(form, sde.P0, sde.H, self.noise_variance, all_ts.astype(dtype), all_ys.reshape(-1),
+                              want_smoothed=True)
+            sms, sPs = res["sms"], res["sPs"]
+            H = np.asarray(sde.H, dtype=dtype).reshape(1, -1)
+        else:
+            ssm = self._make_model(all_ts[:, None])
+            sms, sPs = self._kfs(ssm, all_ys)
+            H = np.asarray(ssm.H)
         sm, sP = sms[all_flags], sPs[all_flags]
-        H = np.asarray(ssm.H)
         mean = sm @ H.T
         var = np.einsum("ai,nij,aj->na", H, sP, H)
         return mean, var
 
     def maximum_log_likelihood_objective(self):
         ts, Y = self.data
+        fused = self._fused_form()
+        if fused is not None:
+            from . import _backend
+            sde, form = fused
+            return _backend.gp(form, sde.P0, sde.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))["ll"]
         ssm = self._make_model(ts)
         _, _, ll = self._kf(ssm, Y)
         return ll

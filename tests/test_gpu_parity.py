@@ -310,3 +310,53 @@ def test_full_size_against_c_oracle(dtype, kname, n):
     slack = 1e-9 if dtype == np.float64 else 1e-3
     for i in range(d):
         assert np.all(got["sPs"][:, i, i] <= got["fPs"][:, i, i] * (1 + slack) + slack)
+
+
+@pytest.mark.parametrize("kname", ["m12", "m32", "m52"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,chunk", [(1, 0), (5, 0), (300, 0), (5000, 0), (256 * 16 * 3 + 77, 16), (256 * 8 * 2 + 9, 8),
+                                     (9000, 5)])
+def test_fused_discretisation_path(kname, dtype, n, chunk):
+    """pgps_gp_*: (t, y) in, filtered / smoothed moments and log-likelihood out, F_k and Q_k formed in
+    registers -- against the oracle fed with the reference's expm discretisation."""
+    from pssgp.kernels import Matern12, Matern32, Matern52
+    B = _gpu()
+    ctx = B.get_context()
+    k = {"m12": Matern12(1.3, 0.7), "m32": Matern32(1.3, 0.7), "m52": Matern52(1.3, 0.7)}[kname]
+    sde = k.get_sde()
+    form = B.nilpotent_form(sde.F)
+    assert form is not None
+    t = make_times(n, seed=n % 89)
+    if n > 10:
+        t[7] = t[6]                                            # a zero step
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series_fast(ssm, seed=n % 89, nan_frac=0.15 if n > 4 else 0.0)
+    from oracle import c_oracle as C
+    cf, cP, cs, csP, cll = C.kfs(ssm, y)
+    tol = TOL64 if dtype == np.float64 else TOL32
+    try:
+        ctx.set_chunk(chunk)
+        res = B.gp(form, sde.P0, sde.H, 0.1, t.astype(dtype), y.astype(dtype), want_smoothed=True)
+        assert relerr(res["fms"], cf) < tol and relerr(res["fPs"], cP) < tol
+        assert relerr(res["sms"], cs) < tol and relerr(res["sPs"], csP) < tol
+        lltol = 1e-9 if dtype == np.float64 else 1e-4
+        if not np.all(np.isnan(y)):
+            assert abs(float(res["ll"]) - cll) < lltol * max(1.0, abs(cll))
+        only_ll = B.gp(form, sde.P0, sde.H, 0.1, t.astype(dtype), y.astype(dtype))
+        assert float(only_ll["ll"]) == float(res["ll"])                     # same arithmetic, nothing stored
+        filt = B.gp(form, sde.P0, sde.H, 0.1, t.astype(dtype), y.astype(dtype), want_filtered=True)
+        assert np.array_equal(filt["fms"], res["fms"]) and np.array_equal(filt["fPs"], res["fPs"])
+    finally:
+        ctx.set_chunk(0)
+
+
+def test_nilpotent_form_detection():
+    from pssgp.kernels import Matern12, Matern32, Matern52, RBF, Periodic, SquaredExponential
+    B = _gpu()
+    for k in (Matern12(2., 0.3), Matern32(1., 1.), Matern52(0.5, 2.)):
+        lam, N1, N2 = B.nilpotent_form(k.get_sde().F)
+        F = np.asarray(k.get_sde().F)
+        assert np.allclose(-lam * np.eye(F.shape[0]) + N1, F) and np.allclose(N2, 0.5 * N1 @ N1)
+    assert B.nilpotent_form(RBF(1., 1., order=3).get_sde().F) is None
+    assert B.nilpotent_form(Periodic(SquaredExponential(1., 1.), 1., order=1).get_sde().F) is None
+    assert B.nilpotent_form((Matern32() + Matern12()).get_sde().F) is None

@@ -139,3 +139,22 @@ def test_merge_sorted_semantics():
     empty = np.array([])
     c, = _merge_sorted(x, empty)
     assert np.array_equal(c, x)
+
+
+def test_nilpotent_form_detection_host():
+    """Which kernels qualify for the fused-discretisation GPU path (F = -lam I + N, N nilpotent, d <= 3)."""
+    from pssgp import _backend as B
+    for k in (Matern12(2., 0.3), Matern32(1., 1.), Matern52(0.5, 2.)):
+        F = np.asarray(k.get_sde().F)
+        lam, N1, N2 = B.nilpotent_form(F)
+        d = F.shape[0]
+        assert np.allclose(-lam * np.eye(d) + N1, F) and np.allclose(N2, 0.5 * N1 @ N1)
+        assert np.max(np.abs(np.linalg.matrix_power(N1, d))) < 1e-9 * max(1.0, np.max(np.abs(F))) ** d
+        # closed form == expm
+        import scipy.linalg as sla
+        dt = 0.37
+        closed = np.exp(-lam * dt) * (np.eye(d) + dt * N1 + dt * dt * N2)
+        assert np.max(np.abs(closed - sla.expm(dt * F))) < 1e-12
+    assert B.nilpotent_form(RBF(1., 1., order=3).get_sde().F) is None
+    assert B.nilpotent_form(Periodic(SquaredExponential(1., 1.), 1., order=1).get_sde().F) is None
+    assert B.nilpotent_form((Matern32() + Matern52()).get_sde().F) is None
