@@ -55,6 +55,9 @@ def parse():
                          "resident ts/ys (discretisation inside the scan); fused-ll: log-likelihood only")
     ap.add_argument("--single-pass", type=int, default=-1,
                     help="single-pass (look-back) filter kernel: -1 auto, 0 off (three launches), 1 on")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--all-on-gpu0", action="store_true",
+                    help="dry run of the multi-rank path on a 1-GPU box: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--force-segments", action="store_true",
                     help="run the multi-GPU segment protocol even at one GPU (measures its overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,6 +106,9 @@ def sample_prior_observations(P0, Fs, Qs, H, R, rng):
 
 def main():
     args = parse()
+    if os.environ.get("PGPS_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PGPS_BENCH_WATCHDOG"]), exit=True)
     import torch
     import torch.distributed as dist
     from pssgp import _backend
@@ -116,11 +122,16 @@ def main():
                              (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.all_on_gpu0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     dtype_np = np.float64 if args.dtype == "f64" else np.float32
     dtype_t = torch.float64 if args.dtype == "f64" else torch.float32
@@ -243,7 +254,7 @@ def main():
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(0)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

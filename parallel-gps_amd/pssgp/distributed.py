@@ -81,8 +81,13 @@ class SegmentScan:
     def _gather(self, out, rec):
         if self.world == 1:
             out.copy_(rec.view(1, -1))
+        elif self.dist.get_backend(self.group) == "nccl":
+            self.dist.all_gather_into_tensor(out, rec, group=self.group)       # RCCL over xGMI
         else:
-            self.dist.all_gather_into_tensor(out, rec, group=self.group)
+            # e.g. gloo (tests: several ranks sharing one GPU): list form, staged through the host
+            parts = [self.torch.empty_like(rec) for _ in range(self.world)]
+            self.dist.all_gather(parts, rec, group=self.group)
+            out.copy_(self.torch.stack(parts))
         return out
 
     def pkfs(self, n_local, P0, Fs, Qs, H, R, ys, fms, fPs, sms, sPs, ll):

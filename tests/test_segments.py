@@ -249,3 +249,69 @@ def test_segmentscan_world1_with_torch():
     assert relerr(fms.cpu().numpy(), of) < 1e-9 and relerr(sms.cpu().numpy(), os_) < 1e-9
     assert relerr(sPs.cpu().numpy(), osP) < 1e-9 and abs(ll[0].item() - oll) < 1e-10 * abs(oll)
     ctx.close()
+
+
+_GPU_WORKER = r"""
+import os, sys
+import numpy as np
+import torch                                   # before libpgps: one HIP runtime per process
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "parallel-gps_amd"))
+from oracle import np_oracle as O
+from pssgp import _backend as B
+from pssgp.distributed import SegmentScan, split_segments
+from tests.test_segments import _problem, _slice
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda", 0)                  # every rank on GPU 0: RCCL would refuse, gloo does not care
+torch.cuda.set_device(dev)
+ssm, y = _problem(n=40000, seed=4)
+d = ssm[1].shape[1]
+lo, hi = split_segments(y.size, world)[rank]
+P0, Fs, Qs, H, R = _slice(ssm, lo, hi)
+ctx = B.Context(0)
+ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+tP0, tFs, tQs, tH, tys = T(P0), T(Fs), T(Qs), T(H.reshape(-1)), T(y[lo:hi])
+n = hi - lo
+E = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
+fms, fPs, sms, sPs, ll = E(n, d), E(n, d, d), E(n, d), E(n, d, d), torch.zeros(2, dtype=torch.float64, device=dev)
+seg = SegmentScan(ctx, rank, world, d, np.float64, torch_device=dev)
+for _ in range(3):                             # repeated passes reuse the scratch and the records
+    seg.pkfs(n, tP0, tFs, tQs, tH, 0.1, tys, fms, fPs, sms, sPs, ll)
+torch.cuda.synchronize(dev)
+of, oP, oll = O.kf(ssm, y, True)
+os_, osP = O.kfs(ssm, y)
+rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+err = max(rel(fms.cpu().numpy(), of[lo:hi]), rel(fPs.cpu().numpy(), oP[lo:hi]), rel(sms.cpu().numpy(), os_[lo:hi]),
+          rel(sPs.cpu().numpy(), osP[lo:hi]), abs(ll[0].item() - oll) / abs(oll))
+dist.barrier()
+dist.destroy_process_group()
+print("RANK", rank, "ERR", err)
+sys.exit(0 if err < 1e-9 else 3)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_segmentscan_multiprocess_on_one_gpu(tmp_path, world):
+    """The real multi-process driver -- one process, one libpgps context and one torch.distributed rank
+    per segment -- with all ranks on GPU 0 and gloo standing in for RCCL (which refuses two ranks on
+    one device): everything except the collective's transport is what `bench.py --gpus N` runs."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GPU_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + world), WORLD_SIZE=str(world),
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
