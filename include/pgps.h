@@ -70,6 +70,9 @@ int pgps_set_family(pgps_ctx* ctx, int family);
 int pgps_set_stage(pgps_ctx* ctx, int steps_per_subtile);
 int pgps_get_chunk(pgps_ctx* ctx, long n_steps, int* steps_per_lane, int* n_workgroups);
 const char* pgps_last_hip_error(pgps_ctx* ctx);
+/* Diagnostic flags raised on the device since the last call (synchronises; 0 = none; bit 1: a bounded
+ * look-back spin of the single-pass filter gave up -- results of that pass are invalid). */
+int pgps_status(pgps_ctx* ctx, int* flags);
 
 /* ---- device memory helpers (for hosts without a device-array library) ----------------- */
 int pgps_malloc(pgps_ctx* ctx, size_t bytes, void** dptr);
@@ -174,6 +177,18 @@ int pgps_gp_f64(pgps_ctx*, long N, int d, double lam, const double* N1, const do
 int pgps_gp_f32(pgps_ctx*, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
                 const double* H, double R, const float* ts, double t0, const float* ys, float* fms, float* fPs,
                 float* sms, float* sPs, double* ll);
+
+/* ---- log-likelihood and its gradient (fused path, d <= 2, fp64) --------------------------------
+ * What the reference gets from TensorFlow autodiff through the scan (tests/test_gp_vs_kfs.py:53-78;
+ * SURVEY.md section 8f, rank 1): forward-mode dual numbers carried through every filtering element and
+ * every application of the associative operator.  `model` (HOST memory) holds 1 + np blocks of
+ * [lam | N1 (d*d) | Pinf (d*d) | H (d) | R]: block 0 the values, block p the partial derivatives with
+ * respect to hyper-parameter p (np <= 3).  out[0] = log-likelihood, out[1..np] = its gradient.
+ * ts, ys, out: host pointers for pgps_gp_ll_grad_f64, device pointers for the _dev form. */
+int pgps_gp_ll_grad_f64(pgps_ctx*, long N, int d, int np, const double* model, const double* ts, double t0,
+                        const double* ys, double* out);
+int pgps_gp_ll_grad_dev_f64(pgps_ctx*, long N, int d, int np, const double* model, const double* ts, double t0,
+                            const double* ys, double* out);
 
 /* ---- one series sharded over several GPUs (contiguous time segments) -------------------
  * No reference equivalent (the reference is single-device).  Rank r of

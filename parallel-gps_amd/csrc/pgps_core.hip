@@ -66,6 +66,11 @@ extern "C" int pgps_create(int device, pgps_ctx** out) {
         return PGPS_E_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipMalloc((void**)&ctx->status_word, 256) != hipSuccess || hipMemset(ctx->status_word, 0, 256) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return PGPS_E_NOMEM;
+    }
     *out = ctx;
     return PGPS_OK;
 }
@@ -76,6 +81,7 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
     if (ctx->stamps.p) (void)hipFree(ctx->stamps.p);
+    if (ctx->status_word) (void)hipFree(ctx->status_word);
     for (auto& b : ctx->st)
         if (b.p) (void)hipFree(b.p);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -114,6 +120,18 @@ extern "C" int pgps_debug_read_stamps(pgps_ctx* ctx, long long* out, long n_valu
     if (!ctx->stamps.p || (size_t)n_values * sizeof(long long) > ctx->stamps.cap) return PGPS_E_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(out, ctx->stamps.p, (size_t)n_values * sizeof(long long), hipMemcpyDeviceToHost));
+    return PGPS_OK;
+}
+
+// Diagnostic flags raised by kernels (bit 1: a look-back spin of the single-pass filter hit its bound).
+// Synchronises, returns and clears them.
+extern "C" int pgps_status(pgps_ctx* ctx, int* flags) {
+    if (!ctx || !flags) return PGPS_E_INVALID;
+    *flags = 0;
+    if (!ctx->status_word) return PGPS_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(flags, ctx->status_word, sizeof(int), hipMemcpyDeviceToHost));
+    if (*flags) HIPCHK(ctx, hipMemset(ctx->status_word, 0, sizeof(int)));
     return PGPS_OK;
 }
 
@@ -696,3 +714,27 @@ static int gp_host(pgps_ctx* ctx, long N, int d, double lam, const double* N1, c
 
 PGPS_DEFINE_GP(f64, double)
 PGPS_DEFINE_GP(f32, float)
+
+// ---------------------------------------------------------------------------------------------
+// log-likelihood and its gradient (fused path, forward-mode duals through the scan)
+// ---------------------------------------------------------------------------------------------
+extern "C" int pgps_gp_ll_grad_dev_f64(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts,
+                                       double t0, const double* ys, double* out) {
+    if (!ctx || N < 1 || !model || !ts || !ys || !out) return PGPS_E_INVALID;
+    return launch_grad(ctx, N, d, np, model, ts, t0, ys, out);
+}
+
+extern "C" int pgps_gp_ll_grad_f64(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts,
+                                   double t0, const double* ys, double* out) {
+    if (!ctx || N < 1 || !model || !ts || !ys || !out) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *dts, *dys, *dout;
+    TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
+    TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, 8, &dout));
+    TRY(launch_grad(ctx, N, d, np, model, dts, t0, dys, dout));
+    TRY(stage_out(ctx, out, dout, (size_t)(1 + np)));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!std::isfinite(out[0])) return PGPS_E_NUMERIC;
+    return PGPS_OK;
+}

@@ -35,7 +35,8 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     a.sspine = (T*)(base + o_sspine);
     a.lsuf = (T*)(base + o_lsuf);
     a.llpart = (double*)(base + o_ll);
-    a.status = (int*)(base + o_status);
+    a.status = ctx->status_word;
+    (void)o_status;
     a.seg_ws = (T*)(base + o_seg);
     a.ticket = (int*)(base + o_flags);
     a.flags = a.ticket + 4;

@@ -28,6 +28,7 @@ struct pgps_ctx {
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
     DevBuf stamps;                      // diagnostic build only
+    int* status_word = nullptr;         // device word kernels raise flags in (pgps_status)
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
     int prof_every = 1;                 // time every n-th launch of an enabled slot
     long prof_seen[PGPS_K_COUNT] = {0};
@@ -141,6 +142,10 @@ struct GpArgs {
 
 template <typename T, int D>
 int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed);
+
+// log-likelihood + gradient on the fused path (pgps_grad.hip); all array pointers device
+int launch_grad(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts, double t0,
+                const double* ys, double* out_dev);
 
 enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS, MODE_SEG_REDUCE, MODE_SEG_FILTER, MODE_SEG_SMOOTHER };
 

@@ -202,13 +202,19 @@ struct ElemTraits<SmthElem<T, D>> {
     }
 };
 
+// 64-wide shuffles of one scalar; overloaded for dual numbers in pgps_grad.hip.h
+__device__ __forceinline__ float wshfl_up(float x, int s) { return __shfl_up(x, s, kWave); }
+__device__ __forceinline__ double wshfl_up(double x, int s) { return __shfl_up(x, s, kWave); }
+__device__ __forceinline__ float wshfl_down(float x, int s) { return __shfl_down(x, s, kWave); }
+__device__ __forceinline__ double wshfl_down(double x, int s) { return __shfl_down(x, s, kWave); }
+
 template <typename E>
 __device__ __forceinline__ E shfl_up_elem(const E& e, int s) {
     using TR = ElemTraits<E>;
     typename TR::Scalar v[TR::N];
     pack(e, v);
 #pragma unroll
-    for (int i = 0; i < TR::N; ++i) v[i] = __shfl_up(v[i], s, kWave);
+    for (int i = 0; i < TR::N; ++i) v[i] = wshfl_up(v[i], s);
     E r;
     unpack(v, r);
     return r;
@@ -219,7 +225,7 @@ __device__ __forceinline__ E shfl_down_elem(const E& e, int s) {
     typename TR::Scalar v[TR::N];
     pack(e, v);
 #pragma unroll
-    for (int i = 0; i < TR::N; ++i) v[i] = __shfl_down(v[i], s, kWave);
+    for (int i = 0; i < TR::N; ++i) v[i] = wshfl_down(v[i], s);
     E r;
     unpack(v, r);
     return r;
@@ -607,9 +613,9 @@ __global__ __launch_bounds__(kBlock) void k_filter_reduce(const ScanArgs<T> a) {
 // K-F3: filter apply (+ log-likelihood, + fused smoothing-aggregate build when SMOOTH)
 // ---------------------------------------------------------------------------------------------
 // one step of the lane-serial Kalman pass; `prev` = filtered state of step k-1 (or the carry-in)
-template <typename T, int D, bool SMOOTH>
+template <typename T, int D, bool SMOOTH, typename LL = LogLik>
 __device__ __forceinline__ void filter_apply_step(const ScanArgs<T>& a, long k, long k0, const T* F, const T* Qf, T y,
-                                                  const T* h, MeanCov<T, D>& s, LogLik& ll, SmthElem<T, D>& sagg) {
+                                                  const T* h, MeanCov<T, D>& s, LL& ll, SmthElem<T, D>& sagg) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM;
     T Q[SYM];
     sym_from_full<T, D>(Qf, Q);

@@ -221,7 +221,8 @@ PGPS_HD void gj_solve(T* M, T* B) {
         if (PIVOT) {
 #pragma unroll
             for (int r = c + 1; r < D; ++r) {
-                const bool sw = std::fabs(M[r * D + c]) > std::fabs(M[c * D + c]);
+                using std::fabs;
+                const bool sw = fabs(M[r * D + c]) > fabs(M[c * D + c]);
 #pragma unroll
                 for (int j = c; j < D; ++j) {
                     const T u = M[c * D + j], v = M[r * D + j];
@@ -431,6 +432,11 @@ PGPS_HD void filt_apply(MeanCov<T, D>& s, const FiltElem<T, D>& e2) {
 // P0 directly (parallel.py:24-30) while the likelihood term uses F0 P0 F0^T + Q0
 // (parallel.py:136-141).  Outputs mp, Pp (the predicted moments) for the smoother element.
 // ------------------------------------------------------------------------------------
+// residual / innovation variance widened to the accumulator's type (fp64 for float and double operands;
+// dual numbers keep their derivatives: overloads in pgps_dual.h)
+template <typename T> PGPS_HD double ll_diff(T y, T mu) { return double(y) - double(mu); }
+template <typename T> PGPS_HD double ll_wide(T S) { return double(S); }
+
 // Log-likelihood accumulator.  sum_k log s2_k is kept as a product of mantissas plus an exponent
 // count (frexp is two cheap instructions on the GPU; an fp64 log is ~80): one log at the end.
 struct LogLik {
@@ -452,9 +458,9 @@ struct LogLik {
     }
 };
 
-template <typename T, int D>
+template <typename T, int D, typename LL>
 PGPS_HD void kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, const T* h, T R,
-                     bool first, LogLik& ll, T* mp, T* Pp, T* FP) {
+                     bool first, LL& ll, T* mp, T* Pp, T* FP) {
     mat_vec<T, D>(F, s.m, mp);
     predict_cov<T, D>(F, s.P, Q, FP, Pp);
     const bool obs = !is_nan(y);
@@ -464,7 +470,7 @@ PGPS_HD void kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, cons
 #pragma unroll
     for (int i = 0; i < D; ++i) { S += h[i] * u[i]; mu += h[i] * mp[i]; }
     if (obs) {
-        ll.add(double(y) - double(mu), double(S));
+        ll.add(ll_diff(y, mu), ll_wide(S));
     }
     if (first) {
         // update straight from the prior (s holds m0 = 0, P0)

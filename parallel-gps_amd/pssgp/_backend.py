@@ -43,6 +43,7 @@ def _declare(lib):
     lib.pgps_set_stream.argtypes = [P, P]
     lib.pgps_use_own_stream.argtypes = [P]
     lib.pgps_synchronize.argtypes = [P]
+    lib.pgps_status.argtypes = [P, ctypes.POINTER(c_int)]
     lib.pgps_set_chunk.argtypes = [P, c_int]
     lib.pgps_set_stage.argtypes = [P, c_int]
     lib.pgps_set_family.argtypes = [P, c_int]
@@ -149,6 +150,12 @@ class Context:
 
     def use_own_stream(self):
         check(self, self.lib.pgps_use_own_stream(self.handle), "pgps_use_own_stream")
+
+    def status(self):
+        """Device-side diagnostic flags since the last call (0 = none); synchronises."""
+        f = c_int(0)
+        check(self, self.lib.pgps_status(self.handle, ctypes.byref(f)), "pgps_status")
+        return f.value
 
     def synchronize(self):
         check(self, self.lib.pgps_synchronize(self.handle), "pgps_synchronize")
@@ -367,3 +374,33 @@ def gp(form, Pinf, H, R, ts, ys, t0=0.0, want_filtered=False, want_smoothed=Fals
     if want_smoothed:
         out["sms"], out["sPs"] = sms, sPs
     return out
+
+
+def pack_grad_model(blocks):
+    """(1 + np, 1 + 2 d^2 + d + 1) array [lam | N1 | Pinf | H | R] per block, as pgps_gp_ll_grad_* reads it."""
+    d = np.asarray(blocks[0][1]).shape[0]
+    rows = []
+    for lam, N1, Pinf, H, R in blocks:
+        rows.append(np.concatenate([[float(lam)], np.asarray(N1, np.float64).reshape(-1),
+                                    np.asarray(Pinf, np.float64).reshape(-1), np.asarray(H, np.float64).reshape(-1),
+                                    [float(R)]]))
+    model = np.ascontiguousarray(np.stack(rows), dtype=np.float64)
+    if model.shape[1] != 1 + 2 * d * d + d + 1:
+        raise ValueError("malformed model block")
+    return model, d, len(blocks) - 1
+
+
+def gp_ll_grad(blocks, ts, ys, t0=0.0, device=0):
+    """Log-likelihood and its gradient on the fused path (pgps_gp_ll_grad_f64, fp64, d <= 2).
+
+    `blocks`: list of 1 + np tuples (lam, N1, Pinf, H, R) -- the model, then its partial derivative
+    with respect to each hyper-parameter.  Returns (ll, grad[np])."""
+    model, d, npar = pack_grad_model(blocks)
+    ts_a = _prep(ts, np.float64, (-1,))
+    ys_a = _prep(ys, np.float64, (-1,))
+    if ys_a.shape[0] != ts_a.shape[0]:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
+    out = np.zeros(1 + npar, np.float64)
+    get_context(device).call("pgps_gp_ll_grad_f64", c_long(ts_a.shape[0]), c_int(d), c_int(npar), _ptr(model),
+                             _ptr(ts_a), c_double(float(t0)), _ptr(ys_a), _ptr(out))
+    return out[0], out[1:]

@@ -3,8 +3,9 @@
 Mirrors pssgp/model.py:58-117 of the reference: same constructor, `predict_f`,
 `maximum_log_likelihood_objective`, `training_loss`; `parallel=True` runs the HIP
 associative-scan path (csrc/), `parallel=False` the sequential host recursion.  Data and
-results are numpy arrays; hyper-parameters are plain floats (no GPflow `Parameter`s, no
-autodiff in this tier -- SURVEY.md section 8f).
+results are numpy arrays; hyper-parameters are plain floats (no GPflow `Parameter`s); the
+gradient of the log-likelihood comes from `log_likelihood_and_grad` (forward-mode duals inside
+the scan kernels) instead of TensorFlow autodiff.
 """
 import numpy as np
 
@@ -127,6 +128,59 @@ class StateSpaceGP:
         ssm = self._make_model(ts)
         _, _, ll = self._kf(ssm, Y)
         return ll
+
+    # -- hyper-parameter gradients (SURVEY.md section 8f rank 1) --------------------------------
+    def trainable_parameters(self):
+        """[(owner, attribute name)] in the order the gradient is returned: the kernel's variance and
+        lengthscale, then the observation-noise variance (the reference's gpflow Parameters,
+        pssgp/model.py:68 and the Matern kernels' variance / lengthscales)."""
+        ps = [(self.kernel, a) for a in ("variance", "lengthscales") if isinstance(getattr(self.kernel, a, None), float)]
+        return ps + [(self, "noise_variance")]
+
+    def _grad_blocks(self):
+        """The fused model (lam, N, Pinf, H, R) and its partial derivatives with respect to each
+        trainable parameter.  The SDE coefficients are low-degree rational functions of the
+        parameters; a Richardson-extrapolated central difference of get_sde() is exact to ~1e-11."""
+        def block():
+            sde = self.kernel.get_sde()
+            from . import _backend
+            form = _backend.nilpotent_form(sde.F)
+            if form is None:
+                raise NotImplementedError("gradients need the closed-form (Matern-family) discretisation")
+            return [np.float64(form[0]), np.asarray(form[1], np.float64), np.asarray(sde.P0, np.float64),
+                    np.asarray(sde.H, np.float64).reshape(-1), np.float64(self.noise_variance)]
+
+        base = block()
+        blocks = [tuple(base)]
+        for owner, name in self.trainable_parameters():
+            x0 = getattr(owner, name)
+
+            def central(h):
+                setattr(owner, name, x0 + h)
+                up = block()
+                setattr(owner, name, x0 - h)
+                dn = block()
+                return [(u - v) / (2.0 * h) for u, v in zip(up, dn)]
+
+            try:
+                h = 1e-3 * max(abs(x0), 1e-3)
+                d1, d2 = central(h), central(0.5 * h)
+                blocks.append(tuple((4.0 * b - a) / 3.0 for a, b in zip(d1, d2)))
+            finally:
+                setattr(owner, name, x0)
+        return blocks
+
+    def log_likelihood_and_grad(self):
+        """(ll, grad): the marginal log-likelihood and its gradient with respect to
+        `trainable_parameters()`, in ONE pass of the parallel filter on dual numbers -- what the
+        reference obtains from tf.GradientTape over maximum_log_likelihood_objective
+        (tests/test_gp_vs_kfs.py:53-78).  parallel=True, Matern-1/2 and Matern-3/2 (d <= 2), fp64."""
+        if not self.parallel:
+            raise NotImplementedError("gradients run on the parallel (HIP) path: construct with parallel=True")
+        from . import _backend
+        ts, Y = self.data
+        ll, g = _backend.gp_ll_grad(self._grad_blocks(), ts.reshape(-1), Y.reshape(-1))
+        return ll, g
 
     def log_posterior_density(self):
         return self.maximum_log_likelihood_objective()

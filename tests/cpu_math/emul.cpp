@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "pgps_math.h"
+#include "pgps_dual.h"
 
 using namespace pgps;
 
@@ -171,4 +172,72 @@ extern "C" int emul_pkfs_f32(int d, long N, int Lc, int W, const float* P0, cons
                              const float* h, float R, const float* ys, float* fms, float* fPs,
                              float* sms, float* sPs, double* ll) {
     return dispatch<float>(d, N, Lc, W, P0, Fs, Qs, h, R, ys, fms, fPs, sms, sPs, ll);
+}
+
+// ---------------------------------------------------------------------------------------------
+// log-likelihood gradient on dual numbers (pgps_dual.h), chunked exactly as k_grad_reduce /
+// k_grad_apply do it: chunk aggregates, a serial fold standing in for the block scan, carry-in,
+// lane-serial Kalman pass with the dual log-likelihood accumulator.
+// model: (1 + np) blocks of [lam | N1 (d*d) | Pinf (d*d) | H (d) | R]
+// ---------------------------------------------------------------------------------------------
+template <int D>
+static int run_grad(long N, int Lc, int np, const double* model, const double* ts, double t0, const double* ys,
+                    double* out) {
+    constexpr int NP = 3, MAT = D * D, SYM = Dim<D>::SYM;
+    using T = Dual<NP>;
+    const int stride = 1 + 2 * MAT + D + 1;
+    auto get = [&](int off) {
+        T x(model[off]);
+        for (int p = 0; p < np; ++p) x.d[p] = model[(p + 1) * stride + off];
+        return x;
+    };
+    T lam = get(0), N1[MAT], Pinf[MAT], h[D], R = get(1 + 2 * MAT + D), P0[SYM];
+    for (int i = 0; i < MAT; ++i) { N1[i] = get(1 + i); Pinf[i] = get(1 + MAT + i); }
+    for (int i = 0; i < D; ++i) h[i] = get(1 + 2 * MAT + i);
+    for (int i = 0; i < D; ++i)
+        for (int j = i; j < D; ++j) P0[symi<D>(i, j)] = T(0.5) * (Pinf[i * D + j] + Pinf[j * D + i]);
+    const long nth = (N + Lc - 1) / Lc;
+    std::vector<FiltElem<T, D>> agg(nth);
+    for (long t = 0; t < nth; ++t) {
+        filt_identity(agg[t]);
+        for (long k = t * Lc; k < std::min<long>(N, (t + 1) * Lc); ++k) {
+            if (k == 0) {
+                filt_first(agg[t], P0, T(ys[0]), h, R);
+            } else {
+                T F[MAT], Q[SYM];
+                lti_step_dual<NP, D>(lam, N1, Pinf, ts[k] - ts[k - 1], F, Q);
+                filt_extend(agg[t], F, Q, T(ys[k]), h, R);
+            }
+        }
+    }
+    FiltElem<T, D> pre;
+    filt_identity(pre);
+    T total(0.0);
+    for (long t = 0; t < nth; ++t) {
+        MeanCov<T, D> s;
+        for (int i = 0; i < D; ++i) s.m[i] = T(0.0);
+        for (int i = 0; i < SYM; ++i) s.P[i] = P0[i];
+        filt_apply(s, pre);
+        LogLikDual<NP> ll;
+        for (long k = t * Lc; k < std::min<long>(N, (t + 1) * Lc); ++k) {
+            T F[MAT], Q[SYM], mp[D], Pp[SYM], FP[MAT];
+            lti_step_dual<NP, D>(lam, N1, Pinf, ts[k] - (k ? ts[k - 1] : t0), F, Q);
+            kf_step(s, F, Q, T(ys[k]), h, R, k == 0, ll, mp, Pp, FP);
+        }
+        total += ll.value();
+        FiltElem<T, D> nxt;
+        filt_combine(pre, agg[t], nxt);
+        pre = nxt;
+    }
+    out[0] = total.v;
+    for (int p = 0; p < np; ++p) out[1 + p] = total.d[p];
+    return 0;
+}
+
+extern "C" int emul_ll_grad(int d, long N, int Lc, int np, const double* model, const double* ts, double t0,
+                            const double* ys, double* out) {
+    if (np < 1 || np > 3) return -1;
+    if (d == 1) return run_grad<1>(N, Lc, np, model, ts, t0, ys, out);
+    if (d == 2) return run_grad<2>(N, Lc, np, model, ts, t0, ys, out);
+    return -1;
 }

@@ -23,7 +23,8 @@ def emul():
     so = os.path.join(BUILD, "libemul.so")
     src = os.path.join(ROOT, "tests", "cpu_math", "emul.cpp")
     hdr = os.path.join(ROOT, "parallel-gps_amd", "csrc", "pgps_math.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdr2 = os.path.join(ROOT, "parallel-gps_amd", "csrc", "pgps_dual.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in (src, hdr, hdr2)):
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.dirname(hdr), src, "-o", so],
                        check=True)
     return ctypes.CDLL(so)
@@ -85,3 +86,90 @@ def test_tiny_series(emul, n):
     sms, sPs = O.kfs(ssm, y)
     e = run_emul(emul, ssm, y, 2, 4, np.float64)
     assert relerr(e[0], fms) < 1e-12 and relerr(e[2], sms) < 1e-12 and abs(e[4] - ll) < 1e-12 * abs(ll)
+
+
+# ----------------------------------------------------------------------------------------------
+# log-likelihood gradient on dual numbers (pgps_dual.h; the algebra of k_grad_reduce / k_grad_apply)
+# ----------------------------------------------------------------------------------------------
+def fd_grad(fun, x, rel=1e-5):
+    """4th-order central differences of a scalar function of a parameter vector."""
+    g = np.zeros(len(x))
+    for i in range(len(x)):
+        def at(h):
+            z = np.array(x, float)
+            z[i] += h
+            return fun(z)
+        h = rel * max(abs(x[i]), 1e-2)
+        g[i] = (8.0 * (at(h) - at(-h)) - (at(2 * h) - at(-2 * h))) / (12.0 * h)
+    return g
+
+
+def grad_case(kname, n, seed, nan_frac=0.0):
+    from pssgp.kernels import Matern12, Matern32
+    cls, spec_name = (Matern12, "matern12") if kname == "m12" else (Matern32, "matern32")
+    rng = np.random.RandomState(seed)
+    t = np.sort(rng.rand(n)) * (n / 100.0)
+    y = np.sin(2.0 * t) + 0.4 * rng.randn(n)
+    if nan_frac:
+        y[rng.rand(n) < nan_frac] = np.nan
+    return cls, spec_name, t, y
+
+
+@pytest.mark.parametrize("kname", ["m12", "m32"])
+@pytest.mark.parametrize("Lc", [1, 7, 16])
+def test_dual_loglik_gradient_vs_dense_gp(emul, kname, Lc):
+    """d ll / d (variance, lengthscale, noise) from ONE dual-number pass of the chunked filter ==
+    finite differences of the dense GP marginal likelihood (the reference checks its autodiff
+    gradient the same way, tests/test_gp_vs_kfs.py:53-78, at 1e-2; here 1e-6)."""
+    from pssgp import _backend
+    from pssgp.model import StateSpaceGP
+    cls, spec_name, t, y = grad_case(kname, 150, 3)
+    theta = np.array([1.3, 0.7, 0.2])
+    m = StateSpaceGP((t[:, None], y[:, None]), cls(theta[0], theta[1]), noise_variance=theta[2], parallel=True)
+    model, d, npar = _backend.pack_grad_model(m._grad_blocks())
+    out = np.zeros(1 + npar)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = emul.emul_ll_grad(ctypes.c_int(d), ctypes.c_long(t.size), ctypes.c_int(Lc), ctypes.c_int(npar), p(model),
+                           p(np.ascontiguousarray(t)), ctypes.c_double(0.0), p(np.ascontiguousarray(y)), p(out))
+    assert rc == 0
+    dense = lambda th: O.dense_gp((spec_name, th[0], th[1]), t, y, th[2])
+    assert abs(out[0] - dense(theta)) < 1e-8 * abs(dense(theta))
+    g = fd_grad(dense, theta)
+    assert relerr(out[1:], g) < 1e-6, (out[1:], g)
+
+
+def test_dual_loglik_gradient_with_missing(emul):
+    """Missing observations (NaN) contribute nothing to ll or to its gradient: against finite
+    differences of the oracle's sequential filter on a longer series."""
+    from pssgp import _backend
+    from pssgp.model import StateSpaceGP
+    cls, _, t, y = grad_case("m32", 3000, 5, nan_frac=0.2)
+    theta = np.array([0.8, 1.1, 0.3])
+    m = StateSpaceGP((t[:, None], y[:, None]), cls(theta[0], theta[1]), noise_variance=theta[2], parallel=True)
+    model, d, npar = _backend.pack_grad_model(m._grad_blocks())
+    out = np.zeros(1 + npar)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert emul.emul_ll_grad(ctypes.c_int(d), ctypes.c_long(t.size), ctypes.c_int(16), ctypes.c_int(npar), p(model),
+                             p(np.ascontiguousarray(t)), ctypes.c_double(0.0), p(np.ascontiguousarray(y)), p(out)) == 0
+    seq = lambda th: float(O.ssgp_log_likelihood(cls(th[0], th[1]).get_sde(), t, y, th[2], parallel=False))
+    assert abs(out[0] - seq(theta)) < 1e-9 * abs(seq(theta))
+    assert relerr(out[1:], fd_grad(seq, theta)) < 1e-6
+
+
+def test_grad_model_blocks_are_exact():
+    """The host-side model derivatives (Richardson central differences of get_sde()) against the
+    closed forms for Matern-3/2: lam = sqrt(3)/l, N = [[lam, 1], [-lam^2, -lam]], Pinf = s2 diag(1, lam^2)."""
+    from pssgp.kernels import Matern32
+    from pssgp.model import StateSpaceGP
+    s2, l, r = 1.7, 0.6, 0.25
+    m = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), Matern32(s2, l), noise_variance=r, parallel=True)
+    base, d_s2, d_l, d_r = m._grad_blocks()
+    lam = np.sqrt(3.0) / l
+    dlam = -lam / l
+    assert abs(base[0] - lam) < 1e-14
+    assert np.allclose(d_s2[2], np.diag([1.0, lam ** 2]), rtol=1e-9, atol=1e-9) and abs(d_s2[0]) < 1e-9
+    assert abs(d_l[0] - dlam) < 1e-8 * abs(dlam)
+    assert np.allclose(d_l[1], np.array([[dlam, 0.0], [-2 * lam * dlam, -dlam]]), rtol=1e-8, atol=1e-8)
+    assert np.allclose(d_l[2], np.diag([0.0, 2 * lam * dlam * s2]), rtol=1e-8, atol=1e-8)
+    assert abs(d_r[4] - 1.0) < 1e-9 and np.allclose(d_r[2], 0.0, atol=1e-9)
+    assert m.kernel.lengthscales == l and m.kernel.variance == s2 and m.noise_variance == r

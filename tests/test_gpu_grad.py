@@ -1,0 +1,89 @@
+"""GPU tests of the log-likelihood gradient (pgps_gp_ll_grad_f64: forward-mode dual numbers carried
+through the parallel filter) -- the replacement for TensorFlow autodiff through the scan that the
+reference checks in tests/test_gp_vs_kfs.py:53-78 (there at 1e-2 against the dense GP's gradient)."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from oracle import c_oracle as C
+from tests.conftest import relerr
+from tests.test_cpu_math import fd_grad, grad_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cls, theta, t, y):
+    from pssgp.model import StateSpaceGP
+    return StateSpaceGP((t[:, None], y[:, None]), cls(theta[0], theta[1]), noise_variance=theta[2], parallel=True)
+
+
+@pytest.mark.parametrize("kname", ["m12", "m32"])
+def test_gradient_equals_dense_gp_gradient(kname):
+    cls, spec_name, t, y = grad_case(kname, 200, 11)
+    theta = np.array([1.3, 0.7, 0.2])
+    ll, g = _model(cls, theta, t, y).log_likelihood_and_grad()
+    dense = lambda th: O.dense_gp((spec_name, th[0], th[1]), t, y, th[2])
+    assert abs(ll - dense(theta)) < 1e-8 * abs(dense(theta))
+    assert relerr(g, fd_grad(dense, theta)) < 1e-6
+
+
+@pytest.mark.parametrize("kname,n", [("m12", 70001), ("m32", 100000)])
+def test_gradient_long_series_with_missing(kname, n):
+    """Many blocks (spine fold + block scans on duals) and missing observations: against 4th-order
+    finite differences of the C sequential oracle's log-likelihood, and the value against the
+    ordinary fused log-likelihood path."""
+    from pssgp import _backend as B
+    cls, _, t, y = grad_case(kname, n, 17, nan_frac=0.15)
+    theta = np.array([0.9, 0.8, 0.3])
+    m = _model(cls, theta, t, y)
+    ll, g = m.log_likelihood_and_grad()
+
+    def seq(th):
+        sde = cls(th[0], th[1]).get_sde()
+        Fs, Qs = B.discretise(sde.F, sde.P0, t, 0.0)
+        return C.kfs((sde.P0, Fs, Qs, np.asarray(sde.H).reshape(1, -1), np.array([[th[2]]])), y)[4]
+
+    assert abs(ll - seq(theta)) < 1e-9 * abs(seq(theta))
+    assert abs(ll - float(m.maximum_log_likelihood_objective())) < 1e-10 * abs(ll)
+    assert relerr(g, fd_grad(seq, theta, rel=1e-4)) < 1e-5
+
+
+def test_gradient_chunk_geometry_invariance():
+    """The same gradient (to rounding) whatever the steps-per-lane geometry, i.e. whichever way the
+    scan brackets the dual elements."""
+    from pssgp import _backend as B
+    cls, _, t, y = grad_case("m32", 30011, 23, nan_frac=0.05)
+    m = _model(cls, np.array([1.1, 0.5, 0.15]), t, y)
+    ctx = B.get_context()
+    res = []
+    try:
+        for lc in (1, 4, 16, 64):
+            ctx.set_chunk(lc)
+            res.append(np.concatenate([[m.log_likelihood_and_grad()[0]], m.log_likelihood_and_grad()[1]]))
+    finally:
+        ctx.set_chunk(0)
+    for r in res[1:]:
+        assert relerr(r, res[0]) < 1e-10
+
+
+def test_gradient_descends():
+    """A few steps of gradient ascent on ll from a poor start increase ll monotonically (the use
+    the reference's L-BFGS / HMC drivers make of the gradient)."""
+    cls, _, t, y = grad_case("m32", 20000, 29)
+    theta = np.log(np.array([3.0, 3.0, 1.0]))
+    lls = []
+    for _ in range(6):
+        ll, g = _model(cls, np.exp(theta), t, y).log_likelihood_and_grad()
+        lls.append(ll)
+        step = g * np.exp(theta)                       # chain rule to log-parameters
+        theta = theta + 0.3 * step / max(1.0, np.linalg.norm(step))
+    assert all(b > a for a, b in zip(lls, lls[1:])), lls
+
+
+def test_gradient_rejects_unsupported():
+    from pssgp.kernels import Matern52
+    from pssgp._backend import PgpsError
+    t = np.linspace(0.0, 1.0, 50)
+    m = _model(Matern52, np.array([1.0, 1.0, 0.1]), t, np.sin(t))
+    with pytest.raises(PgpsError):
+        m.log_likelihood_and_grad()

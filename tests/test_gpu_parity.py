@@ -132,6 +132,7 @@ def test_single_pass_filter_lookback(window, dtype, kname):
         again = _gpu_all(ssm, y, dtype)
         for name in got:
             assert np.array_equal(got[name], again[name]), name      # timing-independent combine order
+        assert ctx.status() == 0                                    # no look-back spin gave up
         ctx.set_single_pass(0, 0)
         ref = _gpu_all(ssm, y, dtype)
         tol = 1e-12 if dtype == np.float64 else 1e-4
