@@ -348,6 +348,29 @@ def main():
             ms = e0.elapsed_time(e1) / min(args.steps, 100)
             fused[name] = {"ms_per_step": ms, "timesteps_per_s": n_local / ms * 1e3,
                            "log_likelihood": float(ll_d[0].item())}
+        if d <= 2 and dtype_np == np.float64:
+            from pssgp.model import StateSpaceGP
+            gm = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), kern, noise_variance=noise, parallel=True)
+            gmodel, _, npar = _backend.pack_grad_model(gm._grad_blocks())
+            g_d = torch.zeros((8,), dtype=torch.float64, device=dev)
+
+            def grad_step():
+                ctx.call("pgps_gp_ll_grad_dev_f64", ctypes.c_long(n_local), ctypes.c_int(d), ctypes.c_int(npar),
+                         HP(gmodel), P(ts_d), ctypes.c_double(t_prev), P(ys_d), P(g_d))
+
+            for _ in range(5):
+                grad_step()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(min(args.steps, 50)):
+                grad_step()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / min(args.steps, 50)
+            fused["log-lik + gradient (3 hyper-parameters, forward-mode duals)"] = {
+                "ms_per_step": ms, "timesteps_per_s": n_local / ms * 1e3,
+                "log_likelihood": float(g_d[0].item()), "gradient": [float(v) for v in g_d[1:1 + npar].tolist()]}
         fused["note"] = ("pgps_gp_dev: discretisation fused into the scan kernels, inputs are (ts, ys) only; "
                          "GPU-event time, not part of `value`")
         out["fused_path"] = fused

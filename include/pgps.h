@@ -178,13 +178,14 @@ int pgps_gp_f32(pgps_ctx*, long N, int d, double lam, const double* N1, const do
                 const double* H, double R, const float* ts, double t0, const float* ys, float* fms, float* fPs,
                 float* sms, float* sPs, double* ll);
 
-/* ---- log-likelihood and its gradient (fused path, d <= 2, fp64) --------------------------------
+/* ---- log-likelihood and its gradient (fused path, d <= 3, fp64) --------------------------------
  * What the reference gets from TensorFlow autodiff through the scan (tests/test_gp_vs_kfs.py:53-78;
  * SURVEY.md section 8f, rank 1): forward-mode dual numbers carried through every filtering element and
  * every application of the associative operator.  `model` (HOST memory) holds 1 + np blocks of
  * [lam | N1 (d*d) | Pinf (d*d) | H (d) | R]: block 0 the values, block p the partial derivatives with
  * respect to hyper-parameter p (np <= 3).  out[0] = log-likelihood, out[1..np] = its gradient.
- * ts, ys, out: host pointers for pgps_gp_ll_grad_f64, device pointers for the _dev form. */
+ * ts, ys, out: host pointers for pgps_gp_ll_grad_f64, device pointers for the _dev form, whose `out`
+ * must hold 1 + 3 np doubles (the tail is scratch for the d = 3 one-direction-per-pass schedule). */
 int pgps_gp_ll_grad_f64(pgps_ctx*, long N, int d, int np, const double* model, const double* ts, double t0,
                         const double* ys, double* out);
 int pgps_gp_ll_grad_dev_f64(pgps_ctx*, long N, int d, int np, const double* model, const double* ts, double t0,

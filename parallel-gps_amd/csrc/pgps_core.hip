@@ -731,7 +731,7 @@ extern "C" int pgps_gp_ll_grad_f64(pgps_ctx* ctx, long N, int d, int np, const d
     double *dts, *dys, *dout;
     TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
     TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));
-    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, 8, &dout));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, 16, &dout));
     TRY(launch_grad(ctx, N, d, np, model, dts, t0, dys, dout));
     TRY(stage_out(ctx, out, dout, (size_t)(1 + np)));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

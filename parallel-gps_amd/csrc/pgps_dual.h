@@ -115,11 +115,11 @@ struct LogLikDual {
     }
 };
 
-// F(dt) = exp(-lam dt) (I + dt N)  and  Q(dt) = Pinf - F Pinf F^T  on duals (d <= 2: N^2 = 0), the
+// F(dt) = exp(-lam dt) (I + dt N + dt^2 N^2/2)  and  Q(dt) = Pinf - F Pinf F^T  on duals (d <= 3), the
 // closed-form discretisation of pgps_fused.hip.h with derivatives carried along.
 template <int NP, int D>
-PGPS_HD void lti_step_dual(const Dual<NP>& lam, const Dual<NP>* N1, const Dual<NP>* Pinf, double dt, Dual<NP>* F,
-                           Dual<NP>* Q /*sym*/) {
+PGPS_HD void lti_step_dual(const Dual<NP>& lam, const Dual<NP>* N1, const Dual<NP>* N2, const Dual<NP>* Pinf, double dt,
+                           Dual<NP>* F, Dual<NP>* Q /*sym*/) {
     using T = Dual<NP>;
     constexpr int MAT = D * D;
     const T e = exp(-(lam * T(dt)));
@@ -130,6 +130,7 @@ PGPS_HD void lti_step_dual(const Dual<NP>& lam, const Dual<NP>* N1, const Dual<N
         for (int j = 0; j < D; ++j) {
             T v = T(i == j ? 1.0 : 0.0);
             if (D >= 2) v += T(dt) * N1[i * D + j];
+            if (D >= 3) v += T(dt * dt) * N2[i * D + j];
             F[i * D + j] = e * v;
         }
     mat_mul<T, D>(F, Pinf, X);

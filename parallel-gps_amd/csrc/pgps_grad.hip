@@ -3,11 +3,11 @@
 
 namespace pgps {
 
-constexpr int kNP = 3;          // hyper-parameters differentiated at once (variance, lengthscale, noise)
+constexpr int kNP = 3;          // hyper-parameters differentiated per pass for d <= 2 (d = 3: one per pass)
 
-template <int D>
-static int launch_grad_d(pgps_ctx* ctx, GradModel<kNP> m) {
-    using T = Dual<kNP>;
+template <int NP, int D>
+static int launch_grad_d(pgps_ctx* ctx, GradModel<NP> m) {
+    using T = Dual<NP>;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     geometry(ctx, m.N, &m.Lc, &m.nblocks);
     m.nlanes = (long)m.nblocks * kBlock;
@@ -24,34 +24,59 @@ static int launch_grad_d(pgps_ctx* ctx, GradModel<kNP> m) {
     m.lpre = (T*)(base + o_lpre);
     m.llpart = (T*)(base + o_ll);
     const dim3 grid(m.nblocks), block(kBlock);
-    timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_grad_reduce<kNP, D>, grid, block, 0, m);
-    timed_launch(ctx, PGPS_K_FILTER_APPLY, k_grad_apply<kNP, D>, grid, block, 0, m);
-    timed_launch(ctx, PGPS_K_LL_FINALIZE, k_grad_finalize<kNP>, dim3(1), block, 0, (const T*)m.llpart, m.nblocks, m.out);
+    timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_grad_reduce<NP, D>, grid, block, 0, m);
+    timed_launch(ctx, PGPS_K_FILTER_APPLY, k_grad_apply<NP, D>, grid, block, 0, m);
+    timed_launch(ctx, PGPS_K_LL_FINALIZE, k_grad_finalize<NP>, dim3(1), block, 0, (const T*)m.llpart, m.nblocks, m.out);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }
 
-// model: (1 + kNP) consecutive blocks, block 0 = values, block p = d/dtheta_p, each
-//   [lam | N1 (d*d) | Pinf (d*d) | H (d) | R]
-int launch_grad(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts, double t0,
-                const double* ys, double* out_dev) {
-    if (np < 1 || np > kNP) return PGPS_E_INVALID;
-    if (d < 1 || d > 2) return PGPS_E_UNSUPPORTED_DIM;
-    GradModel<kNP> m{};
+// model blocks -> duals with derivative directions [p0, p0 + NP)
+template <int NP>
+static GradModel<NP> make_model(int d, int np, int p0, const double* model, long N, const double* ts, double t0,
+                                const double* ys, double* out) {
+    using T = Dual<NP>;
+    GradModel<NP> m{};
     const int stride = 1 + 2 * d * d + d + 1;
     auto get = [&](int off) {
-        Dual<kNP> x(model[off]);
-        for (int p = 0; p < np; ++p) x.d[p] = model[(p + 1) * stride + off];
+        T x(model[off]);
+        for (int p = 0; p < NP && p0 + p < np; ++p) x.d[p] = model[(p0 + p + 1) * stride + off];
         return x;
     };
+    for (int i = 0; i < 9; ++i) { m.N1[i] = T(0.0); m.N2[i] = T(0.0); m.Pinf[i] = T(0.0); }
+    for (int i = 0; i < 3; ++i) m.H[i] = T(0.0);
     m.lam = get(0);
-    for (int i = 0; i < 4; ++i) { m.N1[i] = Dual<kNP>(0.0); m.Pinf[i] = Dual<kNP>(0.0); }
-    for (int i = 0; i < 2; ++i) m.H[i] = Dual<kNP>(0.0);
     for (int i = 0; i < d * d; ++i) { m.N1[i] = get(1 + i); m.Pinf[i] = get(1 + d * d + i); }
     for (int i = 0; i < d; ++i) m.H[i] = get(1 + 2 * d * d + i);
     m.R = get(1 + 2 * d * d + d);
-    m.ts = ts; m.ys = ys; m.t_prev = t0; m.N = N; m.out = out_dev;
-    return d == 1 ? launch_grad_d<1>(ctx, m) : launch_grad_d<2>(ctx, m);
+    for (int i = 0; i < d; ++i)                 // N2 = N1 N1 / 2 (product rule through the dual arithmetic)
+        for (int j = 0; j < d; ++j) {
+            T acc(0.0);
+            for (int l = 0; l < d; ++l) acc += m.N1[i * d + l] * m.N1[l * d + j];
+            m.N2[i * d + j] = T(0.5) * acc;
+        }
+    m.ts = ts; m.ys = ys; m.t_prev = t0; m.N = N; m.out = out;
+    return m;
+}
+
+// model: (1 + np) consecutive blocks, block 0 = values, block p = d/dtheta_p, each
+//   [lam | N1 (d*d) | Pinf (d*d) | H (d) | R]
+// out_dev: 1 + np doubles (d <= 2) -- for d = 3, 2 * np doubles of scratch follow: pass p writes
+// (ll, d ll / d theta_p) at out_dev[2 p] and a last tiny kernel compacts them.
+int launch_grad(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts, double t0,
+                const double* ys, double* out_dev) {
+    if (np < 1 || np > kNP) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    if (d == 1) return launch_grad_d<kNP, 1>(ctx, make_model<kNP>(d, np, 0, model, N, ts, t0, ys, out_dev));
+    if (d == 2) return launch_grad_d<kNP, 2>(ctx, make_model<kNP>(d, np, 0, model, N, ts, t0, ys, out_dev));
+    double* scratch = out_dev + 1 + np;
+    for (int p = 0; p < np; ++p) {
+        int rc = launch_grad_d<1, 3>(ctx, make_model<1>(d, np, p, model, N, ts, t0, ys, scratch + 2 * p));
+        if (rc) return rc;
+    }
+    k_grad_compact<<<1, 64, 0, ctx->stream>>>(scratch, np, out_dev);
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
 }
 
 }  // namespace pgps

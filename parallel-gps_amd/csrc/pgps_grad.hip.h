@@ -34,9 +34,10 @@ __device__ __forceinline__ Dual<NP> wshfl_down(const Dual<NP>& x, int s) {
 template <int NP>
 struct GradModel {              // everything a dual: [value | d/dtheta_1 .. d/dtheta_NP]
     Dual<NP> lam;
-    Dual<NP> N1[4];             // d <= 2
-    Dual<NP> Pinf[4];
-    Dual<NP> H[2];
+    Dual<NP> N1[9];             // row-major d x d in the leading d*d entries
+    Dual<NP> N2[9];             // N^2 / 2 (d = 3 only)
+    Dual<NP> Pinf[9];
+    Dual<NP> H[3];
     Dual<NP> R;
     const double* ts;
     const double* ys;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_grad_reduce(const GradModel<NP> m) {
                 filt_first(agg, P0, T(y), h, m.R);
             } else {
                 T F[MAT], Q[SYM];
-                lti_step_dual<NP, D>(m.lam, m.N1, m.Pinf, t - tprev, F, Q);
+                lti_step_dual<NP, D>(m.lam, m.N1, m.N2, m.Pinf, t - tprev, F, Q);
                 filt_extend(agg, F, Q, T(y), h, m.R);
             }
             tprev = t;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void k_grad_apply(const GradModel<NP> m) {
             const double t = tn, y = yn;
             if (k + 1 < k1) { tn = m.ts[k + 1]; yn = m.ys[k + 1]; }
             T F[MAT], Q[SYM], mp[D], Pp[SYM], FP[MAT];
-            lti_step_dual<NP, D>(m.lam, m.N1, m.Pinf, t - tprev, F, Q);
+            lti_step_dual<NP, D>(m.lam, m.N1, m.N2, m.Pinf, t - tprev, F, Q);
             tprev = t;
             kf_step(s, F, Q, T(y), h, m.R, k == 0, ll, mp, Pp, FP);
         }
@@ -151,6 +152,13 @@ __global__ __launch_bounds__(kBlock) void k_grad_finalize(const Dual<NP>* llpart
         const double t = block_sum_double(v, lds_ll);
         if (threadIdx.x == 0) out[c] = t;
     }
+}
+
+// d = 3: np single-direction passes left (ll, d ll / d theta_p) pairs; gather them as [ll, grad...]
+static __global__ void k_grad_compact(const double* pairs, int np, double* out) {
+    const int i = threadIdx.x;
+    if (i == 0) out[0] = pairs[0];
+    if (i >= 1 && i <= np) out[i] = pairs[2 * (i - 1) + 1];
 }
 
 }  // namespace pgps

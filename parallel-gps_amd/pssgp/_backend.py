@@ -391,7 +391,7 @@ def pack_grad_model(blocks):
 
 
 def gp_ll_grad(blocks, ts, ys, t0=0.0, device=0):
-    """Log-likelihood and its gradient on the fused path (pgps_gp_ll_grad_f64, fp64, d <= 2).
+    """Log-likelihood and its gradient on the fused path (pgps_gp_ll_grad_f64, fp64, d <= 3).
 
     `blocks`: list of 1 + np tuples (lam, N1, Pinf, H, R) -- the model, then its partial derivative
     with respect to each hyper-parameter.  Returns (ll, grad[np])."""

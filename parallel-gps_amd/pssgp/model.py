@@ -174,7 +174,7 @@ class StateSpaceGP:
         """(ll, grad): the marginal log-likelihood and its gradient with respect to
         `trainable_parameters()`, in ONE pass of the parallel filter on dual numbers -- what the
         reference obtains from tf.GradientTape over maximum_log_likelihood_objective
-        (tests/test_gp_vs_kfs.py:53-78).  parallel=True, Matern-1/2 and Matern-3/2 (d <= 2), fp64."""
+        (tests/test_gp_vs_kfs.py:53-78).  parallel=True, the Matern family (d <= 3), fp64."""
         if not self.parallel:
             raise NotImplementedError("gradients run on the parallel (HIP) path: construct with parallel=True")
         from . import _backend

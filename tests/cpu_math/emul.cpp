@@ -191,9 +191,15 @@ static int run_grad(long N, int Lc, int np, const double* model, const double* t
         for (int p = 0; p < np; ++p) x.d[p] = model[(p + 1) * stride + off];
         return x;
     };
-    T lam = get(0), N1[MAT], Pinf[MAT], h[D], R = get(1 + 2 * MAT + D), P0[SYM];
+    T lam = get(0), N1[MAT], N2[MAT], Pinf[MAT], h[D], R = get(1 + 2 * MAT + D), P0[SYM];
     for (int i = 0; i < MAT; ++i) { N1[i] = get(1 + i); Pinf[i] = get(1 + MAT + i); }
     for (int i = 0; i < D; ++i) h[i] = get(1 + 2 * MAT + i);
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+            T acc(0.0);
+            for (int l = 0; l < D; ++l) acc += N1[i * D + l] * N1[l * D + j];
+            N2[i * D + j] = T(0.5) * acc;
+        }
     for (int i = 0; i < D; ++i)
         for (int j = i; j < D; ++j) P0[symi<D>(i, j)] = T(0.5) * (Pinf[i * D + j] + Pinf[j * D + i]);
     const long nth = (N + Lc - 1) / Lc;
@@ -205,7 +211,7 @@ static int run_grad(long N, int Lc, int np, const double* model, const double* t
                 filt_first(agg[t], P0, T(ys[0]), h, R);
             } else {
                 T F[MAT], Q[SYM];
-                lti_step_dual<NP, D>(lam, N1, Pinf, ts[k] - ts[k - 1], F, Q);
+                lti_step_dual<NP, D>(lam, N1, N2, Pinf, ts[k] - ts[k - 1], F, Q);
                 filt_extend(agg[t], F, Q, T(ys[k]), h, R);
             }
         }
@@ -221,7 +227,7 @@ static int run_grad(long N, int Lc, int np, const double* model, const double* t
         LogLikDual<NP> ll;
         for (long k = t * Lc; k < std::min<long>(N, (t + 1) * Lc); ++k) {
             T F[MAT], Q[SYM], mp[D], Pp[SYM], FP[MAT];
-            lti_step_dual<NP, D>(lam, N1, Pinf, ts[k] - (k ? ts[k - 1] : t0), F, Q);
+            lti_step_dual<NP, D>(lam, N1, N2, Pinf, ts[k] - (k ? ts[k - 1] : t0), F, Q);
             kf_step(s, F, Q, T(ys[k]), h, R, k == 0, ll, mp, Pp, FP);
         }
         total += ll.value();
@@ -239,5 +245,6 @@ extern "C" int emul_ll_grad(int d, long N, int Lc, int np, const double* model, 
     if (np < 1 || np > 3) return -1;
     if (d == 1) return run_grad<1>(N, Lc, np, model, ts, t0, ys, out);
     if (d == 2) return run_grad<2>(N, Lc, np, model, ts, t0, ys, out);
+    if (d == 3) return run_grad<3>(N, Lc, np, model, ts, t0, ys, out);
     return -1;
 }

@@ -105,8 +105,8 @@ def fd_grad(fun, x, rel=1e-5):
 
 
 def grad_case(kname, n, seed, nan_frac=0.0):
-    from pssgp.kernels import Matern12, Matern32
-    cls, spec_name = (Matern12, "matern12") if kname == "m12" else (Matern32, "matern32")
+    from pssgp.kernels import Matern12, Matern32, Matern52
+    cls, spec_name = {"m12": (Matern12, "matern12"), "m32": (Matern32, "matern32"), "m52": (Matern52, "matern52")}[kname]
     rng = np.random.RandomState(seed)
     t = np.sort(rng.rand(n)) * (n / 100.0)
     y = np.sin(2.0 * t) + 0.4 * rng.randn(n)
@@ -115,7 +115,7 @@ def grad_case(kname, n, seed, nan_frac=0.0):
     return cls, spec_name, t, y
 
 
-@pytest.mark.parametrize("kname", ["m12", "m32"])
+@pytest.mark.parametrize("kname", ["m12", "m32", "m52"])
 @pytest.mark.parametrize("Lc", [1, 7, 16])
 def test_dual_loglik_gradient_vs_dense_gp(emul, kname, Lc):
     """d ll / d (variance, lengthscale, noise) from ONE dual-number pass of the chunked filter ==
