@@ -178,6 +178,27 @@ int pgps_gp_f32(pgps_ctx*, long N, int d, double lam, const double* N1, const do
                 const double* H, double R, const float* ts, double t0, const float* ys, float* fms, float* fPs,
                 float* sms, float* sPs, double* ll);
 
+/* ---- predict_f on the device (fused path, d <= 3) --------------------------------------------------
+ * StateSpaceGP.predict_f (pssgp/model.py:92-111) in one call: the sorted training times `ts` (N) and
+ * sorted query times `tq` (K) are merged on the device exactly as _merge_sorted does (model.py:15-55:
+ * on equal times the shorter array's point comes first), query rows carry missing observations, the
+ * fused filter + smoother runs over the N + K steps and only  mean[j] = H sm,  var[j] = H sP H^T  of
+ * query j are written -- 2 scalars per query instead of (d^2 + d) per merged step.  ll (nullable)
+ * receives the log-likelihood of the training series (query rows contribute nothing).
+ * Host pointers; the _dev form takes device pointers for ts, ys, tq, mean, var, ll.  N + K < 2^31. */
+int pgps_gp_predict_f64(pgps_ctx*, long N, long K, int d, double lam, const double* N1, const double* N2,
+                        const double* Pinf, const double* H, double R, const double* ts, const double* ys, double t0,
+                        const double* tq, double* mean, double* var, double* ll);
+int pgps_gp_predict_f32(pgps_ctx*, long N, long K, int d, double lam, const double* N1, const double* N2,
+                        const double* Pinf, const double* H, double R, const float* ts, const float* ys, double t0,
+                        const float* tq, float* mean, float* var, double* ll);
+int pgps_gp_predict_dev_f64(pgps_ctx*, long N, long K, int d, double lam, const double* N1, const double* N2,
+                            const double* Pinf, const double* H, double R, const double* ts, const double* ys,
+                            double t0, const double* tq, double* mean, double* var, double* ll);
+int pgps_gp_predict_dev_f32(pgps_ctx*, long N, long K, int d, double lam, const double* N1, const double* N2,
+                            const double* Pinf, const double* H, double R, const float* ts, const float* ys,
+                            double t0, const float* tq, float* mean, float* var, double* ll);
+
 /* ---- log-likelihood and its gradient (fused path, d <= 3, fp64) --------------------------------
  * What the reference gets from TensorFlow autodiff through the scan (tests/test_gp_vs_kfs.py:53-78;
  * SURVEY.md section 8f, rank 1): forward-mode dual numbers carried through every filtering element and

@@ -716,6 +716,141 @@ PGPS_DEFINE_GP(f64, double)
 PGPS_DEFINE_GP(f32, float)
 
 // ---------------------------------------------------------------------------------------------
+// predict_f on the device: merge of the sorted training / query times, NaN marking of the query rows,
+// fused filter + smoother, projection through H at the query rows only (pssgp/model.py:15-55,92-111)
+// ---------------------------------------------------------------------------------------------
+namespace pgps {
+
+template <typename T>
+__device__ __forceinline__ long count_below(const T* a, long n, T x, bool or_equal) {
+    long lo = 0, hi = n;                    // number of a[i] < x (or <= x)
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        const bool left = or_equal ? (a[mid] <= x) : (a[mid] < x);
+        if (left) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// As _merge_sorted (pssgp/model.py:15-55): the shorter array is scattered into the longer one at
+// arange + searchsorted(longer, shorter, side="left"), so on equal times the shorter array's point
+// comes first; the training series is the "longer" one when N >= K (model.py:25 swaps only if N < K).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_merge_sorted(long N, long K, const T* ts, const T* ys, const T* tq, T* ts_m,
+                                                          T* ys_m, int* qslot) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    const bool query_first = (N >= K);
+    if (i < N) {
+        const T t = ts[i];
+        const long pos = i + count_below(tq, K, t, query_first);
+        ts_m[pos] = t;
+        ys_m[pos] = ys[i];
+        qslot[pos] = -1;
+    } else if (i < N + K) {
+        const long j = i - N;
+        const T t = tq[j];
+        const long pos = j + count_below(ts, N, t, !query_first);
+        ts_m[pos] = t;
+        ys_m[pos] = (T)__builtin_nan("");
+        qslot[pos] = (int)j;
+    }
+}
+
+template <typename T>
+int launch_merge(pgps_ctx* ctx, long N, long K, const T* ts, const T* ys, const T* tq, T* ts_m, T* ys_m, int* qslot) {
+    const long M = N + K;
+    const dim3 grid((unsigned)((M + kBlock - 1) / kBlock)), block(kBlock);
+    k_merge_sorted<T><<<grid, block, 0, ctx->stream>>>(N, K, ts, ys, tq, ts_m, ys_m, qslot);
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+}  // namespace pgps
+
+template <typename T>
+static int gp_predict_dev(pgps_ctx* ctx, long N, long K, int d, double lam, const double* N1, const double* N2,
+                          const double* Pinf, const double* H, double R, const T* ts, const T* ys, double t0,
+                          const T* tq, T* mean, T* var, double* ll) {
+    if (!ctx || N < 1 || K < 1 || !N1 || !Pinf || !H || !ts || !ys || !tq || !mean || !var) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    if (N + K > 0x7fffffffL) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t m = (size_t)(N + K), dd = (size_t)d * d;
+    T *ts_m, *ys_m, *fms, *fPs;
+    int* qslot;
+    double* dll;
+    TRY(stage_in<T>(ctx, ctx->st[0], nullptr, m, &ts_m));
+    TRY(stage_in<T>(ctx, ctx->st[1], nullptr, m, &ys_m));
+    TRY(stage_in<int>(ctx, ctx->st[2], nullptr, m, &qslot));
+    TRY(stage_in<T>(ctx, ctx->st[5], nullptr, m * d, &fms));
+    TRY(stage_in<T>(ctx, ctx->st[6], nullptr, m * dd, &fPs));
+    TRY(stage_in<double>(ctx, ctx->st[11], nullptr, 2, &dll));
+    TRY(launch_merge<T>(ctx, N, K, ts, ys, tq, ts_m, ys_m, qslot));
+    GpArgs<T> g{};
+    g.s.N = (long)m;
+    g.s.R = (T)R;
+    g.s.ys = ys_m;
+    g.s.fms = fms; g.s.fPs = fPs; g.s.sms = nullptr; g.s.sPs = nullptr;
+    g.s.ll = ll ? ll : dll;
+    g.m.lam = lam;
+    for (int i = 0; i < 9; ++i) { g.m.N1[i] = 0; g.m.N2[i] = 0; g.m.Pinf[i] = 0; }
+    for (int i = 0; i < d * d; ++i) { g.m.N1[i] = N1[i]; g.m.N2[i] = N2 ? N2[i] : 0.0; g.m.Pinf[i] = Pinf[i]; }
+    for (int i = 0; i < 3; ++i) g.m.H[i] = i < d ? (T)H[i] : T(0);
+    g.m.ts = ts_m;
+    g.m.t_prev = (T)t0;
+    g.qslot = qslot;
+    g.pmean = mean;
+    g.pvar = var;
+    switch (d) {
+        case 1: return launch_gp<T, 1>(ctx, g, 1, 1);
+        case 2: return launch_gp<T, 2>(ctx, g, 1, 1);
+        default: return launch_gp<T, 3>(ctx, g, 1, 1);
+    }
+}
+
+template <typename T>
+static int gp_predict_host(pgps_ctx* ctx, long N, long K, int d, double lam, const double* N1, const double* N2,
+                           const double* Pinf, const double* H, double R, const T* ts, const T* ys, double t0,
+                           const T* tq, T* mean, T* var, double* ll) {
+    if (!ctx || N < 1 || K < 1 || !ts || !ys || !tq || !mean || !var) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    T *dts, *dys, *dtq, *dmean, *dvar;
+    double* dll;
+    TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
+    TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));
+    TRY(stage_in(ctx, ctx->st[3], tq, (size_t)K, &dtq));
+    TRY(stage_in<T>(ctx, ctx->st[7], nullptr, (size_t)K, &dmean));
+    TRY(stage_in<T>(ctx, ctx->st[8], nullptr, (size_t)K, &dvar));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, 2, &dll));
+    TRY(gp_predict_dev<T>(ctx, N, K, d, lam, N1, N2, Pinf, H, R, dts, dys, t0, dtq, dmean, dvar, dll));
+    TRY(stage_out(ctx, mean, dmean, (size_t)K));
+    TRY(stage_out(ctx, var, dvar, (size_t)K));
+    double llh = 0.0;
+    TRY(stage_out(ctx, &llh, dll, 1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ll) *ll = llh;
+    if (!std::isfinite(llh)) return PGPS_E_NUMERIC;
+    return PGPS_OK;
+}
+
+#define PGPS_DEFINE_PREDICT(SUF, T)                                                                                  \
+    extern "C" int pgps_gp_predict_dev_##SUF(pgps_ctx* c, long N, long K, int d, double lam, const double* N1,       \
+                                             const double* N2, const double* Pinf, const double* H, double R,       \
+                                             const T* ts, const T* ys, double t0, const T* tq, T* mean, T* var,     \
+                                             double* ll) {                                                          \
+        return gp_predict_dev<T>(c, N, K, d, lam, N1, N2, Pinf, H, R, ts, ys, t0, tq, mean, var, ll);                \
+    }                                                                                                                \
+    extern "C" int pgps_gp_predict_##SUF(pgps_ctx* c, long N, long K, int d, double lam, const double* N1,           \
+                                         const double* N2, const double* Pinf, const double* H, double R,           \
+                                         const T* ts, const T* ys, double t0, const T* tq, T* mean, T* var,         \
+                                         double* ll) {                                                              \
+        return gp_predict_host<T>(c, N, K, d, lam, N1, N2, Pinf, H, R, ts, ys, t0, tq, mean, var, ll);               \
+    }
+
+PGPS_DEFINE_PREDICT(f64, double)
+PGPS_DEFINE_PREDICT(f32, float)
+
+// ---------------------------------------------------------------------------------------------
 // log-likelihood and its gradient (fused path, forward-mode duals through the scan)
 // ---------------------------------------------------------------------------------------------
 extern "C" int pgps_gp_ll_grad_dev_f64(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts,

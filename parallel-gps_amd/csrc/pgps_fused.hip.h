@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_gp_apply(const GpArgs<T> g) {
 // ---------------------------------------------------------------------------------------------
 // smoother apply
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, bool NT>
+template <typename T, int D, bool NT, bool PROJ = false>
 __global__ __launch_bounds__(kBlock) void k_gp_smooth(const GpArgs<T> g) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM, NS = Dim<D>::NSMTH, G = 4;
     using SE = SmthElem<T, D>;
@@ -289,6 +289,22 @@ __global__ __launch_bounds__(kBlock) void k_gp_smooth(const GpArgs<T> g) {
             if (!last) lti_step<T, D>(g.m, tnext - t, F, Qf);
             smoother_apply_step<T, D>(F, Qf, mk, Pk, last, s);
             tnext = t;
+            if constexpr (PROJ) {
+                // posterior of f = H x at the query rows only (pssgp/model.py:107-111)
+                const int q = g.qslot[k];
+                if (q >= 0) {
+                    T mu = T(0), var = T(0);
+#pragma unroll
+                    for (int r = 0; r < D; ++r) {
+                        mu += g.m.H[r] * s.m[r];
+#pragma unroll
+                        for (int c = 0; c < D; ++c) var += g.m.H[r] * g.m.H[c] * s.P[symi<D>(r < c ? r : c, r < c ? c : r)];
+                    }
+                    g.pmean[q] = mu;
+                    g.pvar[q] = var;
+                }
+                continue;
+            }
             T Pf[MAT];
             full_from_sym<T, D>(s.P, Pf);
             if (staged) {

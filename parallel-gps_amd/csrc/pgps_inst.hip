@@ -177,7 +177,10 @@ static int launch_gp_nt(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_gp_reduce<T, D>, grid, block, 0, g);
     if (want_smoothed) {
         timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_apply<T, D, true, NT>, grid, block, 0, g);
-        timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_gp_smooth<T, D, NT>, grid, block, 0, g);
+        if (g.qslot)
+            timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_gp_smooth<T, D, false, true>, grid, block, 0, g);
+        else
+            timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_gp_smooth<T, D, NT>, grid, block, 0, g);
     } else {
         (void)want_filtered;
         timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_apply<T, D, false, NT>, grid, block, 0, g);

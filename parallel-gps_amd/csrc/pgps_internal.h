@@ -138,10 +138,19 @@ template <typename T>
 struct GpArgs {
     ScanArgs<T> s;          // N, geometry, ys, R, outputs, scratch (Fs, Qs, P0, H unused)
     GpModel<T> m;
+    // projected-posterior mode of the smoother (pgps_gp_predict_*): step k writes H sm_k and H sP_k H^T
+    // to slot qslot[k] when that is >= 0 and nothing otherwise; sms / sPs are not written
+    const int* qslot;       // (N,) or null                         [device]
+    T* pmean;               // (K,)                                 [device]
+    T* pvar;                // (K,)                                 [device]
 };
 
 template <typename T, int D>
 int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed);
+
+// merge of two sorted time arrays on the device + NaN marking of the query rows (pgps_core.hip)
+template <typename T>
+int launch_merge(pgps_ctx* ctx, long N, long K, const T* ts, const T* ys, const T* tq, T* ts_m, T* ys_m, int* qslot);
 
 // log-likelihood + gradient on the fused path (pgps_grad.hip); all array pointers device
 int launch_grad(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts, double t0,

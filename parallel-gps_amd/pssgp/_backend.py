@@ -376,6 +376,31 @@ def gp(form, Pinf, H, R, ts, ys, t0=0.0, want_filtered=False, want_smoothed=Fals
     return out
 
 
+def gp_predict(form, Pinf, H, R, ts, ys, tq, t0=0.0, device=0):
+    """predict_f on the device (pgps_gp_predict_*): merge of the sorted `ts` (N) and `tq` (K), fused
+    filter + smoother over the N + K steps, posterior mean / variance of f = H x at the K query
+    times.  Returns (mean (K,), var (K,), ll of the training series)."""
+    lam, N1, N2 = form
+    ts_a = np.asarray(ts)
+    dtype = ts_a.dtype if ts_a.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+    suf, _ = _suffix(dtype)
+    ts_a = _prep(ts_a, dtype, (-1,))
+    ys_a = _prep(ys, dtype, (-1,))
+    tq_a = _prep(tq, dtype, (-1,))
+    N, K = ts_a.shape[0], tq_a.shape[0]
+    if ys_a.shape[0] != N:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {N} steps")
+    d = N1.shape[0]
+    mean, var = np.empty(K, dtype), np.empty(K, dtype)
+    ll = c_double(0.0)
+    get_context(device).call(f"pgps_gp_predict_{suf}", c_long(N), c_long(K), c_int(d), c_double(lam),
+                             _ptr(_prep(N1, np.float64)), _ptr(_prep(N2, np.float64)), _ptr(_prep(Pinf, np.float64, (d, d))),
+                             _ptr(_prep(H, np.float64, (d,))), c_double(float(R)), _ptr(ts_a), _ptr(ys_a),
+                             c_double(float(t0)), _ptr(tq_a), _ptr(mean), _ptr(var),
+                             ctypes.cast(ctypes.byref(ll), c_void_p))
+    return mean, var, ll.value
+
+
 def pack_grad_model(blocks):
     """(1 + np, 1 + 2 d^2 + d + 1) array [lam | N1 | Pinf | H | R] per block, as pgps_gp_ll_grad_* reads it."""
     d = np.asarray(blocks[0][1]).shape[0]

@@ -96,11 +96,20 @@ class StateSpaceGP:
         Xnew = np.asarray(Xnew, dtype=dtype)
         squeezed_ts = ts.reshape(-1)
         squeezed_Xnew = Xnew.reshape(-1)
+        fused = self._fused_form()
+        if (fused is not None and squeezed_Xnew.size > 0 and np.all(np.diff(squeezed_ts) >= 0)
+                and np.all(np.diff(squeezed_Xnew) >= 0)):
+            # the whole of predict_f on the device: merge, missing-marking, filter + smoother, projection
+            # through H at the query rows -- K means and variances come back, nothing else
+            from . import _backend
+            sde, form = fused
+            mean, var, _ = _backend.gp_predict(form, sde.P0, sde.H, self.noise_variance, squeezed_ts, ys.reshape(-1),
+                                               squeezed_Xnew)
+            return mean[:, None], var[:, None]
         nan_ys = np.full((squeezed_Xnew.shape[0], ys.shape[1]), np.nan, dtype=ys.dtype)
         all_ts, all_ys, all_flags = _merge_sorted(
             squeezed_ts, squeezed_Xnew, (ys, nan_ys),
             (np.zeros(squeezed_ts.shape, dtype=bool), np.ones(squeezed_Xnew.shape, dtype=bool)))
-        fused = self._fused_form()
         if fused is not None:
             # times and observations straight into the scan kernels (Fs / Qs never materialised)
             from . import _backend
