@@ -371,6 +371,29 @@ def main():
             fused["log-lik + gradient (3 hyper-parameters, forward-mode duals)"] = {
                 "ms_per_step": ms, "timesteps_per_s": n_local / ms * 1e3,
                 "log_likelihood": float(g_d[0].item()), "gradient": [float(v) for v in g_d[1:1 + npar].tolist()]}
+        # predict_f on the device: N training steps + N/4 query times (merge + filter + smoother + projection)
+        kq = max(1, n_local // 4)
+        tq_d = (torch.rand(kq, dtype=torch.float64, device=dev) * float(ts_d[-1].item())).sort().values.to(dtype_t)
+        pm_d = torch.empty(kq, dtype=dtype_t, device=dev)
+        pv_d = torch.empty(kq, dtype=dtype_t, device=dev)
+
+        def predict_step():
+            ctx.call(f"pgps_gp_predict_dev_{suf}", ctypes.c_long(n_local), ctypes.c_long(kq), ctypes.c_int(d),
+                     ctypes.c_double(lam), HP(N1), HP(N2), HP(Pinf_h), HP(H_h), ctypes.c_double(noise), P(ts_d), P(ys_d),
+                     ctypes.c_double(t_prev), P(tq_d), P(pm_d), P(pv_d), P(ll_d))
+
+        for _ in range(5):
+            predict_step()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(min(args.steps, 50)):
+            predict_step()
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / min(args.steps, 50)
+        fused[f"predict_f on device (N train + N/4 = {kq} queries)"] = {
+            "ms_per_step": ms, "merged_timesteps_per_s": (n_local + kq) / ms * 1e3}
         fused["note"] = ("pgps_gp_dev: discretisation fused into the scan kernels, inputs are (ts, ys) only; "
                          "GPU-event time, not part of `value`")
         out["fused_path"] = fused

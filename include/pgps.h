@@ -199,6 +199,22 @@ int pgps_gp_predict_dev_f32(pgps_ctx*, long N, long K, int d, double lam, const 
                             const double* Pinf, const double* H, double R, const float* ts, const float* ys,
                             double t0, const float* tq, float* mean, float* var, double* ll);
 
+/* ---- batched log-likelihood (fused path, d <= 3) ---------------------------------------------------
+ * B hyper-parameter settings evaluated over the SAME series in one pair of launches (HMC leapfrogs,
+ * grid search, multi-start optimisation at the reference's typical N of 1e3..1e5: SURVEY.md section
+ * 8f rank 3).  `models` (HOST memory): B consecutive blocks [lam | N1 (d*d) | N2 (d*d) | Pinf (d*d) |
+ * H (d) | R].  ll: B doubles.  Each ll[m] is bit-identical to what pgps_gp_* returns for model m at
+ * the same steps-per-lane geometry.  ts, ys, ll: host pointers; device pointers for the _dev form.
+ * B <= 65535. */
+int pgps_gp_ll_batch_f64(pgps_ctx*, int B, long N, int d, const double* models, const double* ts, double t0,
+                         const double* ys, double* ll);
+int pgps_gp_ll_batch_f32(pgps_ctx*, int B, long N, int d, const double* models, const float* ts, double t0,
+                         const float* ys, double* ll);
+int pgps_gp_ll_batch_dev_f64(pgps_ctx*, int B, long N, int d, const double* models, const double* ts, double t0,
+                             const double* ys, double* ll);
+int pgps_gp_ll_batch_dev_f32(pgps_ctx*, int B, long N, int d, const double* models, const float* ts, double t0,
+                             const float* ys, double* ll);
+
 /* ---- log-likelihood and its gradient (fused path, d <= 3, fp64) --------------------------------
  * What the reference gets from TensorFlow autodiff through the scan (tests/test_gp_vs_kfs.py:53-78;
  * SURVEY.md section 8f, rank 1): forward-mode dual numbers carried through every filtering element and

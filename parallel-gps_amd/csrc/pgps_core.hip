@@ -2,6 +2,7 @@
 // dimension dispatch.  The kernels live in pgps_inst.hip (one unit per dtype x state dim).
 // No PyTorch, no TensorFlow: HIP runtime only.
 #include <cmath>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -849,6 +850,77 @@ static int gp_predict_host(pgps_ctx* ctx, long N, long K, int d, double lam, con
 
 PGPS_DEFINE_PREDICT(f64, double)
 PGPS_DEFINE_PREDICT(f32, float)
+
+// ---------------------------------------------------------------------------------------------
+// batched log-likelihood: B hyper-parameter settings over one series
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int gp_ll_batch_dev(pgps_ctx* ctx, int B, long N, int d, const double* models_host, const T* ts, double t0,
+                           const T* ys, double* ll) {
+    if (!ctx || B < 1 || B > 65535 || N < 1 || !models_host || !ts || !ys || !ll) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // models: B blocks [lam | N1 (d*d) | N2 (d*d) | Pinf (d*d) | H (d) | R] from the caller, re-packed
+    // to the fixed device stride
+    std::vector<double> packed((size_t)B * kGpModelStride, 0.0);
+    const int in_stride = 1 + 3 * d * d + d + 1;
+    for (int m = 0; m < B; ++m) {
+        const double* p = models_host + (size_t)m * in_stride;
+        double* q = packed.data() + (size_t)m * kGpModelStride;
+        q[0] = p[0];
+        for (int i = 0; i < d * d; ++i) { q[1 + i] = p[1 + i]; q[10 + i] = p[1 + d * d + i]; q[19 + i] = p[1 + 2 * d * d + i]; }
+        for (int i = 0; i < d; ++i) q[28 + i] = p[1 + 3 * d * d + i];
+        q[31] = p[1 + 3 * d * d + d];
+        if (!(q[0] > 0.0) || !(q[31] > 0.0)) return PGPS_E_INVALID;
+    }
+    double* dmodels;
+    TRY(stage_in<double>(ctx, ctx->st[0], nullptr, packed.size(), &dmodels));
+    // the packed vector dies with this frame: synchronous copy (pageable memory, so hipMemcpyAsync would
+    // stage it anyway)
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(dmodels, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice));
+    GpBatchArgs<T> b{};
+    b.N = N;
+    b.ts = ts;
+    b.ys = ys;
+    b.t_prev = (T)t0;
+    b.models = dmodels;
+    b.ll = ll;
+    switch (d) {
+        case 1: return launch_gp_batch<T, 1>(ctx, B, b);
+        case 2: return launch_gp_batch<T, 2>(ctx, B, b);
+        default: return launch_gp_batch<T, 3>(ctx, B, b);
+    }
+}
+
+template <typename T>
+static int gp_ll_batch_host(pgps_ctx* ctx, int B, long N, int d, const double* models, const T* ts, double t0,
+                            const T* ys, double* ll) {
+    if (!ctx || B < 1 || N < 1 || !ts || !ys || !ll) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    T *dts, *dys;
+    double* dll;
+    TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
+    TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, (size_t)B, &dll));
+    TRY(gp_ll_batch_dev<T>(ctx, B, N, d, models, dts, t0, dys, dll));
+    TRY(stage_out(ctx, ll, dll, (size_t)B));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGPS_OK;
+}
+
+#define PGPS_DEFINE_LL_BATCH(SUF, T)                                                                                \
+    extern "C" int pgps_gp_ll_batch_dev_##SUF(pgps_ctx* c, int B, long N, int d, const double* models, const T* ts, \
+                                              double t0, const T* ys, double* ll) {                                \
+        return gp_ll_batch_dev<T>(c, B, N, d, models, ts, t0, ys, ll);                                              \
+    }                                                                                                               \
+    extern "C" int pgps_gp_ll_batch_##SUF(pgps_ctx* c, int B, long N, int d, const double* models, const T* ts,     \
+                                          double t0, const T* ys, double* ll) {                                    \
+        return gp_ll_batch_host<T>(c, B, N, d, models, ts, t0, ys, ll);                                             \
+    }
+
+PGPS_DEFINE_LL_BATCH(f64, double)
+PGPS_DEFINE_LL_BATCH(f32, float)
 
 // ---------------------------------------------------------------------------------------------
 // log-likelihood and its gradient (fused path, forward-mode duals through the scan)

@@ -65,7 +65,7 @@ __device__ __forceinline__ void gp_prior(const GpModel<T>& m, T* h, T* P0 /*sym*
 // reduce
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(kBlock) void k_gp_reduce(const GpArgs<T> g) {
+__device__ __forceinline__ void gp_reduce_body(const GpArgs<T>& g) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM;
     using FE = FiltElem<T, D>;
     const ScanArgs<T>& a = g.s;
@@ -100,11 +100,16 @@ __global__ __launch_bounds__(kBlock) void k_gp_reduce(const GpArgs<T> g) {
     if (threadIdx.x == 0) rec_store(a.spine + (long)blockIdx.x * Dim<D>::NFILT, total);
 }
 
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void k_gp_reduce(const GpArgs<T> g) {
+    gp_reduce_body<T, D>(g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // apply (+ log-likelihood, + smoothing aggregates when SMOOTH); fms / fPs are written when non-null
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D, bool SMOOTH, bool NT>
-__global__ __launch_bounds__(kBlock) void k_gp_apply(const GpArgs<T> g) {
+__device__ __forceinline__ void gp_apply_body(const GpArgs<T>& g) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT, G = 4;
     using FE = FiltElem<T, D>;
     using SE = SmthElem<T, D>;
@@ -203,6 +208,61 @@ __global__ __launch_bounds__(kBlock) void k_gp_apply(const GpArgs<T> g) {
         if (threadIdx.x == 0) rec_store(a.sspine + (long)blockIdx.x * Dim<D>::NSMTH, total);
     }
     (void)lane;
+}
+
+template <typename T, int D, bool SMOOTH, bool NT>
+__global__ __launch_bounds__(kBlock) void k_gp_apply(const GpArgs<T> g) {
+    gp_apply_body<T, D, SMOOTH, NT>(g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched log-likelihood: B hyper-parameter settings over the same (ts, ys) in one pair of launches
+// (HMC leapfrogs / grid search at the reference's realistic N of
+// 1e3..1e5, where one series alone cannot fill the chip).  blockIdx.y selects the model; each model
+// has its own slice of the scan scratch.  Same bodies, same arithmetic as the single-model launches.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__device__ __forceinline__ GpArgs<T> gp_batch_select(const GpBatchArgs<T>& b) {
+    const long m = blockIdx.y;
+    const double* p = b.models + m * kGpModelStride;
+    GpArgs<T> g{};
+    g.s.N = b.N; g.s.Lc = b.Lc; g.s.nblocks = b.nblocks; g.s.nlanes = b.nlanes;
+    g.s.seg_first = 1; g.s.seg_last = 1;
+    g.s.ys = b.ys;
+    g.s.R = T(p[31]);
+    g.s.spine = b.spine + m * b.nblocks * Dim<D>::NFILT;
+    g.s.lpre = b.lpre + m * b.nlanes * Dim<D>::NFILT;
+    g.s.llpart = b.llpart + m * b.nblocks;
+    g.m.lam = p[0];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) { g.m.N1[i] = p[1 + i]; g.m.N2[i] = p[10 + i]; g.m.Pinf[i] = p[19 + i]; }
+#pragma unroll
+    for (int i = 0; i < D; ++i) g.m.H[i] = T(p[28 + i]);
+    g.m.ts = b.ts;
+    g.m.t_prev = b.t_prev;
+    return g;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void k_gpb_reduce(const GpBatchArgs<T> b) {
+    const GpArgs<T> g = gp_batch_select<T, D>(b);
+    gp_reduce_body<T, D>(g);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void k_gpb_apply(const GpBatchArgs<T> b) {
+    const GpArgs<T> g = gp_batch_select<T, D>(b);
+    gp_apply_body<T, D, false, false>(g);
+}
+
+// one workgroup per model: ll[m] = sum of its block partials
+static __global__ __launch_bounds__(kBlock) void k_gpb_finalize(const double* llpart, int nblocks, double* ll) {
+    __shared__ double lds_ll[kWaves];
+    const double* p = llpart + (long)blockIdx.x * nblocks;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) v += p[i];
+    const double t = block_sum_double(v, lds_ll);
+    if (threadIdx.x == 0) ll[blockIdx.x] = t;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -213,6 +213,49 @@ int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed) 
     }
 }
 
+// ---- batched log-likelihood (B models over one series) ---------------------------------------------------
+template <typename T, int D>
+int launch_gp_batch(pgps_ctx* ctx, int B, GpBatchArgs<T> b) {
+    if constexpr (D <= 3) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        // steps per lane: the serial part is the efficient one, so as long as the batch keeps the chip
+        // covered (>= 1024 workgroups) use 16 steps per lane; halve towards 4 when B x N is small
+        int lc = ctx->chunk;
+        if (lc <= 0) {
+            lc = 16;
+            while (lc > 4 && (long)B * ((b.N + (long)kBlock * lc - 1) / ((long)kBlock * lc)) < 1024) lc /= 2;
+            if (b.N < (long)kBlock * 4) lc = (int)((b.N + kBlock - 1) / kBlock);
+            if (lc < 1) lc = 1;
+        }
+        b.Lc = lc;
+        b.nblocks = (int)((b.N + (long)kBlock * lc - 1) / ((long)kBlock * lc));
+        b.nlanes = (long)b.nblocks * kBlock;
+        if (b.nblocks > 65535 * 16) return PGPS_E_INVALID;
+        const size_t nb = (size_t)b.nblocks, nl = (size_t)b.nlanes, nB = (size_t)B;
+        auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+        size_t off = 0;
+        const size_t o_spine = off; off = up(off + nB * nb * Dim<D>::NFILT * sizeof(T));
+        const size_t o_lpre = off;  off = up(off + nB * nl * Dim<D>::NFILT * sizeof(T));
+        const size_t o_ll = off;    off = up(off + nB * nb * sizeof(double));
+        int rc = ensure(ctx, ctx->ws, off);
+        if (rc) return rc;
+        char* base = (char*)ctx->ws.p;
+        b.spine = (T*)(base + o_spine);
+        b.lpre = (T*)(base + o_lpre);
+        b.llpart = (double*)(base + o_ll);
+        const dim3 grid(b.nblocks, B), block(kBlock);
+        timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_gpb_reduce<T, D>, grid, block, 0, b);
+        timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gpb_apply<T, D>, grid, block, 0, b);
+        timed_launch(ctx, PGPS_K_LL_FINALIZE, k_gpb_finalize, dim3(B), block, 0, (const double*)b.llpart, b.nblocks, b.ll);
+        HIPCHK(ctx, hipGetLastError());
+        return PGPS_OK;
+    } else {
+        (void)ctx; (void)B; (void)b;
+        return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
+
+template int launch_gp_batch<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, int, GpBatchArgs<PGPS_INST_T>);
 template int launch_gp<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, GpArgs<PGPS_INST_T>, int, int);
 template int launch_scan<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, ScanArgs<PGPS_INST_T>, Mode);
 template int launch_disc<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, long, const PGPS_INST_T*, const PGPS_INST_T*,

@@ -148,6 +148,25 @@ struct GpArgs {
 template <typename T, int D>
 int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed);
 
+template <typename T>
+struct GpBatchArgs {
+    long N;
+    int Lc, nblocks;
+    long nlanes;
+    const T* ts;
+    const T* ys;
+    T t_prev;
+    const double* models;       // (B, kGpModelStride): lam | N1[9] | N2[9] | Pinf[9] | H[3] | R
+    T* spine;                   // (B, nblocks, NFILT)
+    T* lpre;                    // (B, NFILT, nlanes)
+    double* llpart;             // (B, nblocks)
+    double* ll;                 // (B,)
+};
+constexpr int kGpModelStride = 32;
+
+template <typename T, int D>
+int launch_gp_batch(pgps_ctx* ctx, int B, GpBatchArgs<T> b);
+
 // merge of two sorted time arrays on the device + NaN marking of the query rows (pgps_core.hip)
 template <typename T>
 int launch_merge(pgps_ctx* ctx, long N, long K, const T* ts, const T* ys, const T* tq, T* ts_m, T* ys_m, int* qslot);

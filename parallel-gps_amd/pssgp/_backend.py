@@ -401,6 +401,32 @@ def gp_predict(form, Pinf, H, R, ts, ys, tq, t0=0.0, device=0):
     return mean, var, ll.value
 
 
+def gp_ll_batch(models, ts, ys, t0=0.0, device=0):
+    """Log-likelihoods of B models over one series (pgps_gp_ll_batch_*).
+
+    `models`: list of (form=(lam, N1, N2), Pinf, H, R) -- what gp() takes, once per model."""
+    ts_a = np.asarray(ts)
+    dtype = ts_a.dtype if ts_a.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+    suf, _ = _suffix(dtype)
+    ts_a = _prep(ts_a, dtype, (-1,))
+    ys_a = _prep(ys, dtype, (-1,))
+    if ys_a.shape[0] != ts_a.shape[0]:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
+    d = np.asarray(models[0][0][1]).shape[0]
+    rows = []
+    for (lam, N1, N2), Pinf, H, R in models:
+        if np.asarray(N1).shape[0] != d:
+            raise ValueError("all models of a batch must have the same state dimension")
+        rows.append(np.concatenate([[float(lam)], np.asarray(N1, np.float64).reshape(-1), np.asarray(N2, np.float64).reshape(-1),
+                                    np.asarray(Pinf, np.float64).reshape(-1), np.asarray(H, np.float64).reshape(-1),
+                                    [float(R)]]))
+    packed = np.ascontiguousarray(np.stack(rows), dtype=np.float64)
+    out = np.zeros(len(models), np.float64)
+    get_context(device).call(f"pgps_gp_ll_batch_{suf}", c_int(len(models)), c_long(ts_a.shape[0]), c_int(d), _ptr(packed),
+                             _ptr(ts_a), c_double(float(t0)), _ptr(ys_a), _ptr(out))
+    return out
+
+
 def pack_grad_model(blocks):
     """(1 + np, 1 + 2 d^2 + d + 1) array [lam | N1 | Pinf | H | R] per block, as pgps_gp_ll_grad_* reads it."""
     d = np.asarray(blocks[0][1]).shape[0]

@@ -191,6 +191,36 @@ class StateSpaceGP:
         ll, g = _backend.gp_ll_grad(self._grad_blocks(), ts.reshape(-1), Y.reshape(-1))
         return ll, g
 
+    def log_likelihood_batch(self, thetas):
+        """Marginal log-likelihoods at B hyper-parameter settings in one call: `thetas` is (B, P) in the
+        order of `trainable_parameters()`.  The B filters share the series and run side by side on
+        the GPU (pgps_gp_ll_batch_*) -- the evaluation pattern of the reference's HMC / grid-search
+        drivers (pssgp/experiments/*/mcmc.py), which loop over maximum_log_likelihood_objective."""
+        if not self.parallel:
+            raise NotImplementedError("batched evaluation runs on the parallel (HIP) path: construct with parallel=True")
+        from . import _backend
+        thetas = np.atleast_2d(np.asarray(thetas, np.float64))
+        params = self.trainable_parameters()
+        if thetas.shape[1] != len(params):
+            raise ValueError(f"thetas has {thetas.shape[1]} columns, the model {len(params)} trainable parameters")
+        saved = [getattr(o, n) for o, n in params]
+        models = []
+        try:
+            for row in thetas:
+                for (o, n), v in zip(params, row):
+                    setattr(o, n, float(v))
+                sde = self.kernel.get_sde()
+                form = _backend.nilpotent_form(sde.F)
+                if form is None:
+                    raise NotImplementedError("batched evaluation needs the closed-form (Matern-family) discretisation")
+                models.append((form, np.asarray(sde.P0, np.float64), np.asarray(sde.H, np.float64).reshape(-1),
+                               self.noise_variance))
+        finally:
+            for (o, n), v in zip(params, saved):
+                setattr(o, n, v)
+        ts, Y = self.data
+        return _backend.gp_ll_batch(models, ts.reshape(-1), Y.reshape(-1))
+
     def log_posterior_density(self):
         return self.maximum_log_likelihood_objective()
 
