@@ -50,7 +50,10 @@ struct pgps_ctx {
 
 namespace pgps {
 
-constexpr int kBlock = 256;
+#ifndef PGPS_BLOCK
+#define PGPS_BLOCK 256
+#endif
+constexpr int kBlock = PGPS_BLOCK;      // lanes per workgroup (experiments: make EXTRA=-DPGPS_BLOCK=128 ...)
 constexpr int kWave = 64;
 constexpr int kWaves = kBlock / kWave;
 

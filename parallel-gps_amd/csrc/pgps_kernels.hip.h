@@ -941,6 +941,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
     __shared__ T s_base[NMP];
     __shared__ __attribute__((aligned(16))) char stage[kWaves][CFG::F3_BYTES];
 
+    PGPS_STAMP(1, 0);
     if (threadIdx.x == 0) s_tile = atomicAdd(a.ticket, 1);
     __syncthreads();
     const int tile = s_tile;
@@ -1004,8 +1005,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
     } else {
         lane_filter_reduce_direct<T, D>(a, k0, k1, h, agg);
     }
+    PGPS_STAMP(1, 1);
     FE excl, total;
     block_scan_exclusive<FE, true>(agg, excl, total, lds);
+    PGPS_STAMP(1, 2);
 
     // ---- hand-off: publish this tile's total, collect the carry from the left ---------------------
     if (threadIdx.x == 0) {
@@ -1047,6 +1050,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
             }
         }
     }
+    PGPS_STAMP(1, 3);
     FE left;
     block_reduce_ordered(mine, left, lds);          // (its barriers also publish s_base)
     MC s;
@@ -1068,6 +1072,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
     }
     filt_apply(s, excl);                            // ... and this lane's chunk
 
+    PGPS_STAMP(1, 4);
     // ---- phase B: lane-serial Kalman pass over the registers ---------------------------------------
     LogLik ll;
     SE sagg;
@@ -1109,6 +1114,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
         lane_filter_apply_direct<T, D, SMOOTH>(a, k0, k1, h, s, ll, sagg);
     }
 
+    PGPS_STAMP(1, 5);
     {
         const double v = ll.value();
         const double t = block_sum_double(v, lds_ll);
@@ -1120,6 +1126,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
         ws_store(a.lsuf, a.nlanes, gt, sexcl);
         if (threadIdx.x == 0) rec_store(a.sspine + (long)tile * Dim<D>::NSMTH, stotal);
     }
+    PGPS_STAMP(1, 6);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,9 +10,12 @@ from pssgp.kernels import Matern32
 
 chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 stage = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+single = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 1: single-pass filter kernel (k_filter_single)
 n, d = 1 << 20, 2
 ctx = B.Context(0)
 ctx.set_chunk(chunk); ctx.set_stage(stage)
+if single:
+    ctx.set_single_pass(1, 256)
 sde = Matern32(1., 1.).get_sde()
 rng = np.random.default_rng(0)
 ts = np.cumsum(0.05 * rng.uniform(0.5, 1.5, n))
@@ -30,18 +33,25 @@ for it in range(5):
 ctx.synchronize()
 lc, nb = ctx.get_chunk(n)
 buf = np.zeros((3, nb, 8), dtype=np.int64)
+nstamps = {0: 4, 1: 6, 2: 4}
 ctx.lib.pgps_debug_read_stamps.argtypes = [P, P, ctypes.c_long]
 B.check(ctx, ctx.lib.pgps_debug_read_stamps(ctx.handle, buf.ctypes.data_as(P), buf.size), "read_stamps")
 names = {0: ["lane-serial reduce", "block scan", "store lpre/spine"],
          1: ["fold spine (prologue)", "lpre load+apply", "lane-serial KF+smooth-agg", "ll reduce", "suffix scan+store"],
          2: ["fold sspine (prologue)", "lsuf load+apply", "lane-serial RTS"]}
 print(f"chunk {lc}, {nb} workgroups, stage {stage}; s_memtime ticks are 100 MHz-domain? printing raw ticks and share")
+if single:
+    names[1] = ["stream to registers + reduce", "block scan", "publish + wait for left totals", "fold + apply",
+                "Kalman pass from registers + stores", "ll reduce + suffix scan (+ publish)"]
+
 for k, kn in enumerate(["k_filter_reduce", "k_filter_apply", "k_smoother_apply"]):
     st = buf[k]
     nph = len(names[k])
     dur = np.diff(st[:, :nph + 1], axis=1).astype(np.float64)
     tot = dur.sum(axis=1)
     span = st[:, nph].max() - st[:, 0].min()
+    if single and k == 0:
+        continue
     print(f"{kn}: median workgroup total {np.median(tot):.0f} ticks; first-start to last-end {span} ticks")
     for i, nm in enumerate(names[k]):
         print(f"    {nm:32s} median {np.median(dur[:, i]):9.0f}  max {dur[:, i].max():9.0f}  share {np.median(dur[:, i]) / np.median(tot):5.1%}")
