@@ -144,7 +144,7 @@ extern "C" int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window) {
 }
 
 extern "C" int pgps_set_family(pgps_ctx* ctx, int family) {
-    if (!ctx || family < 0 || family > 2) return PGPS_E_INVALID;
+    if (!ctx || family < 0 || family > 3) return PGPS_E_INVALID;
     ctx->family = family;
     return PGPS_OK;
 }
@@ -323,6 +323,12 @@ extern "C" int pgps_get_chunk(pgps_ctx* ctx, long N, int* Lc, int* nb) {
 
 template <typename T>
 static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
+    if constexpr (sizeof(T) == 8) {
+        // row-cooperative family: fp64, d <= 16, whole-series filter / filter+smoother
+        const bool rc_ok = d <= 16 && (mode == MODE_PKF || mode == MODE_PKFS);
+        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE))) return launch_scan_rc(ctx, a, d, mode);
+    }
+    if (ctx->family == 3) return PGPS_E_UNSUPPORTED_DIM;
     if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_scan_wc<T>(ctx, a, d, mode);
     switch (d) {
         case 1: return launch_scan<T, 1>(ctx, a, mode);

@@ -23,7 +23,7 @@ struct pgps_ctx {
     int stage_g = -1;                   // LDS staging: -1 = auto, 0 = off, 2 / 4 = steps per sub-tile
     int single_pass = -1;               // single-pass filter kernel: -1 = auto, 0 = off, 1 = on
     int lookback_window = 256;          // tiles per look-back window (<= 256; small values are for tests)
-    int family = 0;                     // 0 = auto (lane-chunk for d <= 6, else wave-cooperative), 1 = lane, 2 = wave
+    int family = 0;                     // 0 = auto (lane-chunk d <= 6; row-cooperative fp64 d <= 16; else wave-cooperative), 1 = lane, 2 = wave, 3 = row
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
@@ -186,6 +186,8 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
 // wave-cooperative family (pgps_wc.hip): runtime state dimension, 1 <= d <= 32
 template <typename T>
 int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);
+// row-cooperative family (pgps_rc.hip.h): fp64, 1 <= d <= 16, pkf / pkfs
+int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode);
 template <typename T>
 int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);
 

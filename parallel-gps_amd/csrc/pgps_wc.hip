@@ -1196,3 +1196,5 @@ template int launch_scan_wc<double>(pgps_ctx*, ScanArgs<double>, int, Mode);
 template int launch_scan_wc<float>(pgps_ctx*, ScanArgs<float>, int, Mode);
 
 }  // namespace pgps
+
+#include "pgps_rc.hip.h"

@@ -1,0 +1,129 @@
+"""GPU parity of the row-cooperative family (csrc/pgps_rc.hip.h: a 16-lane DPP row owns a chain of steps,
+lane j holds column j of every operand, products are v_fmac_f64_dpp row_newbcast chains; fp64, state dims up
+to 16) against the CPU oracle.  It is the automatic choice for 6 < d <= 16 in fp64; here it is also forced at
+small d, where the lane-chunk family and the dense GP give further opinions."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests.conftest import make_times, relerr, sample_series
+
+pytestmark = pytest.mark.gpu
+TOL64 = 1e-9
+
+
+def _kernels():
+    from pssgp.kernels import Matern32, Matern52, RBF, Periodic, SquaredExponential
+    return {
+        "rbf7": lambda: RBF(variance=1., lengthscales=0.7, order=7, balancing_iter=10),                       # d = 7  (DP 8)
+        "rbf8": lambda: RBF(variance=1., lengthscales=0.7, order=8, balancing_iter=10),                       # d = 8  (DP 8)
+        "rbf9": lambda: RBF(variance=1., lengthscales=0.7, order=9, balancing_iter=10),                       # d = 9  (DP 12)
+        "c5_qp_m52": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) +
+        Matern52(1., 1.),                                                                                     # d = 11 (DP 12)
+        "periodic5": lambda: Periodic(SquaredExponential(1., 0.5), period=0.5, order=5),                      # d = 12 (DP 12)
+        "rbf13": lambda: RBF(variance=1., lengthscales=0.6, order=13, balancing_iter=10),                     # d = 13 (DP 16)
+        "periodic7": lambda: Periodic(SquaredExponential(1., 0.5), period=0.5, order=7),                      # d = 16 (DP 16)
+    }
+
+
+def _oracle_all(ssm, y):
+    fms, fPs, ll = O.kf(ssm, y, True)
+    sms, sPs = O.kfs(ssm, y)
+    return dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([ll]))
+
+
+def _gpu_all(ssm, y):
+    from pssgp import _backend as B
+    ssm_t = tuple(np.asarray(a, dtype=np.float64) for a in ssm)
+    sms, sPs, fms, fPs, ll = B.pkfs(ssm_t, np.asarray(y, np.float64), return_filtered=True, return_loglikelihood=True)
+    return dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([float(ll)]))
+
+
+def _check(got, want, tol):
+    for name in want:
+        e = relerr(got[name], want[name])
+        assert e < tol, f"{name}: rel err {e:.3e} >= {tol}"
+
+
+@pytest.fixture
+def row_family():
+    from pssgp import _backend as B
+    ctx = B.get_context()
+    ctx.set_family(3)
+    yield ctx
+    ctx.set_family(0)
+    ctx.set_chunk(0)
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_forced_rowcoop_small_d(row_family, kernel_zoo, idx):
+    name, make, _, _ = kernel_zoo[idx]
+    t = make_times(1100, seed=idx)
+    ssm = O.get_ssm(make().get_sde(), t, 0.1)
+    y = sample_series(ssm, seed=idx, nan_frac=0.2)
+    _check(_gpu_all(ssm, y), _oracle_all(ssm, y), TOL64)
+
+
+@pytest.mark.parametrize("n,lw", [(1, 8), (2, 8), (7, 8), (8, 8), (9, 8), (31, 8), (33, 8), (2049, 32), (2200, 7),
+                                  (4097, 1), (70000, 16), (70001, 0)])
+def test_rowcoop_ragged_lengths_and_levels(row_family, n, lw):
+    """Chain boundaries, partially filled waves (four chains each), non-power-of-two chain counts in the
+    Kogge-Stone levels, steps beyond the end of the series inside the last chain."""
+    from pssgp.kernels import Matern52
+    row_family.set_chunk(lw)
+    t = make_times(n, seed=n % 97)
+    ssm = O.get_ssm(Matern52(1., 1.).get_sde(), t, 0.1)
+    y = sample_series(ssm, seed=3, nan_frac=0.1 if n > 4 else 0.0)
+    from oracle import c_oracle as C
+    cf, cP, cs, csP, cll = C.kfs(ssm, y)
+    _check(_gpu_all(ssm, y), dict(fms=cf, fPs=cP, sms=cs, sPs=csP, ll=np.array([cll])), TOL64)
+
+
+@pytest.mark.parametrize("name", ["rbf7", "rbf8", "rbf9", "c5_qp_m52", "periodic5", "rbf13", "periodic7"])
+def test_rowcoop_state_dims(name):
+    """d = 7 .. 16 through the automatic dispatch: every padded dimension (8, 12, 16) with and without padding."""
+    from pssgp.kalman.parallel import pkf, pkfs
+    sde = _kernels()[name]().get_sde()
+    n = 1500
+    t = make_times(n, seed=5)
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series(ssm, seed=5, nan_frac=0.2)
+    want = _oracle_all(ssm, y)
+    tol = 1e-7      # badly conditioned high-order RBF / tiny-variance periodic harmonics: the model's scale
+    _check(_gpu_all(ssm, y), want, tol)
+    fms, fPs, ll = pkf(ssm, y[:, None], return_loglikelihood=True)      # filter-only launch sequence
+    assert relerr(fms, want["fms"]) < tol and relerr(fPs, want["fPs"]) < tol
+    assert abs(float(ll) - want["ll"][0]) < tol * abs(want["ll"][0])
+    sms, sPs = pkfs(ssm, y[:, None])
+    assert relerr(sms, want["sms"]) < tol and relerr(sPs, want["sPs"]) < tol
+
+
+def test_rowcoop_first_observation_missing_and_all_missing(row_family):
+    from pssgp.kernels import Matern52
+    t = make_times(300, seed=11)
+    ssm = O.get_ssm(Matern52(1., 1.).get_sde(), t, 0.1)
+    y = sample_series(ssm, seed=4, nan_frac=0.3)
+    y[0] = np.nan
+    _check(_gpu_all(ssm, y), _oracle_all(ssm, y), TOL64)
+    y[:] = np.nan
+    got, want = _gpu_all(ssm, y), _oracle_all(ssm, y)
+    assert got["ll"][0] == 0.0
+    for k in ("fms", "fPs", "sms", "sPs"):
+        assert relerr(got[k], want[k]) < TOL64 or np.max(np.abs(got[k] - want[k])) < 1e-12
+
+
+def test_rowcoop_c5_large_n_vs_c_oracle():
+    """config c5's model (d = 11) at 2^16 steps, 20 % missing, against the sequential C oracle; reruns are
+    bit-identical (fixed chain geometry, fixed combine order)."""
+    from oracle import c_oracle as C
+    sde = _kernels()["c5_qp_m52"]().get_sde()
+    n = 1 << 16
+    t = make_times(n, seed=9)
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series(ssm, seed=9, nan_frac=0.2)
+    cf, cP, cs, csP, cll = C.kfs(ssm, y)
+    got = _gpu_all(ssm, y)
+    _check(got, dict(fms=cf, fPs=cP, sms=cs, sPs=csP, ll=np.array([cll])), 1e-8)
+    again = _gpu_all(ssm, y)
+    for k in got:
+        assert np.array_equal(got[k], again[k]), k
