@@ -186,8 +186,29 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
 // wave-cooperative family (pgps_wc.hip): runtime state dimension, 1 <= d <= 32
 template <typename T>
 int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);
-// row-cooperative family (pgps_rc.hip.h): fp64, 1 <= d <= 16, pkf / pkfs
+// row-cooperative family (pgps_rc.hip.h): fp64, 2 <= d <= 16, pkf / pkfs
 int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode);
+namespace rc {
+constexpr int kDimMin = 2, kDimMax = 16;
+struct RcArgs {
+    long N;
+    int Lw;                     // steps per chain
+    long nchunk;                // chains
+    const double *P0, *H;
+    double R;
+    const double *Fs, *Qs, *ys;
+    double *fms, *fPs, *sms, *sPs;
+    double* agg1;               // (nchunk, nfilt) chunk totals
+    const double* pre;          // (nchunk, nfilt) inclusive prefixes of agg1
+    double* sagg1;              // (nchunk, nsmth) smoothing totals
+    const double* suf;          // (nchunk, nsmth) inclusive suffixes of sagg1
+    double* Lws;                // (N, d, d) the smoothing elements' L
+    double* llpart;             // (nchunk,)
+};
+// defined in pgps_rc_inst.hip, one explicit instantiation per d
+template <int D>
+int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase);
+}  // namespace rc
 template <typename T>
 int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);
 

@@ -1,0 +1,9 @@
+// pgps_rc_inst.hip -- one explicit instantiation of the row-cooperative level-1 kernels per state dimension
+// (-DPGPS_RC_D=d, d = 2..16), so the fully unrolled units compile in parallel.
+#include "pgps_rc.hip.h"
+
+namespace pgps {
+namespace rc {
+template int launch_rc_level1<PGPS_RC_D>(pgps_ctx*, const RcArgs&, int);
+}  // namespace rc
+}  // namespace pgps

@@ -15,14 +15,14 @@ TOL64 = 1e-9
 def _kernels():
     from pssgp.kernels import Matern32, Matern52, RBF, Periodic, SquaredExponential
     return {
-        "rbf7": lambda: RBF(variance=1., lengthscales=0.7, order=7, balancing_iter=10),                       # d = 7  (DP 8)
-        "rbf8": lambda: RBF(variance=1., lengthscales=0.7, order=8, balancing_iter=10),                       # d = 8  (DP 8)
-        "rbf9": lambda: RBF(variance=1., lengthscales=0.7, order=9, balancing_iter=10),                       # d = 9  (DP 12)
+        "rbf7": lambda: RBF(variance=1., lengthscales=0.7, order=7, balancing_iter=10),                       # d = 7
+        "rbf8": lambda: RBF(variance=1., lengthscales=0.7, order=8, balancing_iter=10),                       # d = 8
+        "rbf9": lambda: RBF(variance=1., lengthscales=0.7, order=9, balancing_iter=10),                       # d = 9
         "c5_qp_m52": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) +
-        Matern52(1., 1.),                                                                                     # d = 11 (DP 12)
-        "periodic5": lambda: Periodic(SquaredExponential(1., 0.5), period=0.5, order=5),                      # d = 12 (DP 12)
-        "rbf13": lambda: RBF(variance=1., lengthscales=0.6, order=13, balancing_iter=10),                     # d = 13 (DP 16)
-        "periodic7": lambda: Periodic(SquaredExponential(1., 0.5), period=0.5, order=7),                      # d = 16 (DP 16)
+        Matern52(1., 1.),                                                                                     # d = 11
+        "periodic5": lambda: Periodic(SquaredExponential(1., 0.5), period=0.5, order=5),                      # d = 12
+        "rbf13": lambda: RBF(variance=1., lengthscales=0.6, order=13, balancing_iter=10),                     # d = 13
+        "periodic7": lambda: Periodic(SquaredExponential(1., 0.5), period=0.5, order=7),                      # d = 16
     }
 
 
@@ -55,7 +55,7 @@ def row_family():
     ctx.set_chunk(0)
 
 
-@pytest.mark.parametrize("idx", range(7))
+@pytest.mark.parametrize("idx", range(1, 7))         # d = 2, 3, 6, 6, 5, 6 (the family starts at d = 2)
 def test_forced_rowcoop_small_d(row_family, kernel_zoo, idx):
     name, make, _, _ = kernel_zoo[idx]
     t = make_times(1100, seed=idx)
@@ -81,7 +81,7 @@ def test_rowcoop_ragged_lengths_and_levels(row_family, n, lw):
 
 @pytest.mark.parametrize("name", ["rbf7", "rbf8", "rbf9", "c5_qp_m52", "periodic5", "rbf13", "periodic7"])
 def test_rowcoop_state_dims(name):
-    """d = 7 .. 16 through the automatic dispatch: every padded dimension (8, 12, 16) with and without padding."""
+    """d = 7 .. 16 through the automatic dispatch (one kernel instantiation per d)."""
     from pssgp.kalman.parallel import pkf, pkfs
     sde = _kernels()[name]().get_sde()
     n = 1500
