@@ -208,6 +208,8 @@ struct RcArgs {
 // defined in pgps_rc_inst.hip, one explicit instantiation per d
 template <int D>
 int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase);
+template <int D>
+int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out);
 }  // namespace rc
 template <typename T>
 int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);

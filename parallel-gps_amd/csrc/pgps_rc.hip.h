@@ -459,6 +459,162 @@ __global__ __launch_bounds__(64) void rc_smooth1(const RcArgs a) {
     }
 }
 
+// ====================================================================================================
+// upper levels: Kogge-Stone scans over the chain totals, one ROW per record (four records per wave), operands
+// in registers in the same column layout as level 1.
+// ====================================================================================================
+// Gauss-Jordan with partial pivoting, B <- M^-1 B (M general).  Column c lives in lane c, so every lane learns
+// the candidates by broadcast and applies the same predicated row swaps to its own registers.
+template <int D, int C>
+struct GjPivStep {
+    static __device__ __forceinline__ void run(double* M, double* B) {
+        double pv = bcast<C>(M[C]);
+#pragma unroll
+        for (int r = C + 1; r < D; ++r) {
+            const double t = bcast<C>(M[r]);
+            const bool sw = __builtin_fabs(t) > __builtin_fabs(pv);
+            const double mc = M[C], mr = M[r], bc = B[C], br = B[r];
+            M[C] = sw ? mr : mc; M[r] = sw ? mc : mr;
+            B[C] = sw ? br : bc; B[r] = sw ? bc : br;
+            pv = sw ? t : pv;
+        }
+        const double inv = 1.0 / pv;
+        const double mc = M[C] * inv, bv = B[C] * inv;
+        if constexpr (D <= 8) {
+            Gj<D, C>::run(M, B, -mc, -bv);
+        } else {
+            Gj<8, C>::run(M, B, -mc, -bv);
+            Gj<D - 8, C>::run(M + 8, B + 8, -mc, -bv);
+        }
+        M[C] = mc;
+        B[C] = bv;
+        if constexpr (C + 1 < D) GjPivStep<D, C + 1>::run(M, B);
+    }
+};
+
+template <int D>
+__device__ __forceinline__ void ld_rec_mat(const double* g, bool ok, int lane, double* X) {
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) X[i] = g[i * D + lane];
+    }
+}
+template <int D>
+__device__ __forceinline__ void st_rec_mat(double* g, bool ok, int lane, const double* X) {
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) g[i * D + lane] = X[i];
+    }
+}
+
+// out[c] = in[c - stride] (x) in[c]   (filt_combine of pgps_math.h, parallel.py:100-118), rearranged so that one
+// elimination with a single right-hand side serves everything:
+//   M = I + C1 J2;  Nm = M^-1 C1 (symmetric);  z = eta2 - J2 b1;  W = J2 A1;  G = M^-1 A1 = A1 - Nm W
+//   A = A2 G;  b = A2 (b1 + Nm z) + b2;  C = sym(A2 Nm A2^T) + C2;  eta = G^T z + eta1;  J = sym(G^T W) + J1
+template <int D>
+__global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const double* in, double* out) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    constexpr int dd = D * D, nf = 3 * D * D + 2 * D;
+    const long c = (long)blockIdx.x * 4 + row;
+    const bool lv = lane < D, cv = c < n, comb = cv && c >= stride;
+    const bool ok = lv && cv;
+    // later operand (also the pass-through value)
+    double A2[D], C2[D], J2[D], b2 = 0.0, e2 = 0.0;
+    zero<D>(A2); zero<D>(C2); zero<D>(J2);
+    const double* r2 = in + (cv ? c : 0) * nf;
+    ld_rec_mat<D>(r2, ok, lane, A2); ld_rec_mat<D>(r2 + dd, ok, lane, C2); ld_rec_mat<D>(r2 + 2 * dd, ok, lane, J2);
+    if (ok) { b2 = r2[3 * dd + lane]; e2 = r2[3 * dd + D + lane]; }
+    // earlier operand; rows that only pass through combine with the identity (A = I): same arithmetic, result unused
+    double A1[D], C1[D], J1[D], b1 = 0.0, e1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { A1[i] = (i == lane) ? 1.0 : 0.0; C1[i] = 0.0; J1[i] = 0.0; }
+    const double* r1 = in + (comb ? c - stride : 0) * nf;
+    const bool ok1 = lv && comb;
+    ld_rec_mat<D>(r1, ok1, lane, A1); ld_rec_mat<D>(r1 + dd, ok1, lane, C1); ld_rec_mat<D>(r1 + 2 * dd, ok1, lane, J1);
+    if (ok1) { b1 = r1[3 * dd + lane]; e1 = r1[3 * dd + D + lane]; }
+
+    double M[D], Nm[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { M[i] = (i == lane) ? 1.0 : 0.0; Nm[i] = C1[i]; }
+    mm<D>(M, C1, J2);
+    GjPivStep<D, 0>::run(M, Nm);
+    const double z = e2 - mvr<D>(J2, b1, 0.0);
+    double W[D], T[D], G[D];
+    zero<D>(W); mm<D>(W, J2, A1);
+    zero<D>(T); mm<D>(T, Nm, W);
+#pragma unroll
+    for (int i = 0; i < D; ++i) G[i] = A1[i] - T[i];
+    double Ao[D], X[D], A2r[D], Gt[D];
+    zero<D>(Ao); mm<D>(Ao, A2, G);
+    zero<D>(X); mm<D>(X, A2, Nm);
+    transpose<D>(A2, A2r, patch, lane);
+    mm<D>(C2, X, A2r);                          // C2 <- C2 + A2 Nm A2^T
+    symmetrise<D>(C2, patch, lane);
+    const double w = mvr<D>(Nm, z, b1);         // b1 + Nm z   (Nm symmetric: its column layout is its row layout)
+    const double bo = mvr<D>(A2r, w, b2);
+    const double eo = mvr<D>(G, z, e1);         // G^T z + eta1
+    transpose<D>(G, Gt, patch, lane);
+    mm<D>(J1, Gt, W);                           // J1 <- J1 + G^T W
+    symmetrise<D>(J1, patch, lane);
+    double* ro = out + (cv ? c : 0) * nf;
+    if (comb) {
+        st_rec_mat<D>(ro, ok, lane, Ao); st_rec_mat<D>(ro + dd, ok, lane, C2); st_rec_mat<D>(ro + 2 * dd, ok, lane, J1);
+        if (ok) { ro[3 * dd + lane] = bo; ro[3 * dd + D + lane] = eo; }
+    } else if (ok) {
+        // pass-through: reload (C2 was overwritten above) and copy
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            ro[i * D + lane] = A2[i];
+            ro[dd + i * D + lane] = r2[dd + i * D + lane];
+            ro[2 * dd + i * D + lane] = J2[i];
+        }
+        ro[3 * dd + lane] = b2;
+        ro[3 * dd + D + lane] = e2;
+    }
+}
+
+// out[c] = in[c] (x) in[c + stride] in time order (smth_combine, parallel.py:176-184):
+//   E = Ea Eb;  g = Ea gb + ga;  L = sym(Ea Lb Ea^T) + La
+template <int D>
+__global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const double* in, double* out) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    constexpr int dd = D * D, ns = 2 * D * D + D;
+    const long c = (long)blockIdx.x * 4 + row;
+    const bool lv = lane < D, cv = c < n, comb = cv && c + stride < n;
+    const bool ok = lv && cv, okb = lv && comb;
+    double Ea[D], La[D], ga = 0.0;
+    zero<D>(Ea); zero<D>(La);
+    const double* ra = in + (cv ? c : 0) * ns;
+    ld_rec_mat<D>(ra, ok, lane, Ea); ld_rec_mat<D>(ra + dd, ok, lane, La);
+    if (ok) ga = ra[2 * dd + lane];
+    double Eb[D], Lb[D], gb = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Eb[i] = (i == lane) ? 1.0 : 0.0; Lb[i] = 0.0; }      // identity when passing through
+    const double* rb = in + (comb ? c + stride : 0) * ns;
+    ld_rec_mat<D>(rb, okb, lane, Eb); ld_rec_mat<D>(rb + dd, okb, lane, Lb);
+    if (okb) gb = rb[2 * dd + lane];
+    double Eo[D], T[D], Ear[D];
+    zero<D>(Eo); mm<D>(Eo, Ea, Eb);
+    zero<D>(T); mm<D>(T, Ea, Lb);
+    transpose<D>(Ea, Ear, patch, lane);
+    const double go = mvr<D>(Ear, gb, ga);
+    double Lo[D];
+    copy<D>(Lo, La); mm<D>(Lo, T, Ear);
+    symmetrise<D>(Lo, patch, lane);
+    double* ro = out + (cv ? c : 0) * ns;
+    if (comb) {
+        st_rec_mat<D>(ro, ok, lane, Eo); st_rec_mat<D>(ro + dd, ok, lane, Lo);
+        if (ok) ro[2 * dd + lane] = go;
+    } else {
+        st_rec_mat<D>(ro, ok, lane, Ea); st_rec_mat<D>(ro + dd, ok, lane, La);
+        if (ok) ro[2 * dd + lane] = ga;
+    }
+}
+
 // ---- host side: the level-1 launches of one instantiation ---------------------------------------------
 // phase 0: reduce, 1: apply + smoothing elements, 2: apply only, 3: smoother
 template <int D>
@@ -470,6 +626,16 @@ int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
         case 2: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, false>, g1, blk, 0u, a); break;
         default: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D>, g1, blk, 0u, a); break;
     }
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+// one Kogge-Stone step over n records: which = 0 filter totals (prefix), 1 smoothing totals (suffix)
+template <int D>
+int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out) {
+    const dim3 blk(64), g((unsigned)((n + 3) / 4));
+    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<D>, g, blk, 0u, n, stride, in, out);
+    else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<D>, g, blk, 0u, n, stride, in, out);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

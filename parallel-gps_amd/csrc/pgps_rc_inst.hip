@@ -5,5 +5,6 @@
 namespace pgps {
 namespace rc {
 template int launch_rc_level1<PGPS_RC_D>(pgps_ctx*, const RcArgs&, int);
+template int launch_rc_ks<PGPS_RC_D>(pgps_ctx*, int, long, long, const double*, double*);
 }  // namespace rc
 }  // namespace pgps

@@ -1196,51 +1196,11 @@ template int launch_scan_wc<double>(pgps_ctx*, ScanArgs<double>, int, Mode);
 template int launch_scan_wc<float>(pgps_ctx*, ScanArgs<float>, int, Mode);
 
 // ====================================================================================================
-// Upper levels and host driver of the row-cooperative family (level 1: pgps_rc.hip.h).  Kogge-Stone scans over
-// the chain totals, one wave per record, the combine in LDS (the routines above).
+// Host driver of the row-cooperative family (kernels: pgps_rc.hip.h, one instantiation per state dimension):
+// level-1 reduce, Kogge-Stone steps over the chain totals, level-1 apply, Kogge-Stone over the smoothing totals,
+// level-1 smoother.
 // ====================================================================================================
 namespace rc {
-
-template <int DP>
-__global__ __launch_bounds__(64) void ks_filter(int d, long n, long stride, const double* in, double* out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using GE = wc::Geo<DP>;
-    const long c = blockIdx.x;
-    const int nf = wc::nfilt(d), dk = (d + 3) & ~3;
-    if (c < stride) {
-        for (int e = threadIdx.x; e < nf; e += 64) out[c * nf + e] = in[c * nf + e];
-        return;
-    }
-    wc::Pool<double> pool(reinterpret_cast<double*>(smem));
-    double* e1 = pool.take(GE::NFL); double* e2 = pool.take(GE::NFL); double* o = pool.take(GE::NFL);
-    double* M = pool.take(GE::MSZ); double* rhs = pool.take(DP * GE::NRC); double* X = pool.take(GE::MSZ);
-    double* vt = pool.take(DP);
-    wc::filt_g2l<double, DP>(d, in + (c - stride) * nf, e1);
-    wc::filt_g2l<double, DP>(d, in + c * nf, e2);
-    wc::sync();
-    wc::combine<double, DP>(d, dk, e1, e2, o, M, rhs, X, vt);
-    wc::filt_l2g<double, DP>(d, o, out + c * nf);
-}
-
-template <int DP>
-__global__ __launch_bounds__(64) void ks_smoother(int d, long n, long stride, const double* in, double* out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using GE = wc::Geo<DP>;
-    const long c = blockIdx.x;
-    const int ns = wc::nsmth(d), dk = (d + 3) & ~3;
-    if (c + stride >= n) {
-        for (int e = threadIdx.x; e < ns; e += 64) out[c * ns + e] = in[c * ns + e];
-        return;
-    }
-    wc::Pool<double> pool(reinterpret_cast<double*>(smem));
-    double* ea = pool.take(GE::NSL); double* eb = pool.take(GE::NSL); double* o = pool.take(GE::NSL);
-    double* X = pool.take(GE::MSZ);
-    wc::smth_g2l<double, DP>(d, in + c * ns, ea);
-    wc::smth_g2l<double, DP>(d, in + (c + stride) * ns, eb);
-    wc::sync();
-    wc::scombine<double, DP>(dk, ea, eb, o, X);
-    wc::smth_l2g<double, DP>(d, o, out + c * ns);
-}
 
 static int level1(pgps_ctx* ctx, int d, const RcArgs& a, int phase) {
     switch (d) {
@@ -1253,24 +1213,25 @@ static int level1(pgps_ctx* ctx, int d, const RcArgs& a, int phase) {
     return PGPS_E_UNSUPPORTED_DIM;
 }
 
-template <int DP>
-static int scan_rc_dp(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, double* aggB, double* saggA, double* saggB,
-                      double* ll) {
-    using GE = wc::Geo<DP>;
-    const size_t l_ksf = (3 * GE::NFL + 2 * GE::MSZ + (size_t)DP * GE::NRC + DP + 64) * sizeof(double);
-    const size_t l_kss = (3 * GE::NSL + GE::MSZ + 64) * sizeof(double);
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ks_filter<DP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)l_ksf));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ks_smoother<DP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)l_kss));
-    const dim3 blk(64), gk((unsigned)a.nchunk);
+static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const double* in, double* out) {
+    switch (d) {
+#define PGPS_RC_CASE(DV) case DV: return launch_rc_ks<DV>(ctx, which, n, stride, in, out);
+        PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
+        PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
+        PGPS_RC_CASE(15) PGPS_RC_CASE(16)
+#undef PGPS_RC_CASE
+    }
+    return PGPS_E_UNSUPPORTED_DIM;
+}
+
+static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, double* aggB, double* saggA, double* saggB,
+                   double* ll) {
+    int rcode;
     a.agg1 = aggA;
-    int rcode = level1(ctx, d, a, 0);
-    if (rcode) return rcode;
+    if ((rcode = level1(ctx, d, a, 0))) return rcode;
     double *src = aggA, *dst = aggB;
     for (long s = 1; s < a.nchunk; s *= 2) {
-        timed_launch(ctx, PGPS_K_FILTER_REDUCE, ks_filter<DP>, gk, blk, (unsigned)l_ksf, d, (long)a.nchunk, s,
-                     (const double*)src, dst);
+        if ((rcode = ks_step(ctx, d, 0, a.nchunk, s, src, dst))) return rcode;
         double* t = src; src = dst; dst = t;
     }
     a.pre = src;
@@ -1279,8 +1240,7 @@ static int scan_rc_dp(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, d
         if ((rcode = level1(ctx, d, a, 1))) return rcode;
         src = saggA; dst = saggB;
         for (long s = 1; s < a.nchunk; s *= 2) {
-            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, ks_smoother<DP>, gk, blk, (unsigned)l_kss, d, (long)a.nchunk, s,
-                         (const double*)src, dst);
+            if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, src, dst))) return rcode;
             double* t = src; src = dst; dst = t;
         }
         a.suf = src;
@@ -1289,7 +1249,8 @@ static int scan_rc_dp(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, d
         if ((rcode = level1(ctx, d, a, 2))) return rcode;
     }
     if (ll)
-        timed_launch(ctx, PGPS_K_LL_FINALIZE, wc::wc_ll_finalize, dim3(1), blk, 0u, (const double*)a.llpart, (long)a.nchunk, ll);
+        timed_launch(ctx, PGPS_K_LL_FINALIZE, wc::wc_ll_finalize, dim3(1), dim3(64), 0u, (const double*)a.llpart,
+                     (long)a.nchunk, ll);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }
@@ -1330,9 +1291,7 @@ int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode) {
     a.Lws = (double*)(base + o_L);
     double* aggA = (double*)(base + o_aggA); double* aggB = (double*)(base + o_aggB);
     double* sagA = (double*)(base + o_sagA); double* sagB = (double*)(base + o_sagB);
-    if (d <= 8) return rc::scan_rc_dp<8>(ctx, d, a, mode, aggA, aggB, sagA, sagB, sa.ll);
-    if (d <= 12) return rc::scan_rc_dp<12>(ctx, d, a, mode, aggA, aggB, sagA, sagB, sa.ll);
-    return rc::scan_rc_dp<16>(ctx, d, a, mode, aggA, aggB, sagA, sagB, sa.ll);
+    return rc::scan_rc(ctx, d, a, mode, aggA, aggB, sagA, sagB, sa.ll);
 }
 
 }  // namespace pgps
