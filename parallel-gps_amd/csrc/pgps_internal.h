@@ -194,6 +194,7 @@ struct RcArgs {
     long N;
     int Lw;                     // steps per chain
     long nchunk;                // chains
+    long wfast;                 // waves [1, wfast) lie inside the series, halo step included: predicate-free body
     const double *P0, *H;
     double R;
     const double *Fs, *Qs, *ys;

@@ -134,54 +134,58 @@ struct GjStep {
 };
 
 // Per-lane addressing of one chain's records.  The four chains of a wave sit Lw steps apart, so every access is
-// (wave-uniform base of row 0's step) + (a loop-invariant 32-bit byte offset per lane and register): element
-// (i, lane) for the column layout, (lane, i) for the row layout.  FAST = every chain of the wave is inside the
-// series for the whole loop (all waves but the first / last): the loads of a step are one EXEC-masked block
-// (lanes < D) with no selects behind them, so they stay in flight until their first use.
+// (wave-uniform base of row 0's step) + (one loop-invariant 32-bit byte offset per lane and layout) + (a
+// compile-time offset per register, which rides in the instruction's immediate field): element (i, lane) for the
+// column layout, (lane, i) for the row layout.  FAST = every chain of the wave is inside the series for the
+// whole loop (all waves but the first / last): the loads of a step are one EXEC-masked block (lanes < D) with no
+// selects behind them, so they stay in flight until their first use.
 template <int D>
 struct Io {
-    unsigned oc[D], orw[D], ov;         // byte offsets: column layout, row layout, vector element `lane`
+    unsigned oc, orw, ov;               // byte offsets of (0, lane), (lane, 0) and vector element `lane`
     bool lv;
     int lane;
     __device__ __forceinline__ void init(int lane_, int row, int Lw) {
         lane = lane_;
         lv = lane < D;
         const unsigned ro = (unsigned)row * (unsigned)Lw * (unsigned)(D * D);
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            oc[i] = lv ? (ro + (unsigned)(i * D + lane)) * 8u : 0u;
-            orw[i] = lv ? (ro + (unsigned)(lane * D + i)) * 8u : 0u;
-        }
+        oc = lv ? (ro + (unsigned)lane) * 8u : 0u;
+        orw = lv ? (ro + (unsigned)(lane * D)) * 8u : 0u;
         ov = lv ? ((unsigned)row * (unsigned)Lw * (unsigned)D + (unsigned)lane) * 8u : 0u;
     }
-    static __device__ __forceinline__ double ld(const double* base, unsigned off) {
-        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off);
-    }
+    template <bool ROWL>
+    static constexpr int step_bytes() { return ROWL ? 8 : 8 * D; }      // from register i to register i + 1
     // fast path: X (lanes < D) <- the matrix; lanes >= D keep their zeros
     template <bool ROWL>
     __device__ __forceinline__ void mat_fast(const double* base, double* X) const {
         if (lv) {
+            const char* p = reinterpret_cast<const char*>(base) + (ROWL ? orw : oc);
 #pragma unroll
-            for (int i = 0; i < D; ++i) X[i] = ld(base, ROWL ? orw[i] : oc[i]);
+            for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const double*>(p + i * step_bytes<ROWL>());
         }
     }
     // general path: rows that are not `real` get dg * I
     template <bool ROWL>
     __device__ __forceinline__ void mat_slow(const double* base, bool real, double dg, double* X) const {
+        const char* p = reinterpret_cast<const char*>(base) + (real ? (ROWL ? orw : oc) : 0u);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            const double v = ld(base, real ? (ROWL ? orw[i] : oc[i]) : 0u);
+            const double v = *reinterpret_cast<const double*>(p + (real && lv ? i * step_bytes<ROWL>() : 0));
             X[i] = (lv && real) ? v : ((i == lane && lv) ? dg : 0.0);
         }
     }
+    // fast path: x (lanes < D) <- the vector element; lanes >= D keep their zero
+    __device__ __forceinline__ void vec_fast(const double* base, double& x) const {
+        if (lv) x = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ov);
+    }
     __device__ __forceinline__ double vec(const double* base, bool real) const {
-        const double v = ld(base, real ? ov : 0u);
+        const double v = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (real ? ov : 0u));
         return (lv && real) ? v : 0.0;
     }
     __device__ __forceinline__ void st_mat(double* base, bool pred, const double* X) const {
         if (lv && pred) {
+            char* p = reinterpret_cast<char*>(base) + oc;
 #pragma unroll
-            for (int i = 0; i < D; ++i) *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + oc[i]) = X[i];
+            for (int i = 0; i < D; ++i) *reinterpret_cast<double*>(p + i * 8 * D) = X[i];
         }
     }
     __device__ __forceinline__ void st_vec(double* base, bool pred, double x) const {
@@ -189,19 +193,20 @@ struct Io {
     }
 };
 
+// The level-1 kernels come as two bodies behind one launch: FAST for waves whose four chains lie entirely inside
+// the series and do not contain its first step (no per-row predicates, no selects behind loads -- a select would
+// put an s_waitcnt vmcnt(0) right after the loads and expose the whole memory latency every step), and the general
+// body for the first and the last wave(s).  Two bodies, two loops: no joins inside the hot loop.
+
 // ====================================================================================================
 // level 1: reduce -- filt_extend over the chunk (pgps_math.h filt_extend, parallel.py:46-72,100-118)
 // ====================================================================================================
-template <int D>
-__global__ __launch_bounds__(64) void rc_reduce1(const RcArgs a) {
-    __shared__ double tl[4 * kPatch];
-    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
+template <int D, bool FAST>
+__device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;        // row 0's first step
     const long c = (long)blockIdx.x * 4 + row;
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
-    const bool fast = blockIdx.x != 0 && kw + 4L * a.Lw <= a.N;
     Io<D> io;
     io.init(lane, row, a.Lw);
     const bool lv = io.lv;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(64) void rc_reduce1(const RcArgs a) {
     // inputs of this row's step kw + row Lw + s; steps outside the chunk and step 0 of the series run as F = I, Q = 0
     auto load = [&](int s) {
         const long ku = kw + s, k = k0 + s;
-        if (fast) {
+        if (FAST) {
             io.template mat_fast<false>(a.Fs + ku * dd, Fc);
             io.template mat_fast<true>(a.Fs + ku * dd, Fr);
             io.template mat_fast<false>(a.Qs + ku * dd, Q);
@@ -265,20 +270,25 @@ __global__ __launch_bounds__(64) void rc_reduce1(const RcArgs a) {
     }
 }
 
+template <int D>
+__global__ __launch_bounds__(64) void rc_reduce1(const RcArgs a) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<D, true>(a, patch, lane, row);
+    else reduce1_body<D, false>(a, patch, lane, row);
+}
+
 // ====================================================================================================
 // level 1: apply -- Kalman pass, log-likelihood, smoothing elements and the chunk's smoothing total
 // (kf_step / smth_element / smth_combine of pgps_math.h; parallel.py:135-151, 155-184)
 // ====================================================================================================
-template <int D, bool SMOOTH>
-__global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
-    __shared__ double tl[4 * kPatch];
-    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
+template <int D, bool SMOOTH, bool FAST>
+__device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
-    const bool fast = kw + 4L * a.Lw + 1 <= a.N;        // every step the wave touches (halo included) is in the series
     Io<D> io;
     io.init(lane, row, a.Lw);
     const bool lv = io.lv, cv = c < a.nchunk;
@@ -301,22 +311,24 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
         for (int i = 0; i < D; ++i) { Ec[i] = (i == lane) ? 1.0 : 0.0; Er[i] = Ec[i]; L[i] = 0.0; }
     }
     LogLik ll;
-    double Fc[D], Fr[D], Q[D];
+    double Fc[D], Fr[D], Q[D], y;
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
     // steps at or beyond N run with F = 0, Q = I: the element built from them is (0, m, P), i.e. the last
     // element of the series (parallel.py:155-156), and a total whose E is 0 absorbs whatever follows unchanged
     auto load = [&](int s) {
         const long ku = kw + s, k = k0 + s;
-        if (fast) {
+        if (FAST) {
             io.template mat_fast<false>(a.Fs + ku * dd, Fc);
             io.template mat_fast<true>(a.Fs + ku * dd, Fr);
             io.template mat_fast<false>(a.Qs + ku * dd, Q);
+            y = a.ys[k];
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
             const bool real = k < a.N;
             io.template mat_slow<false>(a.Fs + kc * dd, real, 0.0, Fc);
             io.template mat_slow<true>(a.Fs + kc * dd, real, 0.0, Fr);
             io.template mat_slow<false>(a.Qs + kc * dd, real, 1.0, Q);
+            y = (s < a.Lw && k < k1) ? a.ys[k] : __builtin_nan("");
         }
     };
     load(0);
@@ -328,6 +340,7 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
         zero<D>(FP); mm<D>(FP, Fc, P);
         copy<D>(Pp, Q); mm<D>(Pp, FP, Fr);
         const double mp = mvr<D>(Fr, m, 0.0);
+        const double yk = y;
         if (s + 1 < iters) load(s + 1);
         symmetrise<D>(Pp, patch, lane);
         if (SMOOTH && s > 0) {
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
 #pragma unroll
             for (int i = 0; i < D; ++i) Ln[i] = P[i] - T[i];
             {
-                const bool st = fast || (k - 1 < k1);
+                const bool st = FAST || (k - 1 < k1);
                 io.st_mat(a.sPs + (ku - 1) * dd, st, En);
                 io.st_mat(a.Lws + (ku - 1) * dd, st, Ln);
                 io.st_vec(a.sms + (ku - 1) * D, st, gn);
@@ -358,14 +371,13 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
             transpose<D>(E2, Er, patch, lane);
         }
         if (s < a.Lw) {
-            const bool upd = fast || k < k1;
-            const double y = upd ? a.ys[k] : __builtin_nan("");
-            const bool obs = !(y != y);
+            const bool upd = FAST || k < k1;
+            const bool obs = !(yk != yk);
             double u = dot_h<D>(Pp, h);
             double S = mvr<D>(h, u, a.R), mu = mvr<D>(h, mp, 0.0);
-            if (obs) ll.add(y - mu, S);
+            if (obs) ll.add(yk - mu, S);
             double mb = mp;
-            if (blockIdx.x == 0 && s == 0) {
+            if (!FAST && blockIdx.x == 0 && s == 0) {
                 // first step of the series (chain 0 only): the update uses the prior itself (parallel.py:24-30),
                 // the likelihood term above used F0 P0 F0^T + Q0 (parallel.py:136-141)
                 const bool first = (c == 0);
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
                 mu = first ? mu0 : mu;
             }
             const double inv = obs ? 1.0 / S : 0.0;
-            const double res = obs ? y - mu : 0.0;
+            const double res = obs ? yk - mu : 0.0;
             m = mb + u * (inv * res);
             copy<D>(P, Pp); rank1<D>(P, u, -u * inv);
             io.st_mat(a.fPs + ku * dd, upd, P);
@@ -397,19 +409,24 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
     }
 }
 
-// ====================================================================================================
-// level 1: smoother -- sm = E sm' + g, sP = E sP' E^T + L from the stored elements (parallel.py:176-184)
-// ====================================================================================================
-template <int D>
-__global__ __launch_bounds__(64) void rc_smooth1(const RcArgs a) {
+template <int D, bool SMOOTH>
+__global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
     __shared__ double tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     double* patch = patch_init(tl, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<D, SMOOTH, true>(a, patch, lane, row);
+    else apply1_body<D, SMOOTH, false>(a, patch, lane, row);
+}
+
+// ====================================================================================================
+// level 1: smoother -- sm = E sm' + g, sP = E sP' E^T + L from the stored elements (parallel.py:176-184)
+// ====================================================================================================
+template <int D, bool FAST>
+__device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
-    const bool fast = kw + 4L * a.Lw <= a.N;
     Io<D> io;
     io.init(lane, row, a.Lw);
     const bool lv = io.lv;
@@ -429,11 +446,10 @@ __global__ __launch_bounds__(64) void rc_smooth1(const RcArgs a) {
     // stored element of this row's step; steps outside the chunk run as the identity element (I, 0, 0)
     auto load = [&](int s) {
         const long ku = kw + s, k = k0 + s;
-        if (fast) {
+        if (FAST) {
             io.template mat_fast<false>(a.sPs + ku * dd, Ec);
-            io.template mat_fast<true>(a.sPs + ku * dd, Er);
             io.template mat_fast<false>(a.Lws + ku * dd, L);
-            g = io.vec(a.sms + ku * D, true);
+            io.vec_fast(a.sms + ku * D, g);
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
             const bool real = k < k1;
@@ -447,16 +463,26 @@ __global__ __launch_bounds__(64) void rc_smooth1(const RcArgs a) {
     for (int s = a.Lw - 1; s >= 0; --s) {
         const long ku = kw + s, k = k0 + s;
         double T[D], nP[D];
+        if (FAST) transpose<D>(Ec, Er, patch, lane);   // E in row layout through LDS: a second global read costs more
         zero<D>(T); mm<D>(T, Ec, sP);
         copy<D>(nP, L); mm<D>(nP, T, Er);
         sm = mvr<D>(Er, sm, g);
         if (s > 0) load(s - 1);
         symmetrise<D>(nP, patch, lane);
         copy<D>(sP, nP);
-        const bool st = fast || k < k1;
+        const bool st = FAST || k < k1;
         io.st_mat(a.sPs + ku * dd, st, sP);
         io.st_vec(a.sms + ku * D, st, sm);
     }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void rc_smooth1(const RcArgs a) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<D, true>(a, patch, lane, row);
+    else smooth1_body<D, false>(a, patch, lane, row);
 }
 
 // ====================================================================================================

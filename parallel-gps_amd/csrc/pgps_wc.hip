@@ -1269,11 +1269,13 @@ int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode) {
     if (ctx->chunk > 0) {
         a.Lw = ctx->chunk;
     } else {
-        // four chains per wave, one wave per SIMD: 4096 chains fill the chip
-        long lw = (sa.N + 4095) / 4096;
+        // four chains per wave; 8192 chains = two waves per SIMD where the registers allow it (measured at 2^20
+        // steps, d = 11: 3.57 ms against 3.73 ms with 4096 chains; the Kogge-Stone levels grow with the count)
+        long lw = (sa.N + 8191) / 8192;
         a.Lw = (int)(lw < 8 ? 8 : lw > 512 ? 512 : lw);
     }
     a.nchunk = (sa.N + a.Lw - 1) / a.Lw;
+    a.wfast = (sa.N - 1) / (4L * a.Lw);         // (w + 1) 4 Lw + 1 <= N
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs;
     const size_t dd = (size_t)d * d, nf = wc::nfilt(d), ns = wc::nsmth(d), nc = (size_t)a.nchunk;

@@ -245,6 +245,189 @@ template <int D> __device__ __forceinline__ void mmB(const double* x, const doub
     for (int i = 0; i < D; ++i) z[i] = zz[i];
 }
 
+__device__ __forceinline__ void rows4p_11(double& a0, double& a1, double& a2, double& a3, double x0, double x1, double x2, double x3, const double* y) {
+    asm("s_nop 4\n"
+        "v_fmac_f64_e32 %0, %4, %8\n"
+        "v_fmac_f64_e32 %1, %5, %8\n"
+        "v_fmac_f64_e32 %2, %6, %8\n"
+        "v_fmac_f64_e32 %3, %7, %8\n"
+        "v_fmac_f64_e32 %0, %4, %9\n"
+        "v_fmac_f64_e32 %1, %5, %9\n"
+        "v_fmac_f64_e32 %2, %6, %9\n"
+        "v_fmac_f64_e32 %3, %7, %9\n"
+        "v_fmac_f64_e32 %0, %4, %10\n"
+        "v_fmac_f64_e32 %1, %5, %10\n"
+        "v_fmac_f64_e32 %2, %6, %10\n"
+        "v_fmac_f64_e32 %3, %7, %10\n"
+        "v_fmac_f64_e32 %0, %4, %11\n"
+        "v_fmac_f64_e32 %1, %5, %11\n"
+        "v_fmac_f64_e32 %2, %6, %11\n"
+        "v_fmac_f64_e32 %3, %7, %11\n"
+        "v_fmac_f64_e32 %0, %4, %12\n"
+        "v_fmac_f64_e32 %1, %5, %12\n"
+        "v_fmac_f64_e32 %2, %6, %12\n"
+        "v_fmac_f64_e32 %3, %7, %12\n"
+        "v_fmac_f64_e32 %0, %4, %13\n"
+        "v_fmac_f64_e32 %1, %5, %13\n"
+        "v_fmac_f64_e32 %2, %6, %13\n"
+        "v_fmac_f64_e32 %3, %7, %13\n"
+        "v_fmac_f64_e32 %0, %4, %14\n"
+        "v_fmac_f64_e32 %1, %5, %14\n"
+        "v_fmac_f64_e32 %2, %6, %14\n"
+        "v_fmac_f64_e32 %3, %7, %14\n"
+        "v_fmac_f64_e32 %0, %4, %15\n"
+        "v_fmac_f64_e32 %1, %5, %15\n"
+        "v_fmac_f64_e32 %2, %6, %15\n"
+        "v_fmac_f64_e32 %3, %7, %15\n"
+        "v_fmac_f64_e32 %0, %4, %16\n"
+        "v_fmac_f64_e32 %1, %5, %16\n"
+        "v_fmac_f64_e32 %2, %6, %16\n"
+        "v_fmac_f64_e32 %3, %7, %16\n"
+        "v_fmac_f64_e32 %0, %4, %17\n"
+        "v_fmac_f64_e32 %1, %5, %17\n"
+        "v_fmac_f64_e32 %2, %6, %17\n"
+        "v_fmac_f64_e32 %3, %7, %17\n"
+        "v_fmac_f64_e32 %0, %4, %18\n"
+        "v_fmac_f64_e32 %1, %5, %18\n"
+        "v_fmac_f64_e32 %2, %6, %18\n"
+        "v_fmac_f64_e32 %3, %7, %18\n"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]), "v"(y[10]));
+}
+__device__ __forceinline__ void rows4p_12(double& a0, double& a1, double& a2, double& a3, double x0, double x1, double x2, double x3, const double* y) {
+    asm("s_nop 4\n"
+        "v_fmac_f64_e32 %0, %4, %8\n"
+        "v_fmac_f64_e32 %1, %5, %8\n"
+        "v_fmac_f64_e32 %2, %6, %8\n"
+        "v_fmac_f64_e32 %3, %7, %8\n"
+        "v_fmac_f64_e32 %0, %4, %9\n"
+        "v_fmac_f64_e32 %1, %5, %9\n"
+        "v_fmac_f64_e32 %2, %6, %9\n"
+        "v_fmac_f64_e32 %3, %7, %9\n"
+        "v_fmac_f64_e32 %0, %4, %10\n"
+        "v_fmac_f64_e32 %1, %5, %10\n"
+        "v_fmac_f64_e32 %2, %6, %10\n"
+        "v_fmac_f64_e32 %3, %7, %10\n"
+        "v_fmac_f64_e32 %0, %4, %11\n"
+        "v_fmac_f64_e32 %1, %5, %11\n"
+        "v_fmac_f64_e32 %2, %6, %11\n"
+        "v_fmac_f64_e32 %3, %7, %11\n"
+        "v_fmac_f64_e32 %0, %4, %12\n"
+        "v_fmac_f64_e32 %1, %5, %12\n"
+        "v_fmac_f64_e32 %2, %6, %12\n"
+        "v_fmac_f64_e32 %3, %7, %12\n"
+        "v_fmac_f64_e32 %0, %4, %13\n"
+        "v_fmac_f64_e32 %1, %5, %13\n"
+        "v_fmac_f64_e32 %2, %6, %13\n"
+        "v_fmac_f64_e32 %3, %7, %13\n"
+        "v_fmac_f64_e32 %0, %4, %14\n"
+        "v_fmac_f64_e32 %1, %5, %14\n"
+        "v_fmac_f64_e32 %2, %6, %14\n"
+        "v_fmac_f64_e32 %3, %7, %14\n"
+        "v_fmac_f64_e32 %0, %4, %15\n"
+        "v_fmac_f64_e32 %1, %5, %15\n"
+        "v_fmac_f64_e32 %2, %6, %15\n"
+        "v_fmac_f64_e32 %3, %7, %15\n"
+        "v_fmac_f64_e32 %0, %4, %16\n"
+        "v_fmac_f64_e32 %1, %5, %16\n"
+        "v_fmac_f64_e32 %2, %6, %16\n"
+        "v_fmac_f64_e32 %3, %7, %16\n"
+        "v_fmac_f64_e32 %0, %4, %17\n"
+        "v_fmac_f64_e32 %1, %5, %17\n"
+        "v_fmac_f64_e32 %2, %6, %17\n"
+        "v_fmac_f64_e32 %3, %7, %17\n"
+        "v_fmac_f64_e32 %0, %4, %18\n"
+        "v_fmac_f64_e32 %1, %5, %18\n"
+        "v_fmac_f64_e32 %2, %6, %18\n"
+        "v_fmac_f64_e32 %3, %7, %18\n"
+        "v_fmac_f64_e32 %0, %4, %19\n"
+        "v_fmac_f64_e32 %1, %5, %19\n"
+        "v_fmac_f64_e32 %2, %6, %19\n"
+        "v_fmac_f64_e32 %3, %7, %19\n"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]), "v"(y[10]), "v"(y[11]));
+}
+__device__ __forceinline__ void rows4p_16(double& a0, double& a1, double& a2, double& a3, double x0, double x1, double x2, double x3, const double* y) {
+    asm("s_nop 4\n"
+        "v_fmac_f64_e32 %0, %4, %8\n"
+        "v_fmac_f64_e32 %1, %5, %8\n"
+        "v_fmac_f64_e32 %2, %6, %8\n"
+        "v_fmac_f64_e32 %3, %7, %8\n"
+        "v_fmac_f64_e32 %0, %4, %9\n"
+        "v_fmac_f64_e32 %1, %5, %9\n"
+        "v_fmac_f64_e32 %2, %6, %9\n"
+        "v_fmac_f64_e32 %3, %7, %9\n"
+        "v_fmac_f64_e32 %0, %4, %10\n"
+        "v_fmac_f64_e32 %1, %5, %10\n"
+        "v_fmac_f64_e32 %2, %6, %10\n"
+        "v_fmac_f64_e32 %3, %7, %10\n"
+        "v_fmac_f64_e32 %0, %4, %11\n"
+        "v_fmac_f64_e32 %1, %5, %11\n"
+        "v_fmac_f64_e32 %2, %6, %11\n"
+        "v_fmac_f64_e32 %3, %7, %11\n"
+        "v_fmac_f64_e32 %0, %4, %12\n"
+        "v_fmac_f64_e32 %1, %5, %12\n"
+        "v_fmac_f64_e32 %2, %6, %12\n"
+        "v_fmac_f64_e32 %3, %7, %12\n"
+        "v_fmac_f64_e32 %0, %4, %13\n"
+        "v_fmac_f64_e32 %1, %5, %13\n"
+        "v_fmac_f64_e32 %2, %6, %13\n"
+        "v_fmac_f64_e32 %3, %7, %13\n"
+        "v_fmac_f64_e32 %0, %4, %14\n"
+        "v_fmac_f64_e32 %1, %5, %14\n"
+        "v_fmac_f64_e32 %2, %6, %14\n"
+        "v_fmac_f64_e32 %3, %7, %14\n"
+        "v_fmac_f64_e32 %0, %4, %15\n"
+        "v_fmac_f64_e32 %1, %5, %15\n"
+        "v_fmac_f64_e32 %2, %6, %15\n"
+        "v_fmac_f64_e32 %3, %7, %15\n"
+        "v_fmac_f64_e32 %0, %4, %16\n"
+        "v_fmac_f64_e32 %1, %5, %16\n"
+        "v_fmac_f64_e32 %2, %6, %16\n"
+        "v_fmac_f64_e32 %3, %7, %16\n"
+        "v_fmac_f64_e32 %0, %4, %17\n"
+        "v_fmac_f64_e32 %1, %5, %17\n"
+        "v_fmac_f64_e32 %2, %6, %17\n"
+        "v_fmac_f64_e32 %3, %7, %17\n"
+        "v_fmac_f64_e32 %0, %4, %18\n"
+        "v_fmac_f64_e32 %1, %5, %18\n"
+        "v_fmac_f64_e32 %2, %6, %18\n"
+        "v_fmac_f64_e32 %3, %7, %18\n"
+        "v_fmac_f64_e32 %0, %4, %19\n"
+        "v_fmac_f64_e32 %1, %5, %19\n"
+        "v_fmac_f64_e32 %2, %6, %19\n"
+        "v_fmac_f64_e32 %3, %7, %19\n"
+        "v_fmac_f64_e32 %0, %4, %20\n"
+        "v_fmac_f64_e32 %1, %5, %20\n"
+        "v_fmac_f64_e32 %2, %6, %20\n"
+        "v_fmac_f64_e32 %3, %7, %20\n"
+        "v_fmac_f64_e32 %0, %4, %21\n"
+        "v_fmac_f64_e32 %1, %5, %21\n"
+        "v_fmac_f64_e32 %2, %6, %21\n"
+        "v_fmac_f64_e32 %3, %7, %21\n"
+        "v_fmac_f64_e32 %0, %4, %22\n"
+        "v_fmac_f64_e32 %1, %5, %22\n"
+        "v_fmac_f64_e32 %2, %6, %22\n"
+        "v_fmac_f64_e32 %3, %7, %22\n"
+        "v_fmac_f64_e32 %0, %4, %23\n"
+        "v_fmac_f64_e32 %1, %5, %23\n"
+        "v_fmac_f64_e32 %2, %6, %23\n"
+        "v_fmac_f64_e32 %3, %7, %23\n"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]), "v"(y[10]), "v"(y[11]), "v"(y[12]), "v"(y[13]), "v"(y[14]), "v"(y[15]));
+}
+template <int D> __device__ __forceinline__ void mmC(const double* x, const double* y, double* z) {
+    constexpr int DR = (D + 3) / 4 * 4;
+    double xx[DR], zz[DR];
+#pragma unroll
+    for (int i = 0; i < DR; ++i) { xx[i] = i < D ? x[i] : 0.0; zz[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < DR; i += 4) {
+        if constexpr (D == 11) rows4p_11(zz[i], zz[i + 1], zz[i + 2], zz[i + 3], xx[i], xx[i + 1], xx[i + 2], xx[i + 3], y);
+        if constexpr (D == 12) rows4p_12(zz[i], zz[i + 1], zz[i + 2], zz[i + 3], xx[i], xx[i + 1], xx[i + 2], xx[i + 3], y);
+        if constexpr (D == 16) rows4p_16(zz[i], zz[i + 1], zz[i + 2], zz[i + 3], xx[i], xx[i + 1], xx[i + 2], xx[i + 3], y);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) z[i] = zz[i];
+}
+
 template <int D, int V>
 __global__ __launch_bounds__(256) void kern(const double* X, const double* Y, double* Z, int iters) {
     const int lane = threadIdx.x & 15;
@@ -256,7 +439,7 @@ __global__ __launch_bounds__(256) void kern(const double* X, const double* Y, do
         y[i] = lane < D ? Y[row * D * D + i * D + lane] : 0.0;
     }
     for (int it = 0; it < iters; ++it) {
-        if (V == 0) mmA<D>(x, y, z); else mmB<D>(x, y, z);
+        if (V == 0) mmA<D>(x, y, z); else if (V == 1) mmB<D>(x, y, z); else mmC<D>(x, y, z);
         if (it + 1 < iters) {
 #pragma unroll
             for (int i = 0; i < D; ++i) { y[i] = z[i] * 0.25; }
@@ -267,8 +450,8 @@ __global__ __launch_bounds__(256) void kern(const double* X, const double* Y, do
 }
 
 template <int D, int V>
-static void run(const char* name) {
-    const int blocks = 1024, threads = 256, rows = blocks * threads / 16;
+static void run(const char* name, int blocks = 1024, int threads = 256) {
+    const int rows = blocks * threads / 16;
     const int iters = 200;
     std::vector<double> X((size_t)rows * D * D), Y(X.size()), Z(X.size()), Zr(X.size());
     srand(1);
@@ -282,7 +465,7 @@ static void run(const char* name) {
     kern<D, V><<<blocks, threads>>>(dX, dY, dZ, 3);
     hipMemcpy(Z.data(), dZ, X.size() * 8, hipMemcpyDeviceToHost);
     double maxerr = 0;
-    for (int r = 0; r < 64; ++r) {
+    for (int r = 0; r < 64 && V != 2; ++r) {
         std::vector<double> y(Y.begin() + (size_t)r * D * D, Y.begin() + (size_t)(r + 1) * D * D), z(D * D);
         const double* x = &X[(size_t)r * D * D];
         for (int it = 0; it < 3; ++it) {
@@ -300,17 +483,19 @@ static void run(const char* name) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double fma_lane = (double)blocks * threads * iters * D * D;      // lane-FMAs issued (incl. idle lanes)
     const double useful = (double)rows * iters * D * D * D;
-    printf("%s D=%d: maxerr %.3e  %.3f ms  issued %.2f T lane-FMA/s (peak 39.3)  useful %.2f TFLOP/s\n", name, D, maxerr, ms,
+    printf("[%d x %d] %s D=%d: maxerr %.3e  %.3f ms  issued %.2f T lane-FMA/s (peak 39.3)  useful %.2f TFLOP/s\n", blocks, threads, name, D, maxerr, ms,
            fma_lane / ms * 1e-9, 2 * useful / ms * 1e-9);
     hipFree(dX); hipFree(dY); hipFree(dZ);
 }
 
 int main() {
-    run<11, 0>("mov_dpp+fma ");
-    run<11, 1>("fmac_dpp asm");
-    run<12, 0>("mov_dpp+fma ");
-    run<12, 1>("fmac_dpp asm");
-    run<16, 0>("mov_dpp+fma ");
-    run<16, 1>("fmac_dpp asm");
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        run<12, 0>("mov_dpp+fma ", 256 * wps, 256);
+        run<12, 1>("fmac_dpp asm", 256 * wps, 256);
+        run<12, 2>("plain fmac  ", 256 * wps, 256);
+    }
+    run<11, 1>("fmac_dpp asm", 1024, 64);
+    run<16, 1>("fmac_dpp asm", 1024, 64);
+    run<16, 2>("plain fmac  ", 1024, 64);
     return 0;
 }
