@@ -393,6 +393,12 @@ static int pkfs_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, cons
 template <typename T>
 static int disc_dev(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
     if (!ctx || N < 1 || !F || !Pinf || !ts || !Fs || !Qs) return PGPS_E_INVALID;
+    if constexpr (sizeof(T) == 8) {
+        const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
+        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)))
+            return launch_disc_rc(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
+    }
+    if (ctx->family == 3) return PGPS_E_UNSUPPORTED_DIM;
     if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_disc_wc<T>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
     switch (d) {
         case 1: return launch_disc<T, 1>(ctx, N, F, Pinf, ts, t0, Fs, Qs);

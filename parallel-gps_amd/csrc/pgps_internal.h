@@ -188,6 +188,8 @@ template <typename T>
 int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);
 // row-cooperative family (pgps_rc.hip.h): fp64, 2 <= d <= 16, pkf / pkfs
 int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode);
+int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* ts, double t0,
+                   double* Fs, double* Qs);
 namespace rc {
 constexpr int kDimMin = 2, kDimMax = 16;
 struct RcArgs {
@@ -211,6 +213,9 @@ template <int D>
 int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase);
 template <int D>
 int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out);
+template <int D>
+int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, const double* ts, double t0, double* Fs,
+                   double* Qs);
 }  // namespace rc
 template <typename T>
 int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);

@@ -113,6 +113,14 @@ __device__ __forceinline__ double* patch_init(double* tl, int row) {
 template <int K>
 __device__ __forceinline__ double bcast(double x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + K, 0xf, 0xf, true); }
 
+// maximum of a distributed vector over the row (every lane gets it)
+template <int D, int K = 0>
+__device__ __forceinline__ double mvr_max(double v) {
+    const double t = bcast<K>(v);
+    if constexpr (K + 1 < D) return fmax(t, mvr_max<D, K + 1>(v));
+    else return t;
+}
+
 // Gauss-Jordan without pivoting (M symmetric positive definite): B <- M^-1 B.  Row operations in column layout:
 // row_r -= M[r][c] * row_c / M[c][c], the factor M[r][c] being lane c's register r broadcast to the row.
 // M is destroyed.
@@ -641,6 +649,97 @@ __global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const 
     }
 }
 
+// ====================================================================================================
+// LTI discretisation (kernels/base.py:29-47): Fs[k] = expm(dt_k F) by Pade-13 scaling and squaring (what
+// tf.linalg.expm implements), Qs[k] = Pinf - Fs[k] Pinf Fs[k]^T (equal to the reference's matrix-fraction
+// expression because Pinf solves the Lyapunov equation; tests/test_oracle.py).  One ROW per time step, every
+// matrix in registers; a wave takes `per` steps per row one after the other.
+// ====================================================================================================
+template <int D>
+__global__ __launch_bounds__(64) void rc_discretise(long N, int per, const double* Fg, const double* Pg, const double* ts,
+                                                    double t_prev, double* Fs, double* Qs) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    constexpr int dd = D * D;
+    const bool lv = lane < D;
+    const double b[14] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
+                          129060195264000., 10559470521600., 670442572800., 33522128640.,
+                          1323241920., 40840800., 960960., 16380., 182., 1.};
+    double F[D], Pm[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        F[i] = lv ? Fg[i * D + lane] : 0.0;
+        Pm[i] = lv ? 0.5 * (Pg[i * D + lane] + Pg[lane * D + i]) : 0.0;
+    }
+    // 1-norm of F: column sums are lane-local, the maximum goes round the row
+    double colsum = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) colsum += __builtin_fabs(F[i]);
+    double normF = mvr_max<D>(colsum);
+    for (int q = 0; q < per; ++q) {
+        const long k = ((long)blockIdx.x * per + q) * 4 + row;
+        const bool kv = k < N;
+        const long kc = kv ? k : N - 1;
+        const double dt = ts[kc] - (kc > 0 ? ts[kc - 1] : t_prev);
+        int sq = 0;
+        const double nrm = __builtin_fabs(dt) * normF;
+        if (nrm > 5.371920351148152) {
+            sq = (int)ceil(log2(nrm / 5.371920351148152));
+            sq = sq < 0 ? 0 : (sq > 60 ? 60 : sq);
+        }
+        const double sc = ldexp(dt, -sq);
+        double A[D], A2[D], A4[D], A6[D], W[D], Z[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) A[i] = sc * F[i];
+        zero<D>(A2); mm<D>(A2, A, A);
+        zero<D>(A4); mm<D>(A4, A2, A2);
+        zero<D>(A6); mm<D>(A6, A4, A2);
+        // U = A (A6 (b13 A6 + b11 A4 + b9 A2) + b7 A6 + b5 A4 + b3 A2 + b1 I)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            W[i] = b[13] * A6[i] + b[11] * A4[i] + b[9] * A2[i];
+            Z[i] = b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i] + ((i == lane) ? b[1] : 0.0);
+        }
+        mm<D>(Z, A6, W);
+        double U[D], V[D];
+        zero<D>(U); mm<D>(U, A, Z);
+        // V = A6 (b12 A6 + b10 A4 + b8 A2) + b6 A6 + b4 A4 + b2 A2 + b0 I
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            W[i] = b[12] * A6[i] + b[10] * A4[i] + b[8] * A2[i];
+            V[i] = b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i] + ((i == lane) ? b[0] : 0.0);
+        }
+        mm<D>(V, A6, W);
+        // (V - U) R = V + U; lanes >= D get a unit diagonal nowhere (their columns are zero and never pivot)
+        double M[D], R[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { M[i] = V[i] - U[i]; R[i] = V[i] + U[i]; }
+        GjPivStep<D, 0>::run(M, R);
+        // squarings: the count differs between the rows of a wave
+        int smax = sq;
+        smax = max(smax, __shfl_xor(smax, 16, 64));
+        smax = max(smax, __shfl_xor(smax, 32, 64));
+        for (int t = 0; t < smax; ++t) {
+            double R2[D];
+            zero<D>(R2); mm<D>(R2, R, R);
+            const bool on = t < sq;
+#pragma unroll
+            for (int i = 0; i < D; ++i) R[i] = on ? R2[i] : R[i];
+        }
+        // Q = Pinf - sym(R Pinf R^T)
+        double T[D], Rr[D], X[D];
+        zero<D>(T); mm<D>(T, R, Pm);
+        transpose<D>(R, Rr, patch, lane);
+        zero<D>(X); mm<D>(X, T, Rr);
+        symmetrise<D>(X, patch, lane);
+        if (lv && kv) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) { Fs[k * dd + i * D + lane] = R[i]; Qs[k * dd + i * D + lane] = Pm[i] - X[i]; }
+        }
+    }
+}
+
 // ---- host side: the level-1 launches of one instantiation ---------------------------------------------
 // phase 0: reduce, 1: apply + smoothing elements, 2: apply only, 3: smoother
 template <int D>
@@ -662,6 +761,16 @@ int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in
     const dim3 blk(64), g((unsigned)((n + 3) / 4));
     if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<D>, g, blk, 0u, n, stride, in, out);
     else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<D>, g, blk, 0u, n, stride, in, out);
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+template <int D>
+int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, const double* ts, double t0, double* Fs,
+                   double* Qs) {
+    const int per = 8;                          // steps per row: amortises the model load and the norm
+    const long grid = (N + 4L * per - 1) / (4L * per);
+    timed_launch(ctx, PGPS_K_DISCRETISE, rc_discretise<D>, dim3((unsigned)grid), dim3(64), 0u, N, per, F, Pinf, ts, t0, Fs, Qs);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

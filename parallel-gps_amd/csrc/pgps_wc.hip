@@ -1202,6 +1202,21 @@ template int launch_scan_wc<float>(pgps_ctx*, ScanArgs<float>, int, Mode);
 // ====================================================================================================
 namespace rc {
 
+// sum of the chains' log-likelihood partials: one workgroup of 16 waves, fixed order (bit-reproducible)
+static __global__ __launch_bounds__(1024) void ll_finalize(const double* llpart, long n, double* ll) {
+    __shared__ double part[16];
+    double t = 0.0;
+    for (long c = threadIdx.x; c < n; c += 1024) t += llpart[c];
+    t = wc::wave_sum(t);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += part[w];
+        *ll = s;
+    }
+}
+
 static int level1(pgps_ctx* ctx, int d, const RcArgs& a, int phase) {
     switch (d) {
 #define PGPS_RC_CASE(DV) case DV: return launch_rc_level1<DV>(ctx, a, phase);
@@ -1249,13 +1264,26 @@ static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, doub
         if ((rcode = level1(ctx, d, a, 2))) return rcode;
     }
     if (ll)
-        timed_launch(ctx, PGPS_K_LL_FINALIZE, wc::wc_ll_finalize, dim3(1), dim3(64), 0u, (const double*)a.llpart,
+        timed_launch(ctx, PGPS_K_LL_FINALIZE, ll_finalize, dim3(1), dim3(1024), 0u, (const double*)a.llpart,
                      (long)a.nchunk, ll);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }
 
 }  // namespace rc
+
+int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* ts, double t0,
+                   double* Fs, double* Qs) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    switch (d) {
+#define PGPS_RC_CASE(DV) case DV: return rc::launch_rc_disc<DV>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
+        PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
+        PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
+        PGPS_RC_CASE(15) PGPS_RC_CASE(16)
+#undef PGPS_RC_CASE
+    }
+    return PGPS_E_UNSUPPORTED_DIM;
+}
 
 static inline size_t rc_align(size_t x) { return (x + 255) / 256 * 256; }
 

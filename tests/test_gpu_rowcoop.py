@@ -96,6 +96,36 @@ def test_rowcoop_state_dims(name):
     assert abs(float(ll) - want["ll"][0]) < tol * abs(want["ll"][0])
     sms, sPs = pkfs(ssm, y[:, None])
     assert relerr(sms, want["sms"]) < tol and relerr(sPs, want["sPs"]) < tol
+    # discretisation of the same model on the GPU vs the reference's matrix-fraction formula
+    from pssgp import _backend as B
+    gFs, gQs = B.discretise(sde.F, sde.P0, t, 0.0)
+    assert np.max(np.abs(gFs - ssm[1])) < 1e-10 * max(1.0, float(np.max(np.abs(ssm[1]))))
+    assert np.max(np.abs(gQs - ssm[2])) < 1e-10 * max(1.0, float(np.max(np.abs(ssm[0]))))
+
+
+@pytest.mark.parametrize("name", ["rbf7", "c5_qp_m52", "periodic7"])
+def test_rowcoop_discretise_mixed_step_sizes(name):
+    """Steps from 1e-4 to 40 time units in one series: zero to several squarings, different in the four rows of
+    a wave; a repeated time stamp (dt = 0: F = I, Q = 0); ragged length."""
+    from pssgp import _backend as B
+    sde = _kernels()[name]().get_sde()
+    rng = np.random.default_rng(12)
+    n = 1003
+    dt = 10.0 ** rng.uniform(-4, 1.6, n)
+    dt[17] = 0.0
+    t = np.cumsum(dt)
+    ssm = O.get_ssm(sde, t, 0.1)
+    gFs, gQs = B.discretise(sde.F, sde.P0, t, 0.0)
+    scale = max(1.0, float(np.max(np.abs(ssm[0]))))
+    assert np.max(np.abs(gFs - ssm[1])) < 1e-9 * max(1.0, float(np.max(np.abs(ssm[1]))))
+    # the reference's matrix-fraction Q (kernels/base.py:39-46) exponentiates -F^T as well and loses all digits
+    # once dt * |F| is large; it is the yardstick for the short steps, P - F P F^T from the oracle's F for all
+    short = dt < 0.3
+    assert np.max(np.abs(gQs[short] - ssm[2][short])) < 1e-9 * scale
+    P = np.asarray(ssm[0])
+    q_stable = P[None] - np.einsum("kij,jl,kml->kim", ssm[1], P, ssm[1])
+    assert np.max(np.abs(gQs - q_stable)) < 1e-9 * scale
+    assert np.max(np.abs(gFs[17] - np.eye(gFs.shape[1]))) < 1e-15 and np.max(np.abs(gQs[17])) < 1e-14 * scale
 
 
 def test_rowcoop_first_observation_missing_and_all_missing(row_family):
