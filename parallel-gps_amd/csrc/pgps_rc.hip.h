@@ -121,13 +121,22 @@ __device__ __forceinline__ double mvr_max(double v) {
     else return t;
 }
 
+// 1 / x by v_rcp_f64 and two Newton steps (the IEEE division sequence is ~25 instructions, this is 5; pivots of
+// a positive definite matrix need neither the denormal nor the overflow path)
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // Gauss-Jordan without pivoting (M symmetric positive definite): B <- M^-1 B.  Row operations in column layout:
 // row_r -= M[r][c] * row_c / M[c][c], the factor M[r][c] being lane c's register r broadcast to the row.
 // M is destroyed.
 template <int D, int C>
 struct GjStep {
     static __device__ __forceinline__ void run(double* M, double* B) {
-        const double inv = 1.0 / bcast<C>(M[C]);
+        const double inv = rcp_nr(bcast<C>(M[C]));
         const double mc = M[C] * inv, bv = B[C] * inv;
         if constexpr (D <= 8) {
             Gj<D, C>::run(M, B, -mc, -bv);
