@@ -180,14 +180,17 @@ struct Io {
             for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const double*>(p + i * step_bytes<ROWL>());
         }
     }
-    // general path: rows that are not `real` get dg * I
+    // general path: rows that are not `real` get dg * I.  One divergent if / else around the whole block, no
+    // selects behind the loads (a select would wait for them on the spot).
     template <bool ROWL>
     __device__ __forceinline__ void mat_slow(const double* base, bool real, double dg, double* X) const {
-        const char* p = reinterpret_cast<const char*>(base) + (real ? (ROWL ? orw : oc) : 0u);
+        if (lv && real) {
+            const char* p = reinterpret_cast<const char*>(base) + (ROWL ? orw : oc);
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const double v = *reinterpret_cast<const double*>(p + (real && lv ? i * step_bytes<ROWL>() : 0));
-            X[i] = (lv && real) ? v : ((i == lane && lv) ? dg : 0.0);
+            for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const double*>(p + i * step_bytes<ROWL>());
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) X[i] = (i == lane && lv) ? dg : 0.0;
         }
     }
     // fast path: x (lanes < D) <- the vector element; lanes >= D keep their zero
@@ -195,8 +198,9 @@ struct Io {
         if (lv) x = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ov);
     }
     __device__ __forceinline__ double vec(const double* base, bool real) const {
-        const double v = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (real ? ov : 0u));
-        return (lv && real) ? v : 0.0;
+        double v = 0.0;
+        if (lv && real) v = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ov);
+        return v;
     }
     __device__ __forceinline__ void st_mat(double* base, bool pred, const double* X) const {
         if (lv && pred) {
@@ -254,7 +258,8 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
             io.template mat_slow<false>(a.Fs + kc * dd, real, 1.0, Fc);
             io.template mat_slow<true>(a.Fs + kc * dd, real, 1.0, Fr);
             io.template mat_slow<false>(a.Qs + kc * dd, real, 0.0, Q);
-            y = k < k1 ? a.ys[k] : __builtin_nan("");
+            y = __builtin_nan("");
+            if (k < k1) y = a.ys[k];
         }
     };
     load(0);
@@ -322,10 +327,10 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
         for (int i = 0; i < D; ++i)
             P[i] = !lv ? 0.0 : pr ? rec[dd + i * D + lane] : (c == 0 ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0);
     }
-    double Ec[D], Er[D], L[D], g = 0.0;        // smoothing total of the steps seen so far (E in both layouts)
+    double Ec[D], L[D], g = 0.0;               // smoothing total of the steps seen so far
     if (SMOOTH) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) { Ec[i] = (i == lane) ? 1.0 : 0.0; Er[i] = Ec[i]; L[i] = 0.0; }
+        for (int i = 0; i < D; ++i) { Ec[i] = (i == lane) ? 1.0 : 0.0; L[i] = 0.0; }
     }
     LogLik ll;
     double Fc[D], Fr[D], Q[D], y;
@@ -345,7 +350,8 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             io.template mat_slow<false>(a.Fs + kc * dd, real, 0.0, Fc);
             io.template mat_slow<true>(a.Fs + kc * dd, real, 0.0, Fr);
             io.template mat_slow<false>(a.Qs + kc * dd, real, 1.0, Q);
-            y = (s < a.Lw && k < k1) ? a.ys[k] : __builtin_nan("");
+            y = __builtin_nan("");
+            if (s < a.Lw && k < k1) y = a.ys[k];
         }
     };
     load(0);
@@ -358,7 +364,10 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
         copy<D>(Pp, Q); mm<D>(Pp, FP, Fr);
         const double mp = mvr<D>(Fr, m, 0.0);
         const double yk = y;
-        if (s + 1 < iters) load(s + 1);
+        // Next step's inputs.  The filter-only kernel has the registers to fetch them a whole step ahead; with
+        // the smoothing total on board the fetch waits until the end of the step so that the kernel fits 256
+        // registers and two waves share a SIMD (they cover each other's latency instead).
+        if (!SMOOTH && s + 1 < iters) load(s + 1);
         symmetrise<D>(Pp, patch, lane);
         if (SMOOTH && s > 0) {
             // element of step k-1: W = Pp^-1 F P = E^T (i.e. E in row layout), g = m - E mp, L = P - E F P
@@ -381,11 +390,12 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             double E2[D];
             zero<D>(E2); mm<D>(E2, Ec, En);
             zero<D>(T); mm<D>(T, Ec, Ln);
+            double Er[D];                       // the total's E in row layout, made where it is used
+            transpose<D>(Ec, Er, patch, lane);
             g = mvr<D>(Er, gn, g);
             mm<D>(L, T, Er);
             symmetrise<D>(L, patch, lane);
             copy<D>(Ec, E2);
-            transpose<D>(E2, Er, patch, lane);
         }
         if (s < a.Lw) {
             const bool upd = FAST || k < k1;
@@ -414,6 +424,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             io.st_mat(a.fPs + ku * dd, upd, P);
             io.st_vec(a.fms + ku * D, upd, m);
         }
+        if (SMOOTH && s + 1 < iters) load(s + 1);
     }
     if (cv) {
         if (SMOOTH && lv) {
