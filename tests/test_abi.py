@@ -71,3 +71,36 @@ def test_sequential_mode_matches_oracle(dtype):
         assert relerr(fms, of) < tol and relerr(fPs, oP) < tol
         assert relerr(sms, os_) < tol and relerr(sPs, osP) < tol
         assert abs(float(ll) - oll) < tol * abs(oll)
+
+
+def test_generated_asm_header_is_current():
+    """csrc/pgps_rc_asm.h (the DPP building blocks of the row-cooperative kernels) is generated: the committed
+    file must be what tools/gen_rc_asm.py writes, and every block must follow the hazard rules it documents."""
+    import io
+    import os
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import gen_rc_asm
+    finally:
+        sys.path.pop(0)
+    buf = io.StringIO()
+    gen_rc_asm.emit(buf)
+    text = open(os.path.join(root, "parallel-gps_amd", "csrc", "pgps_rc_asm.h")).read()
+    assert buf.getvalue() == text
+    blocks = re.findall(r"asm volatile\((.*?)\);", text, flags=re.S)
+    assert len(blocks) > 90
+    for b in blocks:
+        lines = [ln.strip().strip('"') for ln in b.split("\n") if "v_fmac" in ln or "s_nop" in ln]
+        assert lines[0].startswith("s_nop 4"), "every block opens with the DPP entry wait states"
+        written = set()
+        for ln in lines[1:]:
+            m = re.match(r"v_fmac_f64_dpp %(\d+), %(\d+), %(\d+) row_newbcast", ln)
+            assert m, ln
+            dst, src0 = int(m.group(1)), int(m.group(2))
+            # a DPP source is never a register an earlier instruction of the block wrote, except the
+            # elimination's own accumulator (read and written by the same instruction, after its last DPP use)
+            assert src0 not in written or src0 == dst, ln
+            written.add(dst)
