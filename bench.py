@@ -398,6 +398,46 @@ def main():
                          "GPU-event time, not part of `value`")
         out["fused_path"] = fused
 
+    # ---- general-LTI device path (any kernel, fp64, 2 <= d <= 16): ts, ys in, results out ---------------------
+    if (rank == 0 and world == 1 and args.path == "lgssm" and dtype_np == np.float64 and 2 <= d <= 16
+            and _backend.nilpotent_form(sde.F) is None):
+        F_h = np.ascontiguousarray(sde.F, np.float64)
+        Pinf_h = np.ascontiguousarray(sde.P0, np.float64)
+        H_h = np.ascontiguousarray(np.asarray(sde.H, np.float64).reshape(-1))
+        HP = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+        kq = max(1, n_local // 4)
+        tq_d = (torch.rand(kq, dtype=torch.float64, device=dev) * float(ts_d[-1].item())).sort().values
+        pm_d = torch.empty(kq, dtype=torch.float64, device=dev)
+        pv_d = torch.empty(kq, dtype=torch.float64, device=dev)
+
+        def lti_ll_step():
+            ctx.call("pgps_lti_ll_dev_f64", ctypes.c_long(n_local), ctypes.c_int(d), HP(F_h), HP(Pinf_h), HP(H_h),
+                     ctypes.c_double(noise), P(ts_d), P(ys_d), ctypes.c_double(t_prev), P(ll_d))
+
+        def lti_predict_step():
+            ctx.call("pgps_lti_predict_dev_f64", ctypes.c_long(n_local), ctypes.c_long(kq), ctypes.c_int(d), HP(F_h),
+                     HP(Pinf_h), HP(H_h), ctypes.c_double(noise), P(ts_d), P(ys_d), ctypes.c_double(t_prev), P(tq_d),
+                     P(pm_d), P(pv_d), P(ll_d))
+
+        lti = {}
+        for name, fn, steps in (("log-lik only (discretise + filter)", lti_ll_step, n_local),
+                                (f"predict_f on device (N train + N/4 = {kq} queries)", lti_predict_step, n_local + kq)):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = min(args.steps, 10)
+            e0.record(stream)
+            for _ in range(reps):
+                fn()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / reps
+            lti[name] = {"ms_per_step": ms, "timesteps_per_s": steps / ms * 1e3, "log_likelihood": float(ll_d[0].item())}
+        lti["note"] = ("pgps_lti_*_dev_f64: discretisation, scan and projection on the device, inputs are (ts, ys[, tq]) "
+                       "only; GPU-event time, not part of `value`")
+        out["lti_path"] = lti
+
     # ---- CPU baseline: the oracle's C restatement of the reference's sequential path ----------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle

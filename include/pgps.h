@@ -179,6 +179,28 @@ int pgps_gp_f32(pgps_ctx*, long N, int d, double lam, const double* N1, const do
                 const double* H, double R, const float* ts, double t0, const float* ys, float* fms, float* fPs,
                 float* sms, float* sPs, double* ll);
 
+/* ---- general LTI models on the device: any kernel, fp64, 2 <= d <= 16 ------------------------------
+ * The chain  _get_ssm (pssgp/kernels/base.py:29-47) -> pkf / pkfs (parallel.py:121-201) that StateSpaceGP runs
+ * (pssgp/model.py:92-117) for kernels without the closed-form discretisation (RBF, Periodic, sums, products),
+ * with only the results leaving the GPU.  The model F (d,d), Pinf (d,d) (= P0, the stationary covariance: Qs =
+ * Pinf - Fs Pinf Fs^T), H (d) is always passed from HOST memory; ts, ys, tq, mean, var, ll are host pointers for
+ * the plain entry points and device pointers for the _dev ones.
+ *   pgps_lti_ll_*      : discretise, filter, log-likelihood -- nothing is written per step
+ *   pgps_lti_predict_* : merge of the sorted ts (N) and tq (K) exactly as _merge_sorted (model.py:15-55), missing
+ *                        observations at the query rows, discretise, filter + smoother over the N + K steps,
+ *                        mean[j] = H sm, var[j] = H sP H^T of query j; ll (nullable) = log-likelihood of the
+ *                        training series.  N + K < 2^31. */
+int pgps_lti_ll_f64(pgps_ctx*, long N, int d, const double* F, const double* Pinf, const double* H, double R,
+                    const double* ts, const double* ys, double t0, double* ll);
+int pgps_lti_ll_dev_f64(pgps_ctx*, long N, int d, const double* F, const double* Pinf, const double* H, double R,
+                        const double* ts, const double* ys, double t0, double* ll);
+int pgps_lti_predict_f64(pgps_ctx*, long N, long K, int d, const double* F, const double* Pinf, const double* H,
+                         double R, const double* ts, const double* ys, double t0, const double* tq, double* mean,
+                         double* var, double* ll);
+int pgps_lti_predict_dev_f64(pgps_ctx*, long N, long K, int d, const double* F, const double* Pinf, const double* H,
+                             double R, const double* ts, const double* ys, double t0, const double* tq, double* mean,
+                             double* var, double* ll);
+
 /* ---- predict_f on the device (fused path, d <= 3) --------------------------------------------------
  * StateSpaceGP.predict_f (pssgp/model.py:92-111) in one call: the sorted training times `ts` (N) and
  * sorted query times `tq` (K) are merged on the device exactly as _merge_sorted does (model.py:15-55:

@@ -85,6 +85,8 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
     if (ctx->status_word) (void)hipFree(ctx->status_word);
     for (auto& b : ctx->st)
         if (b.p) (void)hipFree(b.p);
+    for (auto& b : ctx->lti)
+        if (b.p) (void)hipFree(b.p);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -863,6 +865,105 @@ static int gp_predict_host(pgps_ctx* ctx, long N, long K, int d, double lam, con
 
 PGPS_DEFINE_PREDICT(f64, double)
 PGPS_DEFINE_PREDICT(f32, float)
+
+// ---------------------------------------------------------------------------------------------
+// general LTI models on the device (fp64, 2 <= d <= 16): _get_ssm -> pkf / pkfs for any kernel, with
+// nothing but the results leaving the GPU (row-cooperative kernels, pgps_rc.hip.h)
+// ---------------------------------------------------------------------------------------------
+static int lti_dev(pgps_ctx* ctx, long N, long K, int d, const double* F, const double* Pinf, const double* H, double R,
+                   const double* ts, const double* ys, double t0, const double* tq, double* mean, double* var,
+                   double* ll) {
+    if (!ctx || N < 1 || K < 0 || !F || !Pinf || !H || !ts || !ys) return PGPS_E_INVALID;
+    if (K > 0 && (!tq || !mean || !var)) return PGPS_E_INVALID;
+    if (K == 0 && !ll) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
+    if (N + K > 0x7fffffffL) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t m = (size_t)(N + K), dd = (size_t)d * d;
+    // the small model: [F | Pinf | H] from host memory
+    double* model;
+    TRY(ensure(ctx, ctx->lti[0], (2 * dd + d) * sizeof(double)));
+    model = (double*)ctx->lti[0].p;
+    HIPCHK(ctx, hipMemcpyAsync(model, F, dd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(model + dd, Pinf, dd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(model + 2 * dd, H, d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // the pageable host sources may change after return: the copies above are staged by the runtime before it
+    // returns (pageable memcpy semantics), so no synchronisation is needed here
+    const double *ts_m = ts, *ys_m = ys;
+    int* qslot = nullptr;
+    if (K > 0) {
+        double *tsm, *ysm;
+        TRY(stage_in<double>(ctx, ctx->lti[1], nullptr, m, &tsm));
+        TRY(stage_in<double>(ctx, ctx->lti[2], nullptr, m, &ysm));
+        TRY(stage_in<int>(ctx, ctx->lti[3], nullptr, m, &qslot));
+        TRY(launch_merge<double>(ctx, N, K, ts, ys, tq, tsm, ysm, qslot));
+        ts_m = tsm; ys_m = ysm;
+    }
+    double *Fs, *Qs, *dll;
+    TRY(stage_in<double>(ctx, ctx->lti[4], nullptr, m * dd, &Fs));
+    TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, m * dd, &Qs));
+    TRY(stage_in<double>(ctx, ctx->st[11], nullptr, 2, &dll));
+    TRY(launch_disc_rc(ctx, (long)m, d, model, model + dd, ts_m, t0, Fs, Qs));
+    ScanArgs<double> a{};
+    a.N = (long)m; a.seg_first = 1; a.seg_last = 1;
+    a.P0 = model + dd; a.H = model + 2 * dd; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys_m;
+    a.ll = ll ? ll : dll;
+    if (K == 0) return launch_scan_rc_proj(ctx, a, d, MODE_PKF, nullptr, nullptr, nullptr);
+    // scratch for the smoothing elements (E, g) where pkfs would have sPs, sms
+    TRY(stage_in<double>(ctx, ctx->lti[6], nullptr, m * dd, &a.sPs));
+    TRY(stage_in<double>(ctx, ctx->lti[7], nullptr, m * d, &a.sms));
+    return launch_scan_rc_proj(ctx, a, d, MODE_PKFS, qslot, mean, var);
+}
+
+static int lti_host(pgps_ctx* ctx, long N, long K, int d, const double* F, const double* Pinf, const double* H, double R,
+                    const double* ts, const double* ys, double t0, const double* tq, double* mean, double* var,
+                    double* ll) {
+    if (!ctx || N < 1 || K < 0 || !ts || !ys) return PGPS_E_INVALID;
+    if (K > 0 && (!tq || !mean || !var)) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *dts, *dys, *dtq = nullptr, *dmean = nullptr, *dvar = nullptr, *dll;
+    TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
+    TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));
+    if (K > 0) {
+        TRY(stage_in(ctx, ctx->st[3], tq, (size_t)K, &dtq));
+        TRY(stage_in<double>(ctx, ctx->st[7], nullptr, (size_t)K, &dmean));
+        TRY(stage_in<double>(ctx, ctx->st[8], nullptr, (size_t)K, &dvar));
+    }
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, 2, &dll));
+    TRY(lti_dev(ctx, N, K, d, F, Pinf, H, R, dts, dys, t0, dtq, dmean, dvar, dll));
+    if (K > 0) {
+        TRY(stage_out(ctx, mean, dmean, (size_t)K));
+        TRY(stage_out(ctx, var, dvar, (size_t)K));
+    }
+    double llh = 0.0;
+    TRY(stage_out(ctx, &llh, dll, 1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ll) *ll = llh;
+    if (!std::isfinite(llh)) return PGPS_E_NUMERIC;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_lti_ll_f64(pgps_ctx* c, long N, int d, const double* F, const double* Pinf, const double* H, double R,
+                               const double* ts, const double* ys, double t0, double* ll) {
+    if (!ll) return PGPS_E_INVALID;
+    return lti_host(c, N, 0, d, F, Pinf, H, R, ts, ys, t0, nullptr, nullptr, nullptr, ll);
+}
+extern "C" int pgps_lti_ll_dev_f64(pgps_ctx* c, long N, int d, const double* F, const double* Pinf, const double* H,
+                                   double R, const double* ts, const double* ys, double t0, double* ll) {
+    return lti_dev(c, N, 0, d, F, Pinf, H, R, ts, ys, t0, nullptr, nullptr, nullptr, ll);
+}
+extern "C" int pgps_lti_predict_f64(pgps_ctx* c, long N, long K, int d, const double* F, const double* Pinf,
+                                    const double* H, double R, const double* ts, const double* ys, double t0,
+                                    const double* tq, double* mean, double* var, double* ll) {
+    if (K < 1) return PGPS_E_INVALID;
+    return lti_host(c, N, K, d, F, Pinf, H, R, ts, ys, t0, tq, mean, var, ll);
+}
+extern "C" int pgps_lti_predict_dev_f64(pgps_ctx* c, long N, long K, int d, const double* F, const double* Pinf,
+                                        const double* H, double R, const double* ts, const double* ys, double t0,
+                                        const double* tq, double* mean, double* var, double* ll) {
+    if (K < 1) return PGPS_E_INVALID;
+    return lti_dev(c, N, K, d, F, Pinf, H, R, ts, ys, t0, tq, mean, var, ll);
+}
 
 // ---------------------------------------------------------------------------------------------
 // batched log-likelihood: B hyper-parameter settings over one series

@@ -27,6 +27,7 @@ struct pgps_ctx {
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
+    DevBuf lti[8];                      // general-LTI entry points: model, merged series, Fs, Qs, E, g
     DevBuf stamps;                      // diagnostic build only
     int* status_word = nullptr;         // device word kernels raise flags in (pgps_status)
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
@@ -188,6 +189,10 @@ template <typename T>
 int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);
 // row-cooperative family (pgps_rc.hip.h): fp64, 2 <= d <= 16, pkf / pkfs
 int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode);
+// the same with nothing written per step: MODE_PKF = log-likelihood only; MODE_PKFS = H sm, H sP H^T at the steps
+// qslot marks (a.sPs / a.sms are then scratch of N d^2 / N d doubles for the smoothing elements)
+int launch_scan_rc_proj(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode, const int* qslot, double* pmean,
+                        double* pvar);
 int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* ts, double t0,
                    double* Fs, double* Qs);
 namespace rc {
@@ -207,6 +212,9 @@ struct RcArgs {
     const double* suf;          // (nchunk, nsmth) inclusive suffixes of sagg1
     double* Lws;                // (N, d, d) the smoothing elements' L
     double* llpart;             // (nchunk,)
+    int store_f;                // write fms / fPs (0: log-likelihood-only and projected-posterior calls)
+    const int* qslot;           // projected-posterior mode: (N,) slot of step k in pmean / pvar, or -1
+    double *pmean, *pvar;       // (K,) H sm and H sP H^T at the query steps
 };
 // defined in pgps_rc_inst.hip, one explicit instantiation per d
 template <int D>

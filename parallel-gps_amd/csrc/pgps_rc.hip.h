@@ -421,8 +421,10 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             const double res = obs ? yk - mu : 0.0;
             m = mb + u * (inv * res);
             copy<D>(P, Pp); rank1<D>(P, u, -u * inv);
-            io.st_mat(a.fPs + ku * dd, upd, P);
-            io.st_vec(a.fms + ku * D, upd, m);
+            if (a.store_f) {                    // log-likelihood-only and projected-posterior calls skip these
+                io.st_mat(a.fPs + ku * dd, upd, P);
+                io.st_vec(a.fms + ku * D, upd, m);
+            }
         }
         if (SMOOTH && s + 1 < iters) load(s + 1);
     }
@@ -449,7 +451,9 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
 // ====================================================================================================
 // level 1: smoother -- sm = E sm' + g, sP = E sP' E^T + L from the stored elements (parallel.py:176-184)
 // ====================================================================================================
-template <int D, bool FAST>
+// PROJ (pgps_lti_predict_*): nothing is stored per step; step k writes  H sm_k  and  H sP_k H^T  to slot qslot[k]
+// when that is >= 0 (StateSpaceGP.predict_f keeps exactly those, pssgp/model.py:107-111)
+template <int D, bool FAST, bool PROJ>
 __device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
@@ -471,9 +475,16 @@ __device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int
     }
     double Ec[D], Er[D], L[D], g = 0.0;
     zero<D>(Ec); zero<D>(Er); zero<D>(L);
+    double h[D];
+    int q = -1;
+    if (PROJ) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) h[i] = a.H[i];
+    }
     // stored element of this row's step; steps outside the chunk run as the identity element (I, 0, 0)
     auto load = [&](int s) {
         const long ku = kw + s, k = k0 + s;
+        if (PROJ) { q = -1; if (FAST || k < k1) q = a.qslot[k]; }
         if (FAST) {
             io.template mat_fast<false>(a.sPs + ku * dd, Ec);
             io.template mat_fast<false>(a.Lws + ku * dd, L);
@@ -495,22 +506,29 @@ __device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int
         zero<D>(T); mm<D>(T, Ec, sP);
         copy<D>(nP, L); mm<D>(nP, T, Er);
         sm = mvr<D>(Er, sm, g);
+        const int qk = q;
         if (s > 0) load(s - 1);
         symmetrise<D>(nP, patch, lane);
         copy<D>(sP, nP);
-        const bool st = FAST || k < k1;
-        io.st_mat(a.sPs + ku * dd, st, sP);
-        io.st_vec(a.sms + ku * D, st, sm);
+        if (PROJ) {
+            const double mean = mvr<D>(h, sm, 0.0);                     // H sm            (every lane of the row)
+            const double var = mvr<D>(h, dot_h<D>(sP, h), 0.0);         // H sP H^T
+            if (qk >= 0 && lane == 0) { a.pmean[qk] = mean; a.pvar[qk] = var; }
+        } else {
+            const bool st = FAST || k < k1;
+            io.st_mat(a.sPs + ku * dd, st, sP);
+            io.st_vec(a.sms + ku * D, st, sm);
+        }
     }
 }
 
-template <int D>
+template <int D, bool PROJ>
 __global__ __launch_bounds__(64) void rc_smooth1(const RcArgs a) {
     __shared__ double tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     double* patch = patch_init(tl, row);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<D, true>(a, patch, lane, row);
-    else smooth1_body<D, false>(a, patch, lane, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<D, true, PROJ>(a, patch, lane, row);
+    else smooth1_body<D, false, PROJ>(a, patch, lane, row);
 }
 
 // ====================================================================================================
@@ -761,7 +779,7 @@ __global__ __launch_bounds__(64) void rc_discretise(long N, int per, const doubl
 }
 
 // ---- host side: the level-1 launches of one instantiation ---------------------------------------------
-// phase 0: reduce, 1: apply + smoothing elements, 2: apply only, 3: smoother
+// phase 0: reduce, 1: apply + smoothing elements, 2: apply only, 3: smoother, 4: smoother writing projections
 template <int D>
 int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
     const dim3 blk(64), g1((unsigned)((a.nchunk + 3) / 4));
@@ -769,7 +787,8 @@ int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
         case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_reduce1<D>, g1, blk, 0u, a); break;
         case 1: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, true>, g1, blk, 0u, a); break;
         case 2: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, false>, g1, blk, 0u, a); break;
-        default: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D>, g1, blk, 0u, a); break;
+        case 3: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D, false>, g1, blk, 0u, a); break;
+        default: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D, true>, g1, blk, 0u, a); break;
     }
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;

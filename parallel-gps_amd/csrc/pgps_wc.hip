@@ -1259,7 +1259,7 @@ static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, doub
             double* t = src; src = dst; dst = t;
         }
         a.suf = src;
-        if ((rcode = level1(ctx, d, a, 3))) return rcode;
+        if ((rcode = level1(ctx, d, a, a.qslot ? 4 : 3))) return rcode;
     } else {
         if ((rcode = level1(ctx, d, a, 2))) return rcode;
     }
@@ -1287,8 +1287,20 @@ int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* 
 
 static inline size_t rc_align(size_t x) { return (x + 255) / 256 * 256; }
 
+static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, int store_f, const int* qslot, double* pmean,
+                         double* pvar);
+
 // fp64, 2 <= d <= 16, pkf / pkfs on one device
 int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode) {
+    return scan_rc_entry(ctx, sa, d, mode, 1, nullptr, nullptr, nullptr);
+}
+int launch_scan_rc_proj(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, const int* qslot, double* pmean, double* pvar) {
+    if (mode == MODE_PKFS && (!qslot || !pmean || !pvar)) return PGPS_E_INVALID;
+    return scan_rc_entry(ctx, sa, d, mode, 0, mode == MODE_PKFS ? qslot : nullptr, pmean, pvar);
+}
+
+static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, int store_f, const int* qslot, double* pmean,
+                         double* pvar) {
     if (mode != MODE_PKF && mode != MODE_PKFS) return PGPS_E_UNSUPPORTED_DIM;
     if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1306,6 +1318,7 @@ int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode) {
     a.wfast = (sa.N - 1) / (4L * a.Lw);         // (w + 1) 4 Lw + 1 <= N
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs;
+    a.store_f = store_f; a.qslot = qslot; a.pmean = pmean; a.pvar = pvar;
     const size_t dd = (size_t)d * d, nf = wc::nfilt(d), ns = wc::nsmth(d), nc = (size_t)a.nchunk;
     size_t off = 0;
     const size_t o_aggA = off;  off = rc_align(off + nc * nf * sizeof(double));

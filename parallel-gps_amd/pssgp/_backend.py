@@ -401,6 +401,52 @@ def gp_predict(form, Pinf, H, R, ts, ys, tq, t0=0.0, device=0):
     return mean, var, ll.value
 
 
+LTI_DIM_MIN, LTI_DIM_MAX = 2, 16          # state dimensions of the general-LTI device path (row-cooperative kernels)
+
+
+def _lti_model(F, Pinf, H):
+    F = _prep(F, np.float64)
+    d = F.shape[0]
+    if not (LTI_DIM_MIN <= d <= LTI_DIM_MAX):
+        raise ValueError(f"the general-LTI device path covers state dimensions {LTI_DIM_MIN}..{LTI_DIM_MAX}, got {d}")
+    return F, _prep(Pinf, np.float64, (d, d)), _prep(H, np.float64, (d,)), d
+
+
+def lti_ll(F, Pinf, H, R, ts, ys, t0=0.0, device=0):
+    """Log-likelihood of any LTI state-space GP on the device (pgps_lti_ll_f64): discretisation, parallel filter
+    and the likelihood terms with nothing written per step.  `Pinf` must be the stationary covariance of the SDE
+    (it is every kernel's P0)."""
+    F, Pinf, H, d = _lti_model(F, Pinf, H)
+    ts_a = _prep(ts, np.float64, (-1,))
+    ys_a = _prep(ys, np.float64, (-1,))
+    if ys_a.shape[0] != ts_a.shape[0]:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
+    ll = c_double(0.0)
+    get_context(device).call("pgps_lti_ll_f64", c_long(ts_a.shape[0]), c_int(d), _ptr(F), _ptr(Pinf), _ptr(H),
+                             c_double(float(R)), _ptr(ts_a), _ptr(ys_a), c_double(float(t0)),
+                             ctypes.cast(ctypes.byref(ll), c_void_p))
+    return ll.value
+
+
+def lti_predict(F, Pinf, H, R, ts, ys, tq, t0=0.0, device=0):
+    """predict_f of any LTI state-space GP on the device (pgps_lti_predict_f64): merge of the sorted `ts` (N) and
+    `tq` (K), discretisation, filter + smoother over the N + K steps, posterior mean / variance of f = H x at the K
+    query times.  Returns (mean (K,), var (K,), ll of the training series)."""
+    F, Pinf, H, d = _lti_model(F, Pinf, H)
+    ts_a = _prep(ts, np.float64, (-1,))
+    ys_a = _prep(ys, np.float64, (-1,))
+    tq_a = _prep(tq, np.float64, (-1,))
+    N, K = ts_a.shape[0], tq_a.shape[0]
+    if ys_a.shape[0] != N:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {N} steps")
+    mean, var = np.empty(K, np.float64), np.empty(K, np.float64)
+    ll = c_double(0.0)
+    get_context(device).call("pgps_lti_predict_f64", c_long(N), c_long(K), c_int(d), _ptr(F), _ptr(Pinf), _ptr(H),
+                             c_double(float(R)), _ptr(ts_a), _ptr(ys_a), c_double(float(t0)), _ptr(tq_a), _ptr(mean),
+                             _ptr(var), ctypes.cast(ctypes.byref(ll), c_void_p))
+    return mean, var, ll.value
+
+
 def gp_ll_batch(models, ts, ys, t0=0.0, device=0):
     """Log-likelihoods of B models over one series (pgps_gp_ll_batch_*).
 

@@ -83,6 +83,22 @@ class StateSpaceGP:
             return None
         return sde, form
 
+    def _lti_form(self):
+        """The kernel's SDE when the general-LTI device path applies (parallel=True, fp64, state dimension
+        2..16, P0 stationary -- the GPU discretisation forms Q = P0 - F_k P0 F_k^T), else None."""
+        if not self.parallel or np.dtype(config.default_float()) != np.float64:
+            return None
+        from . import _backend
+        sde = self.kernel.get_sde()
+        F, P0 = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64)
+        if not (_backend.LTI_DIM_MIN <= F.shape[0] <= _backend.LTI_DIM_MAX):
+            return None
+        L = np.asarray(sde.L, np.float64)
+        LQL = L @ np.atleast_2d(np.asarray(sde.Q, np.float64)) @ L.T
+        if np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) > 1e-8 * max(1.0, float(np.max(np.abs(LQL)))):
+            return None
+        return sde
+
     def _make_model(self, ts):
         R = np.reshape(np.asarray(self.noise_variance, dtype=config.default_float()), (1, 1))
         return self.kernel.get_ssm(ts, R)
@@ -106,6 +122,15 @@ class StateSpaceGP:
             mean, var, _ = _backend.gp_predict(form, sde.P0, sde.H, self.noise_variance, squeezed_ts, ys.reshape(-1),
                                                squeezed_Xnew)
             return mean[:, None], var[:, None]
+        lti = self._lti_form() if fused is None else None
+        if (lti is not None and squeezed_Xnew.size > 0 and np.all(np.diff(squeezed_ts) >= 0)
+                and np.all(np.diff(squeezed_Xnew) >= 0)):
+            # kernels without the closed-form discretisation (RBF, Periodic, sums, products): merge, discretisation,
+            # filter + smoother and projection on the device as well
+            from . import _backend
+            mean, var, _ = _backend.lti_predict(lti.F, lti.P0, lti.H, self.noise_variance, squeezed_ts, ys.reshape(-1),
+                                                squeezed_Xnew)
+            return mean[:, None].astype(dtype), var[:, None].astype(dtype)
         nan_ys = np.full((squeezed_Xnew.shape[0], ys.shape[1]), np.nan, dtype=ys.dtype)
         all_ts, all_ys, all_flags = _merge_sorted(
             squeezed_ts, squeezed_Xnew, (ys, nan_ys),
@@ -134,6 +159,10 @@ class StateSpaceGP:
             from . import _backend
             sde, form = fused
             return _backend.gp(form, sde.P0, sde.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))["ll"]
+        lti = self._lti_form()
+        if lti is not None:
+            from . import _backend
+            return _backend.lti_ll(lti.F, lti.P0, lti.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))
         ssm = self._make_model(ts)
         _, _, ll = self._kf(ssm, Y)
         return ll

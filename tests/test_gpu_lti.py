@@ -1,0 +1,106 @@
+"""GPU parity of the general-LTI device path (pgps_lti_ll_*, pgps_lti_predict_*: discretisation, parallel filter /
+smoother and the projection at the query rows for any kernel with 2 <= d <= 16, fp64) against the oracle, and of
+StateSpaceGP's dispatch to it."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests.conftest import make_times
+
+pytestmark = pytest.mark.gpu
+
+
+def _kernels():
+    from pssgp.kernels import Matern32, Matern52, RBF, Periodic, SquaredExponential
+    return {
+        "m32+m52": lambda: Matern32(variance=1., lengthscales=0.5) + Matern52(variance=1., lengthscales=0.5),  # d = 5
+        "rbf6": lambda: RBF(variance=1., lengthscales=0.5, order=6, balancing_iter=10),                       # d = 6
+        "c5_qp_m52": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) +
+        Matern52(1., 1.),                                                                                     # d = 11
+        "rbf15": lambda: RBF(variance=1., lengthscales=0.5, order=15, balancing_iter=10),                     # d = 15
+    }
+
+
+def _series(n, seed):
+    rng = np.random.default_rng(seed)
+    t = make_times(n, seed=seed)
+    y = np.sin(t) + 0.5 * np.cos(2.3 * t) + 0.3 * rng.standard_normal(n)
+    return t, y
+
+
+@pytest.mark.parametrize("name", ["m32+m52", "rbf6", "c5_qp_m52", "rbf15"])
+def test_lti_ll_and_predict_vs_oracle(name):
+    from pssgp import _backend as B
+    sde = _kernels()[name]().get_sde()
+    t, y = _series(1700, 3)
+    y[::7] = np.nan
+    rng = np.random.default_rng(5)
+    tq = np.sort(rng.uniform(t[0] - 0.5, t[-1] + 0.5, 400))
+    ll = B.lti_ll(sde.F, sde.P0, sde.H, 0.1, t, y)
+    ll_o = O.ssgp_log_likelihood(sde, t, y, 0.1, parallel=False)
+    assert abs(ll - ll_o) < 1e-8 * abs(ll_o)
+    mean, var, ll2 = B.lti_predict(sde.F, sde.P0, sde.H, 0.1, t, y, tq)
+    mean_o, var_o = O.ssgp_predict_f(sde, t, y, 0.1, tq, parallel=False)
+    scale = max(1.0, float(np.max(np.abs(mean_o))))
+    assert np.max(np.abs(mean - mean_o)) < 1e-7 * scale
+    assert np.max(np.abs(var - var_o)) < 1e-7 * max(1.0, float(np.max(var_o)))
+    assert abs(ll2 - ll_o) < 1e-8 * abs(ll_o)
+
+
+def test_lti_predict_ties_follow_merge_sorted():
+    """Query times equal to training times, repeated queries, more queries than training points (the shorter array
+    is the one scattered, pssgp/model.py:15-55), queries before the first and after the last observation."""
+    from pssgp import _backend as B
+    sde = _kernels()["m32+m52"]().get_sde()
+    t, y = _series(60, 8)
+    tq = np.sort(np.concatenate([t[::3], t[::3], [t[0] - 1.0, t[-1] + 2.0], np.linspace(t[0], t[-1], 150)]))
+    mean, var, _ = B.lti_predict(sde.F, sde.P0, sde.H, 0.2, t, y, tq)
+    mean_o, var_o = O.ssgp_predict_f(sde, t, y, 0.2, tq, parallel=False)
+    assert np.max(np.abs(mean - mean_o)) < 1e-9 and np.max(np.abs(var - var_o)) < 1e-9
+
+
+def test_state_space_gp_dispatches_to_the_lti_path(monkeypatch):
+    """RBF order 15 / Periodic-product kernels through StateSpaceGP(parallel=True): both entry points run on the
+    device path (no (N, d, d) array crosses the host), and agree with the reference's own tolerance vs dense GP."""
+    from pssgp import _backend as B
+    from pssgp.kernels import RBF
+    from pssgp.model import StateSpaceGP
+    calls = []
+    real_ll, real_pr = B.lti_ll, B.lti_predict
+    monkeypatch.setattr(B, "lti_ll", lambda *a, **k: calls.append("ll") or real_ll(*a, **k))
+    monkeypatch.setattr(B, "lti_predict", lambda *a, **k: calls.append("predict") or real_pr(*a, **k))
+    rng = np.random.RandomState(31415926)
+    T, K = 200, 50
+    t = np.sort(rng.rand(T))
+    f = np.sin(np.pi * t) + np.sin(2 * np.pi * t) + np.cos(3 * np.pi * t)
+    y = f + np.sqrt(0.1) * rng.normal(f, np.sqrt(0.1), (T,))
+    query = np.sort(rng.rand(K, 1), 0)
+    cov = RBF(variance=1., lengthscales=0.5, order=15, balancing_iter=10)
+    ll_gp, mean_gp, var_gp = O.dense_gp(("rbf", 1., 0.5), t, y, 0.1, query)
+    model = StateSpaceGP(data=(t[:, None], y[:, None]), kernel=cov, noise_variance=0.1, parallel=True)
+    np.testing.assert_allclose(float(model.maximum_log_likelihood_objective()), ll_gp, atol=1e-2, rtol=1e-2)
+    mean, var = model.predict_f(query)
+    np.testing.assert_allclose(mean[:, 0], mean_gp, atol=1e-2, rtol=1e-2)
+    np.testing.assert_allclose(var[:, 0], var_gp, atol=1e-2, rtol=1e-2)
+    assert calls == ["ll", "predict"]
+
+
+def test_lti_large_series_vs_c_oracle():
+    """config c5's model at 2^16 + 2^14 merged steps against the sequential C oracle run on the merged series."""
+    from oracle import c_oracle as C
+    from pssgp import _backend as B
+    sde = _kernels()["c5_qp_m52"]().get_sde()
+    t, y = _series(1 << 16, 21)
+    rng = np.random.default_rng(2)
+    tq = np.sort(rng.uniform(t[0], t[-1], 1 << 14))
+    mean, var, ll = B.lti_predict(sde.F, sde.P0, sde.H, 0.1, t, y, tq)
+    all_t, all_y, flags = O.merge_sorted(t, tq, (y, np.full(tq.shape, np.nan)),
+                                         (np.zeros(t.shape, bool), np.ones(tq.shape, bool)))
+    ssm = O.get_ssm(sde, all_t, 0.1)
+    _, _, cs, csP, cll = C.kfs(ssm, all_y)
+    H = np.asarray(sde.H, np.float64).reshape(-1)
+    mean_o = cs[flags] @ H
+    var_o = np.einsum("i,nij,j->n", H, csP[flags], H)
+    assert np.max(np.abs(mean - mean_o)) < 1e-8 * max(1.0, float(np.max(np.abs(mean_o))))
+    assert np.max(np.abs(var - var_o)) < 1e-8 * max(1.0, float(np.max(var_o)))
+    assert abs(ll - cll) < 1e-9 * abs(cll)
