@@ -1309,9 +1309,11 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
     if (ctx->chunk > 0) {
         a.Lw = ctx->chunk;
     } else {
-        // four chains per wave; 8192 chains = two waves per SIMD where the registers allow it (measured at 2^20
-        // steps, d = 11: 3.57 ms against 3.73 ms with 4096 chains; the Kogge-Stone levels grow with the count)
-        long lw = (sa.N + 8191) / 8192;
+        // four chains per wave: 4096 chains put one wave on every SIMD, and every doubling adds a Kogge-Stone
+        // launch to both scans.  Measured at d = 11: 2^17 steps 0.67 ms with 4096 chains against 0.79 ms with 8192;
+        // 2^20 steps 3.57 ms with 8192 (two waves per SIMD where the registers allow) against 3.73 ms with 4096.
+        long lw = (sa.N + 4095) / 4096;
+        if (lw > 128) { lw = (sa.N + 8191) / 8192; if (lw < 128) lw = 128; }
         a.Lw = (int)(lw < 8 ? 8 : lw > 512 ? 512 : lw);
     }
     a.nchunk = (sa.N + a.Lw - 1) / a.Lw;
