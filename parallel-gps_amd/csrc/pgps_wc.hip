@@ -48,10 +48,13 @@ struct Geo {
     static constexpr int NSL = 2 * MSZ + DP;        // a smoother 3-tuple in LDS [E | L | g]
 };
 
+// Every kernel of this family is one wave per workgroup and its LDS pool is private to that wave: LDS executes a
+// wave's instructions in issue order, so only the compiler has to be held back.  (A workgroup-scope fence also
+// drains vmcnt -- it would wait for the prefetched next step at every one of the dozens of syncs per step.)
 __device__ __forceinline__ void sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
