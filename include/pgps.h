@@ -201,6 +201,14 @@ int pgps_lti_predict_dev_f64(pgps_ctx*, long N, long K, int d, const double* F, 
                              double R, const double* ts, const double* ys, double t0, const double* tq, double* mean,
                              double* var, double* ll);
 
+/* B models over the same series in one set of launches (hyper-parameter grids, HMC chains, multi-start optimisation
+ * -- the realistic series, N = 1e3..1e5, are launch-latency bound one model at a time).  `models` is HOST memory,
+ * B rows of [F (d*d) | Pinf (d*d) | H (d) | R]; ll receives B log-likelihoods (host pointer; device for _dev). */
+int pgps_lti_ll_batch_f64(pgps_ctx*, int B, long N, int d, const double* models, const double* ts, const double* ys,
+                          double t0, double* ll);
+int pgps_lti_ll_batch_dev_f64(pgps_ctx*, int B, long N, int d, const double* models, const double* ts, const double* ys,
+                              double t0, double* ll);
+
 /* ---- predict_f on the device (fused path, d <= 3) --------------------------------------------------
  * StateSpaceGP.predict_f (pssgp/model.py:92-111) in one call: the sorted training times `ts` (N) and
  * sorted query times `tq` (K) are merged on the device exactly as _merge_sorted does (model.py:15-55:

@@ -943,6 +943,44 @@ static int lti_host(pgps_ctx* ctx, long N, long K, int d, const double* F, const
     return PGPS_OK;
 }
 
+// B models over one series: table = B x [F | Pinf | H | R] from host memory
+static int lti_ll_batch_dev(pgps_ctx* ctx, int B, long N, int d, const double* models, const double* ts, const double* ys,
+                            double t0, double* ll) {
+    if (!ctx || B < 1 || N < 1 || !models || !ts || !ys || !ll) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t dd = (size_t)d * d, ms = 2 * dd + d + 1;
+    double *table, *Fs, *Qs;
+    TRY(stage_in<double>(ctx, ctx->lti[0], models, (size_t)B * ms, &table));
+    TRY(stage_in<double>(ctx, ctx->lti[4], nullptr, (size_t)B * (size_t)N * dd, &Fs));
+    TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, (size_t)B * (size_t)N * dd, &Qs));
+    TRY(launch_disc_rc(ctx, N, d, table, table + dd, ts, t0, Fs, Qs, B, (long)ms));
+    return launch_ll_batch_rc(ctx, N, d, B, table, (long)ms, Fs, Qs, ys, ll);
+}
+
+static int lti_ll_batch_host(pgps_ctx* ctx, int B, long N, int d, const double* models, const double* ts, const double* ys,
+                             double t0, double* ll) {
+    if (!ctx || B < 1 || N < 1 || !models || !ts || !ys || !ll) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *dts, *dys, *dll;
+    TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
+    TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, (size_t)B, &dll));
+    TRY(lti_ll_batch_dev(ctx, B, N, d, models, dts, dys, t0, dll));
+    TRY(stage_out(ctx, ll, dll, (size_t)B));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGPS_OK;
+}
+
+extern "C" int pgps_lti_ll_batch_f64(pgps_ctx* c, int B, long N, int d, const double* models, const double* ts,
+                                     const double* ys, double t0, double* ll) {
+    return lti_ll_batch_host(c, B, N, d, models, ts, ys, t0, ll);
+}
+extern "C" int pgps_lti_ll_batch_dev_f64(pgps_ctx* c, int B, long N, int d, const double* models, const double* ts,
+                                         const double* ys, double t0, double* ll) {
+    return lti_ll_batch_dev(c, B, N, d, models, ts, ys, t0, ll);
+}
+
 extern "C" int pgps_lti_ll_f64(pgps_ctx* c, long N, int d, const double* F, const double* Pinf, const double* H, double R,
                                const double* ts, const double* ys, double t0, double* ll) {
     if (!ll) return PGPS_E_INVALID;

@@ -194,7 +194,11 @@ int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode);
 int launch_scan_rc_proj(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode, const int* qslot, double* pmean,
                         double* pvar);
 int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* ts, double t0,
-                   double* Fs, double* Qs);
+                   double* Fs, double* Qs, int batch = 1, long bs_model = 0);
+// log-likelihoods of `batch` models over one series: table = batch x [F | Pinf | H | R] (stride bs_model, device),
+// Fs / Qs = (batch, N, d, d) discretised arrays, ll = (batch,) device
+int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* table, long bs_model, const double* Fs,
+                       const double* Qs, const double* ys, double* ll);
 namespace rc {
 constexpr int kDimMin = 2, kDimMax = 16;
 struct RcArgs {
@@ -212,6 +216,9 @@ struct RcArgs {
     const double* suf;          // (nchunk, nsmth) inclusive suffixes of sagg1
     double* Lws;                // (N, d, d) the smoothing elements' L
     double* llpart;             // (nchunk,)
+    int batch;                  // models evaluated over the same series (blockIdx.y); 0 / 1 = one
+    long bs_F, bs_agg, bs_model;    // per-model strides of Fs / Qs, of agg1 / pre, of the model table
+    const double* Rs;           // batch entry point: observation noise of model b at Rs[b * bs_model] (else null)
     int store_f;                // write fms / fPs (0: log-likelihood-only and projected-posterior calls)
     const int* qslot;           // projected-posterior mode: (N,) slot of step k in pmean / pvar, or -1
     double *pmean, *pvar;       // (K,) H sm and H sP H^T at the query steps
@@ -220,10 +227,10 @@ struct RcArgs {
 template <int D>
 int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase);
 template <int D>
-int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out);
+int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out, int batch, long bstride);
 template <int D>
 int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, const double* ts, double t0, double* Fs,
-                   double* Qs);
+                   double* Qs, int batch, long bs_model);
 }  // namespace rc
 template <typename T>
 int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);

@@ -214,6 +214,23 @@ struct Io {
     }
 };
 
+// Batched evaluation (pgps_lti_ll_batch_*): blockIdx.y selects one of `batch` models over the same series; each
+// model has its own slice of the discretised arrays, of the scan scratch and of the model table
+// [F | Pinf | H | R] (stride bs_model).  The kernel bodies below never see the difference.
+__device__ __forceinline__ RcArgs model_view(const RcArgs& a) {
+    RcArgs b = a;
+    if (a.Rs) {
+        const long mb = blockIdx.y;
+        b.Fs += mb * a.bs_F; b.Qs += mb * a.bs_F;
+        b.P0 += mb * a.bs_model; b.H += mb * a.bs_model;
+        b.R = a.Rs[mb * a.bs_model];
+        b.agg1 += mb * a.bs_agg;
+        b.pre += mb * a.bs_agg;
+        b.llpart += mb * a.nchunk;
+    }
+    return b;
+}
+
 // The level-1 kernels come as two bodies behind one launch: FAST for waves whose four chains lie entirely inside
 // the series and do not contain its first step (no per-row predicates, no selects behind loads -- a select would
 // put an s_waitcnt vmcnt(0) right after the loads and expose the whole memory latency every step), and the general
@@ -293,10 +310,11 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void rc_reduce1(const RcArgs a) {
+__global__ __launch_bounds__(64) void rc_reduce1(const RcArgs a0) {
     __shared__ double tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     double* patch = patch_init(tl, row);
+    const RcArgs a = model_view(a0);
     if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<D, true>(a, patch, lane, row);
     else reduce1_body<D, false>(a, patch, lane, row);
 }
@@ -440,10 +458,11 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
 }
 
 template <int D, bool SMOOTH>
-__global__ __launch_bounds__(64) void rc_apply1(const RcArgs a) {
+__global__ __launch_bounds__(64) void rc_apply1(const RcArgs a0) {
     __shared__ double tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     double* patch = patch_init(tl, row);
+    const RcArgs a = model_view(a0);
     if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<D, SMOOTH, true>(a, patch, lane, row);
     else apply1_body<D, SMOOTH, false>(a, patch, lane, row);
 }
@@ -584,10 +603,12 @@ __device__ __forceinline__ void st_rec_mat(double* g, bool ok, int lane, const d
 //   M = I + C1 J2;  Nm = M^-1 C1 (symmetric);  z = eta2 - J2 b1;  W = J2 A1;  G = M^-1 A1 = A1 - Nm W
 //   A = A2 G;  b = A2 (b1 + Nm z) + b2;  C = sym(A2 Nm A2^T) + C2;  eta = G^T z + eta1;  J = sym(G^T W) + J1
 template <int D>
-__global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const double* in, double* out) {
+__global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const double* in, double* out, long bstride) {
     __shared__ double tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     double* patch = patch_init(tl, row);
+    in += blockIdx.y * bstride;
+    out += blockIdx.y * bstride;
     constexpr int dd = D * D, nf = 3 * D * D + 2 * D;
     const long c = (long)blockIdx.x * 4 + row;
     const bool lv = lane < D, cv = c < n, comb = cv && c >= stride;
@@ -695,11 +716,13 @@ __global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const 
 // ====================================================================================================
 template <int D>
 __global__ __launch_bounds__(64) void rc_discretise(long N, int per, const double* Fg, const double* Pg, const double* ts,
-                                                    double t_prev, double* Fs, double* Qs) {
+                                                    double t_prev, double* Fs, double* Qs, long bs_model) {
     __shared__ double tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     double* patch = patch_init(tl, row);
     constexpr int dd = D * D;
+    Fg += blockIdx.y * bs_model; Pg += blockIdx.y * bs_model;         // batched: one model per blockIdx.y
+    Fs += blockIdx.y * N * dd; Qs += blockIdx.y * N * dd;
     const bool lv = lane < D;
     const double b[14] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
                           129060195264000., 10559470521600., 670442572800., 33522128640.,
@@ -782,7 +805,7 @@ __global__ __launch_bounds__(64) void rc_discretise(long N, int per, const doubl
 // phase 0: reduce, 1: apply + smoothing elements, 2: apply only, 3: smoother, 4: smoother writing projections
 template <int D>
 int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
-    const dim3 blk(64), g1((unsigned)((a.nchunk + 3) / 4));
+    const dim3 blk(64), g1((unsigned)((a.nchunk + 3) / 4), (unsigned)(a.batch > 1 ? a.batch : 1));
     switch (phase) {
         case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_reduce1<D>, g1, blk, 0u, a); break;
         case 1: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, true>, g1, blk, 0u, a); break;
@@ -796,9 +819,9 @@ int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
 
 // one Kogge-Stone step over n records: which = 0 filter totals (prefix), 1 smoothing totals (suffix)
 template <int D>
-int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out) {
-    const dim3 blk(64), g((unsigned)((n + 3) / 4));
-    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<D>, g, blk, 0u, n, stride, in, out);
+int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out, int batch, long bstride) {
+    const dim3 blk(64), g((unsigned)((n + 3) / 4), (unsigned)batch);
+    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<D>, g, blk, 0u, n, stride, in, out, bstride);
     else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<D>, g, blk, 0u, n, stride, in, out);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
@@ -806,10 +829,11 @@ int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in
 
 template <int D>
 int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, const double* ts, double t0, double* Fs,
-                   double* Qs) {
+                   double* Qs, int batch, long bs_model) {
     const int per = 8;                          // steps per row: amortises the model load and the norm
     const long grid = (N + 4L * per - 1) / (4L * per);
-    timed_launch(ctx, PGPS_K_DISCRETISE, rc_discretise<D>, dim3((unsigned)grid), dim3(64), 0u, N, per, F, Pinf, ts, t0, Fs, Qs);
+    timed_launch(ctx, PGPS_K_DISCRETISE, rc_discretise<D>, dim3((unsigned)grid, (unsigned)batch), dim3(64), 0u, N, per, F, Pinf,
+                 ts, t0, Fs, Qs, bs_model);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

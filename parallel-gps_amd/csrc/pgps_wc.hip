@@ -1208,6 +1208,8 @@ namespace rc {
 // sum of the chains' log-likelihood partials: one workgroup of 16 waves, fixed order (bit-reproducible)
 static __global__ __launch_bounds__(1024) void ll_finalize(const double* llpart, long n, double* ll) {
     __shared__ double part[16];
+    llpart += blockIdx.x * n;           // batched: one model per workgroup
+    ll += blockIdx.x;
     double t = 0.0;
     for (long c = threadIdx.x; c < n; c += 1024) t += llpart[c];
     t = wc::wave_sum(t);
@@ -1231,9 +1233,10 @@ static int level1(pgps_ctx* ctx, int d, const RcArgs& a, int phase) {
     return PGPS_E_UNSUPPORTED_DIM;
 }
 
-static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const double* in, double* out) {
+static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const double* in, double* out, int batch = 1,
+                   long bstride = 0) {
     switch (d) {
-#define PGPS_RC_CASE(DV) case DV: return launch_rc_ks<DV>(ctx, which, n, stride, in, out);
+#define PGPS_RC_CASE(DV) case DV: return launch_rc_ks<DV>(ctx, which, n, stride, in, out, batch, bstride);
         PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
         PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
         PGPS_RC_CASE(15) PGPS_RC_CASE(16)
@@ -1248,8 +1251,9 @@ static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, doub
     a.agg1 = aggA;
     if ((rcode = level1(ctx, d, a, 0))) return rcode;
     double *src = aggA, *dst = aggB;
+    const int nb = a.batch > 1 ? a.batch : 1;
     for (long s = 1; s < a.nchunk; s *= 2) {
-        if ((rcode = ks_step(ctx, d, 0, a.nchunk, s, src, dst))) return rcode;
+        if ((rcode = ks_step(ctx, d, 0, a.nchunk, s, src, dst, nb, a.bs_agg))) return rcode;
         double* t = src; src = dst; dst = t;
     }
     a.pre = src;
@@ -1267,7 +1271,7 @@ static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, doub
         if ((rcode = level1(ctx, d, a, 2))) return rcode;
     }
     if (ll)
-        timed_launch(ctx, PGPS_K_LL_FINALIZE, ll_finalize, dim3(1), dim3(1024), 0u, (const double*)a.llpart,
+        timed_launch(ctx, PGPS_K_LL_FINALIZE, ll_finalize, dim3((unsigned)nb), dim3(1024), 0u, (const double*)a.llpart,
                      (long)a.nchunk, ll);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
@@ -1276,10 +1280,10 @@ static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, doub
 }  // namespace rc
 
 int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* ts, double t0,
-                   double* Fs, double* Qs) {
+                   double* Fs, double* Qs, int batch, long bs_model) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     switch (d) {
-#define PGPS_RC_CASE(DV) case DV: return rc::launch_rc_disc<DV>(ctx, N, F, Pinf, ts, t0, Fs, Qs);
+#define PGPS_RC_CASE(DV) case DV: return rc::launch_rc_disc<DV>(ctx, N, F, Pinf, ts, t0, Fs, Qs, batch, bs_model);
         PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
         PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
         PGPS_RC_CASE(15) PGPS_RC_CASE(16)
@@ -1291,7 +1295,7 @@ int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* 
 static inline size_t rc_align(size_t x) { return (x + 255) / 256 * 256; }
 
 static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, int store_f, const int* qslot, double* pmean,
-                         double* pvar);
+                         double* pvar, int batch = 1, long bs_model = 0);
 
 // fp64, 2 <= d <= 16, pkf / pkfs on one device
 int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode) {
@@ -1302,8 +1306,21 @@ int launch_scan_rc_proj(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, co
     return scan_rc_entry(ctx, sa, d, mode, 0, mode == MODE_PKFS ? qslot : nullptr, pmean, pvar);
 }
 
+int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* table, long bs_model, const double* Fs,
+                       const double* Qs, const double* ys, double* ll) {
+    if (batch < 1 || !table || !Fs || !Qs || !ys || !ll) return PGPS_E_INVALID;
+    const long dd = (long)d * d;
+    ScanArgs<double> a{};
+    a.N = N; a.seg_first = 1; a.seg_last = 1;
+    a.P0 = table + dd; a.H = table + 2 * dd; a.R = 0.0; a.Fs = Fs; a.Qs = Qs; a.ys = ys;
+    a.ll = ll;
+    // R of model b sits at table[b * bs_model + 2 dd + d]; scan_rc_entry turns that into RcArgs::Rs
+    a.carry_in = table + 2 * dd + d;
+    return scan_rc_entry(ctx, a, d, MODE_PKF, 0, nullptr, nullptr, nullptr, batch, bs_model);
+}
+
 static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, int store_f, const int* qslot, double* pmean,
-                         double* pvar) {
+                         double* pvar, int batch, long bs_model) {
     if (mode != MODE_PKF && mode != MODE_PKFS) return PGPS_E_UNSUPPORTED_DIM;
     if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1317,6 +1334,10 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
         // 2^20 steps 3.57 ms with 8192 (two waves per SIMD where the registers allow) against 3.73 ms with 4096.
         long lw = (sa.N + 4095) / 4096;
         if (lw > 128) { lw = (sa.N + 8191) / 8192; if (lw < 128) lw = 128; }
+        if (batch > 1) {                        // the models multiply the chains: keep about 8192 in flight
+            lw = ((long)sa.N * batch + 8191) / 8192;
+            if (lw > 128) lw = 128;
+        }
         a.Lw = (int)(lw < 8 ? 8 : lw > 512 ? 512 : lw);
     }
     a.nchunk = (sa.N + a.Lw - 1) / a.Lw;
@@ -1325,12 +1346,18 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs;
     a.store_f = store_f; a.qslot = qslot; a.pmean = pmean; a.pvar = pvar;
     const size_t dd = (size_t)d * d, nf = wc::nfilt(d), ns = wc::nsmth(d), nc = (size_t)a.nchunk;
+    const size_t nbm = batch > 1 ? (size_t)batch : 1;
+    if (bs_model > 0) {                                             // the batch entry point, B >= 1
+        if (mode != MODE_PKF || store_f) return PGPS_E_INVALID;     // batched: log-likelihood only
+        a.batch = batch; a.bs_F = (long)sa.N * (long)dd; a.bs_agg = (long)(nc * nf); a.bs_model = bs_model;
+        a.Rs = sa.carry_in;
+    }
     size_t off = 0;
-    const size_t o_aggA = off;  off = rc_align(off + nc * nf * sizeof(double));
-    const size_t o_aggB = off;  off = rc_align(off + nc * nf * sizeof(double));
+    const size_t o_aggA = off;  off = rc_align(off + nbm * nc * nf * sizeof(double));
+    const size_t o_aggB = off;  off = rc_align(off + nbm * nc * nf * sizeof(double));
     const size_t o_sagA = off;  off = rc_align(off + nc * ns * sizeof(double));
     const size_t o_sagB = off;  off = rc_align(off + nc * ns * sizeof(double));
-    const size_t o_ll = off;    off = rc_align(off + nc * sizeof(double));
+    const size_t o_ll = off;    off = rc_align(off + nbm * nc * sizeof(double));
     const size_t o_L = off;     if (mode == MODE_PKFS) off = rc_align(off + (size_t)sa.N * dd * sizeof(double));
     int rcode = ensure(ctx, ctx->ws, off);
     if (rcode) return rcode;

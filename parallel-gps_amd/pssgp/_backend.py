@@ -447,6 +447,29 @@ def lti_predict(F, Pinf, H, R, ts, ys, tq, t0=0.0, device=0):
     return mean, var, ll.value
 
 
+def lti_ll_batch(models, ts, ys, t0=0.0, device=0):
+    """Log-likelihoods of B general LTI models over one series in one set of launches (pgps_lti_ll_batch_f64).
+
+    `models`: list of (F, Pinf, H, R) -- what lti_ll() takes, once per model; all of one state dimension."""
+    rows, d = [], None
+    for F, Pinf, H, R in models:
+        F, Pinf, H, dm = _lti_model(F, Pinf, H)
+        if d is None:
+            d = dm
+        if dm != d:
+            raise ValueError("all models of a batch must have the same state dimension")
+        rows.append(np.concatenate([F.reshape(-1), Pinf.reshape(-1), H.reshape(-1), [float(R)]]))
+    packed = np.ascontiguousarray(np.stack(rows), dtype=np.float64)
+    ts_a = _prep(ts, np.float64, (-1,))
+    ys_a = _prep(ys, np.float64, (-1,))
+    if ys_a.shape[0] != ts_a.shape[0]:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
+    out = np.zeros(len(models), np.float64)
+    get_context(device).call("pgps_lti_ll_batch_f64", c_int(len(models)), c_long(ts_a.shape[0]), c_int(d), _ptr(packed),
+                             _ptr(ts_a), _ptr(ys_a), c_double(float(t0)), _ptr(out))
+    return out
+
+
 def gp_ll_batch(models, ts, ys, t0=0.0, device=0):
     """Log-likelihoods of B models over one series (pgps_gp_ll_batch_*).
 

@@ -233,22 +233,29 @@ class StateSpaceGP:
         if thetas.shape[1] != len(params):
             raise ValueError(f"thetas has {thetas.shape[1]} columns, the model {len(params)} trainable parameters")
         saved = [getattr(o, n) for o, n in params]
-        models = []
+        models, general = [], []
         try:
             for row in thetas:
                 for (o, n), v in zip(params, row):
                     setattr(o, n, float(v))
                 sde = self.kernel.get_sde()
                 form = _backend.nilpotent_form(sde.F)
-                if form is None:
-                    raise NotImplementedError("batched evaluation needs the closed-form (Matern-family) discretisation")
-                models.append((form, np.asarray(sde.P0, np.float64), np.asarray(sde.H, np.float64).reshape(-1),
-                               self.noise_variance))
+                P0, H = np.asarray(sde.P0, np.float64), np.asarray(sde.H, np.float64).reshape(-1)
+                if form is not None:
+                    models.append((form, P0, H, self.noise_variance))
+                # kernels without the closed-form discretisation (RBF, Periodic, sums, products): general-LTI batch
+                general.append((np.asarray(sde.F, np.float64), P0, H, self.noise_variance))
         finally:
             for (o, n), v in zip(params, saved):
                 setattr(o, n, v)
         ts, Y = self.data
-        return _backend.gp_ll_batch(models, ts.reshape(-1), Y.reshape(-1))
+        if len(models) == len(general):
+            return _backend.gp_ll_batch(models, ts.reshape(-1), Y.reshape(-1))
+        d = general[0][0].shape[0]
+        if not (_backend.LTI_DIM_MIN <= d <= _backend.LTI_DIM_MAX):
+            raise NotImplementedError(f"batched evaluation covers the Matern family and state dimensions "
+                                      f"{_backend.LTI_DIM_MIN}..{_backend.LTI_DIM_MAX}; this kernel has d = {d}")
+        return _backend.lti_ll_batch(general, ts.reshape(-1), Y.reshape(-1))
 
     def log_posterior_density(self):
         return self.maximum_log_likelihood_objective()

@@ -104,3 +104,46 @@ def test_lti_large_series_vs_c_oracle():
     assert np.max(np.abs(mean - mean_o)) < 1e-8 * max(1.0, float(np.max(np.abs(mean_o))))
     assert np.max(np.abs(var - var_o)) < 1e-8 * max(1.0, float(np.max(var_o)))
     assert abs(ll - cll) < 1e-9 * abs(cll)
+
+
+@pytest.mark.parametrize("name,B,n", [("rbf6", 7, 900), ("rbf6", 1, 1000), ("c5_qp_m52", 33, 300), ("rbf15", 5, 5000)])
+def test_lti_ll_batch_equals_single_calls(name, B, n):
+    """B models (different lengthscale-like scalings of F, different noise) over one series in one set of launches:
+    each log-likelihood equals the single-model call; the batch is also checked against the oracle."""
+    from pssgp import _backend as B_
+    sde = _kernels()[name]().get_sde()
+    t, y = _series(n, 17)
+    y[::5] = np.nan
+    rng = np.random.default_rng(4)
+    models = []
+    F, P0, H = np.asarray(sde.F, float), np.asarray(sde.P0, float), np.asarray(sde.H, float).reshape(-1)
+    for b in range(B):
+        a, v = rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0)      # time rescaling and variance rescaling keep P0 stationary
+        models.append((a * F, v * P0, H, rng.uniform(0.05, 0.5)))
+    got = B_.lti_ll_batch(models, t, y)
+    single = np.array([B_.lti_ll(*m, t, y) for m in models])
+    assert np.max(np.abs(got - single)) < 1e-9 * np.max(np.abs(single))
+    # oracle check of one model through the stable discretisation: Fs = expm(dt F), Qs = P - Fs P Fs^T
+    from scipy.linalg import expm
+    Fm, Pm, _, Rm = models[-1]
+    dts = np.diff(np.concatenate([[0.0], t]))
+    Fs = np.stack([expm(dt * Fm) for dt in dts])
+    Qs = Pm[None] - np.einsum("kij,jl,kml->kim", Fs, Pm, Fs)
+    ll_o = O.kf((Pm, Fs, Qs, H.reshape(1, -1), np.array([[Rm]])), y, True)[2]
+    assert abs(got[-1] - ll_o) < 1e-8 * abs(ll_o)
+
+
+def test_state_space_gp_batch_for_rbf():
+    from pssgp.kernels import RBF
+    from pssgp.model import StateSpaceGP
+    t, y = _series(700, 23)
+    m = StateSpaceGP((t[:, None], y[:, None]), RBF(variance=1., lengthscales=0.5, order=6, balancing_iter=10),
+                     noise_variance=0.1, parallel=True)
+    thetas = np.array([[1.0, 0.5, 0.1], [0.7, 0.8, 0.2], [1.5, 0.3, 0.05]])
+    got = m.log_likelihood_batch(thetas)
+    want = []
+    for v, l, r in thetas:
+        mm = StateSpaceGP((t[:, None], y[:, None]), RBF(variance=v, lengthscales=l, order=6, balancing_iter=10),
+                          noise_variance=r, parallel=True)
+        want.append(float(mm.maximum_log_likelihood_objective()))
+    assert np.max(np.abs(got - np.array(want))) < 1e-8 * np.max(np.abs(want))
