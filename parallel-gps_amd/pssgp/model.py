@@ -169,10 +169,22 @@ class StateSpaceGP:
 
     # -- hyper-parameter gradients (SURVEY.md section 8f rank 1) --------------------------------
     def trainable_parameters(self):
-        """[(owner, attribute name)] in the order the gradient is returned: the kernel's variance and
-        lengthscale, then the observation-noise variance (the reference's gpflow Parameters,
-        pssgp/model.py:68 and the Matern kernels' variance / lengthscales)."""
-        ps = [(self.kernel, a) for a in ("variance", "lengthscales") if isinstance(getattr(self.kernel, a, None), float)]
+        """[(owner, attribute name)] in the order the gradient is returned: every leaf kernel's variance,
+        lengthscale and period (the reference's gpflow Parameters: the Matern / RBF kernels' variance /
+        lengthscales, Periodic's period and its base kernel's parameters, the leaves of sums and products in order),
+        then the observation-noise variance (pssgp/model.py:68)."""
+        ps = []
+
+        def walk(k):
+            for sub in getattr(k, "kernels", ()):
+                walk(sub)
+            if getattr(k, "kernels", None):
+                return
+            ps.extend((k, a) for a in ("variance", "lengthscales", "period") if isinstance(getattr(k, a, None), float))
+            if getattr(k, "base_kernel", None) is not None:
+                walk(k.base_kernel)
+
+        walk(self.kernel)
         return ps + [(self, "noise_variance")]
 
     def _grad_blocks(self):
@@ -217,8 +229,34 @@ class StateSpaceGP:
             raise NotImplementedError("gradients run on the parallel (HIP) path: construct with parallel=True")
         from . import _backend
         ts, Y = self.data
+        if self._fused_form() is None and self._lti_form() is not None:
+            return self._lti_ll_and_grad()
         ll, g = _backend.gp_ll_grad(self._grad_blocks(), ts.reshape(-1), Y.reshape(-1))
         return ll, g
+
+    def _lti_ll_and_grad(self, rel_step=1e-3):
+        """Kernels without the closed-form discretisation (RBF, Periodic, sums, products; d <= 16): the gradient by
+        Richardson-extrapolated central differences -- 4 P + 1 likelihood evaluations, ALL IN ONE batched device call
+        (pgps_lti_ll_batch_*), so its cost is that of one launch set, not of 4 P + 1.  Truncation error O(h^4):
+        ~1e-8 relative for these smooth objectives (tests/test_gpu_lti.py checks it against the dense GP's
+        gradient); the dual-number pass of the Matern family is exact."""
+        params = self.trainable_parameters()
+        x0 = np.array([getattr(o, n) for o, n in params], np.float64)
+        rows = [x0]
+        hs = rel_step * np.maximum(np.abs(x0), 1e-3)
+        for i in range(len(params)):
+            for mult in (1.0, -1.0, 0.5, -0.5):
+                x = x0.copy()
+                x[i] += mult * hs[i]
+                rows.append(x)
+        lls = self.log_likelihood_batch(np.stack(rows))
+        grad = np.empty(len(params))
+        for i in range(len(params)):
+            up, dn, up2, dn2 = lls[1 + 4 * i:5 + 4 * i]
+            d1 = (up - dn) / (2.0 * hs[i])
+            d2 = (up2 - dn2) / hs[i]
+            grad[i] = (4.0 * d2 - d1) / 3.0
+        return float(lls[0]), grad
 
     def log_likelihood_batch(self, thetas):
         """Marginal log-likelihoods at B hyper-parameter settings in one call: `thetas` is (B, P) in the

@@ -147,3 +147,41 @@ def test_state_space_gp_batch_for_rbf():
                           noise_variance=r, parallel=True)
         want.append(float(mm.maximum_log_likelihood_objective()))
     assert np.max(np.abs(got - np.array(want))) < 1e-8 * np.max(np.abs(want))
+
+
+def test_gradients_of_general_kernels_vs_dense_gp():
+    """log_likelihood_and_grad for RBF order 15 and a sum kernel with three leaves: against 4th-order finite
+    differences of the DENSE GP marginal likelihood (the reference's gradient test compares state-space and GPR
+    gradients, tests/test_gp_vs_kfs.py:53-78); RBF's state-space form is an approximation of the dense kernel,
+    hence its looser tolerance there."""
+    from pssgp.kernels import Matern32, Matern52, RBF
+    from pssgp.model import StateSpaceGP
+    rng = np.random.RandomState(7)
+    T = 150
+    t = np.sort(rng.rand(T))
+    y = np.sin(np.pi * t) + np.sin(2 * np.pi * t) + 0.3 * rng.randn(T)
+
+    def dense_ll(spec, r):
+        return O.dense_gp(spec, t, y, r)
+
+    def fd(f, x, i, h):
+        e = np.zeros_like(x); e[i] = h
+        return (-f(x + 2 * e) + 8 * f(x + e) - 8 * f(x - e) + f(x - 2 * e)) / (12 * h)
+
+    # sum of Matern kernels: the state-space model is exact, parameters in leaf order then noise
+    m = StateSpaceGP((t[:, None], y[:, None]), Matern32(1.2, 0.4) + Matern52(0.7, 0.6), noise_variance=0.15, parallel=True)
+    assert [n for _, n in m.trainable_parameters()] == ["variance", "lengthscales", "variance", "lengthscales", "noise_variance"]
+    ll, g = m.log_likelihood_and_grad()
+    x0 = np.array([1.2, 0.4, 0.7, 0.6, 0.15])
+    f = lambda x: dense_ll(("sum", [("matern32", x[0], x[1]), ("matern52", x[2], x[3])]), x[4])
+    assert abs(ll - f(x0)) < 1e-6 * abs(f(x0))
+    want = np.array([fd(f, x0, i, 1e-3 * x0[i]) for i in range(5)])
+    assert np.max(np.abs(g - want)) < 1e-5 * np.max(np.abs(want))
+    # RBF order 15
+    m = StateSpaceGP((t[:, None], y[:, None]), RBF(1.1, 0.5, order=15, balancing_iter=10), noise_variance=0.2, parallel=True)
+    ll, g = m.log_likelihood_and_grad()
+    x0 = np.array([1.1, 0.5, 0.2])
+    f = lambda x: dense_ll(("rbf", x[0], x[1]), x[2])
+    want = np.array([fd(f, x0, i, 1e-3 * x0[i]) for i in range(3)])
+    assert abs(ll - f(x0)) < 1e-2 * abs(f(x0))
+    assert np.max(np.abs(g - want)) < 1e-2 * np.max(np.abs(want))
