@@ -74,6 +74,13 @@ __device__ __forceinline__ double mvr(const double* xr, double v, double add) {
     Asm<D>::mv(a0, a1, v, xr);
     return a0 + a1;
 }
+// add + sum_k v_k over the row (every lane gets it)
+template <int D>
+__device__ __forceinline__ double rowsum(double v, double add) {
+    double a0 = add, a1 = 0.0;
+    Asm<D>::rsum(a0, a1, v, 1.0);
+    return a0 + a1;
+}
 // sum_i h_i X[i][lane]: (X^T h)_lane, = (X h)_lane for symmetric X
 template <int D>
 __device__ __forceinline__ double dot_h(const double* x, const double* h) {
@@ -335,6 +342,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
     double h[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) h[i] = a.H[i];
+    const double hl = lv ? a.H[lane] : 0.0;     // this lane's entry of H: row sums of hl * v replace H-weighted ones
     // state entering the chunk: (b, C) of the inclusive prefix of the chunk before (A = 0 there); prior for chunk 0
     double m, P[D];
     {
@@ -419,7 +427,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             const bool upd = FAST || k < k1;
             const bool obs = !(yk != yk);
             double u = dot_h<D>(Pp, h);
-            double S = mvr<D>(h, u, a.R), mu = mvr<D>(h, mp, 0.0);
+            double S = rowsum<D>(hl * u, a.R), mu = rowsum<D>(hl * mp, 0.0);
             if (obs) ll.add(yk - mu, S);
             double mb = mp;
             if (!FAST && blockIdx.x == 0 && s == 0) {
@@ -427,7 +435,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
                 // the likelihood term above used F0 P0 F0^T + Q0 (parallel.py:136-141)
                 const bool first = (c == 0);
                 const double u0 = dot_h<D>(P, h);
-                const double S0 = mvr<D>(h, u0, a.R), mu0 = mvr<D>(h, m, 0.0);
+                const double S0 = rowsum<D>(hl * u0, a.R), mu0 = rowsum<D>(hl * m, 0.0);
 #pragma unroll
                 for (int i = 0; i < D; ++i) Pp[i] = first ? P[i] : Pp[i];
                 mb = first ? m : mp;
