@@ -476,6 +476,99 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a0) {
 }
 
 // ====================================================================================================
+// level 1 of the stand-alone smoother (pks, parallel.py:187-196): smoothing elements from GIVEN filtered
+// moments -- the element part of rc_apply1 with (m, P) of step k read from fms / fPs and the predict taken with
+// F, Q of step k + 1 (parallel.py:159-173); stores E, g, L and the chain's smoothing total.
+// ====================================================================================================
+template <int D, bool FAST>
+__device__ __forceinline__ void selem1_body(const RcArgs& a, double* patch, int lane, int row) {
+    constexpr int dd = D * D;
+    const long kw = (long)blockIdx.x * 4 * a.Lw;
+    const long c = (long)blockIdx.x * 4 + row;
+    const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
+    Io<D> io;
+    io.init(lane, row, a.Lw);
+    const bool lv = io.lv, cv = c < a.nchunk;
+    double Ec[D], L[D], g = 0.0;               // smoothing total of the steps seen so far
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Ec[i] = (i == lane) ? 1.0 : 0.0; L[i] = 0.0; }
+    double Fc[D], Fr[D], Q[D], P[D], m = 0.0;
+    zero<D>(Fc); zero<D>(Fr); zero<D>(Q); zero<D>(P);
+    // step k's filtered moments and step k + 1's (F, Q); at or beyond the end of the series F = 0, Q = I, which
+    // makes the element (0, m, P): the last element for k = N - 1, a no-op on a total whose E is already 0 after it
+    auto load = [&](int s) {
+        const long ku = kw + s, k = k0 + s;
+        if (FAST) {
+            io.template mat_fast<false>(a.Fs + (ku + 1) * dd, Fc);
+            io.template mat_fast<true>(a.Fs + (ku + 1) * dd, Fr);
+            io.template mat_fast<false>(a.Qs + (ku + 1) * dd, Q);
+            io.template mat_fast<false>(a.fPs + ku * dd, P);
+            io.vec_fast(a.fms + ku * D, m);
+        } else {
+            const long kc = ku < a.N ? ku : a.N - 1, kn = ku + 1 < a.N ? ku + 1 : a.N - 1;
+            const bool real = k < k1, nreal = k + 1 < a.N;
+            io.template mat_slow<false>(a.Fs + kn * dd, nreal, 0.0, Fc);
+            io.template mat_slow<true>(a.Fs + kn * dd, nreal, 0.0, Fr);
+            io.template mat_slow<false>(a.Qs + kn * dd, nreal, 1.0, Q);
+            io.template mat_slow<false>(a.fPs + kc * dd, real, 0.0, P);
+            m = io.vec(a.fms + kc * D, real);
+        }
+    };
+    load(0);
+    for (int s = 0; s < a.Lw; ++s) {
+        const long ku = kw + s, k = k0 + s;
+        double Ps[D];
+        symmetrise<D>(P, patch, lane);           // the caller's filtered covariances need not be exactly symmetric
+        copy<D>(Ps, P);
+        const double ms = m;
+        double FP[D], Pp[D];
+        zero<D>(FP); mm<D>(FP, Fc, Ps);
+        copy<D>(Pp, Q); mm<D>(Pp, FP, Fr);
+        const double mp = mvr<D>(Fr, ms, 0.0);
+        if (s + 1 < a.Lw) load(s + 1);
+        symmetrise<D>(Pp, patch, lane);
+        double W[D];
+        copy<D>(W, FP);
+        GjStep<D, 0>::run(Pp, W);                // Pp is not needed afterwards: eliminated in place
+        const double gn = ms - mvr<D>(W, mp, 0.0);
+        double En[D], Ln[D], T[D];
+        transpose<D>(W, En, patch, lane);
+        zero<D>(T); mm<D>(T, En, FP);
+#pragma unroll
+        for (int i = 0; i < D; ++i) Ln[i] = Ps[i] - T[i];
+        {
+            const bool st = FAST || k < k1;
+            io.st_mat(a.sPs + ku * dd, st, En);
+            io.st_mat(a.Lws + ku * dd, st, Ln);
+            io.st_vec(a.sms + ku * D, st, gn);
+        }
+        double E2[D], Er[D];
+        zero<D>(E2); mm<D>(E2, Ec, En);
+        zero<D>(T); mm<D>(T, Ec, Ln);
+        transpose<D>(Ec, Er, patch, lane);
+        g = mvr<D>(Er, gn, g);
+        mm<D>(L, T, Er);
+        symmetrise<D>(L, patch, lane);
+        copy<D>(Ec, E2);
+    }
+    if (cv && lv) {
+        double* rec = a.sagg1 + c * nsmth(D);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { rec[i * D + lane] = Ec[i]; rec[dd + i * D + lane] = L[i]; }
+        rec[2 * dd + lane] = g;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void rc_selem1(const RcArgs a) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    if (blockIdx.x < a.wfast) selem1_body<D, true>(a, patch, lane, row);    // no first-step special case here
+    else selem1_body<D, false>(a, patch, lane, row);
+}
+
+// ====================================================================================================
 // level 1: smoother -- sm = E sm' + g, sP = E sP' E^T + L from the stored elements (parallel.py:176-184)
 // ====================================================================================================
 // PROJ (pgps_lti_predict_*): nothing is stored per step; step k writes  H sm_k  and  H sP_k H^T  to slot qslot[k]
@@ -810,7 +903,8 @@ __global__ __launch_bounds__(64) void rc_discretise(long N, int per, const doubl
 }
 
 // ---- host side: the level-1 launches of one instantiation ---------------------------------------------
-// phase 0: reduce, 1: apply + smoothing elements, 2: apply only, 3: smoother, 4: smoother writing projections
+// phase 0: reduce, 1: apply + smoothing elements, 2: apply only, 3: smoother, 4: smoother writing projections,
+// 5: smoothing elements from given filtered moments (stand-alone pks)
 template <int D>
 int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
     const dim3 blk(64), g1((unsigned)((a.nchunk + 3) / 4), (unsigned)(a.batch > 1 ? a.batch : 1));
@@ -819,6 +913,7 @@ int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
         case 1: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, true>, g1, blk, 0u, a); break;
         case 2: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, false>, g1, blk, 0u, a); break;
         case 3: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D, false>, g1, blk, 0u, a); break;
+        case 5: timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_selem1<D>, g1, blk, 0u, a); break;
         default: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D, true>, g1, blk, 0u, a); break;
     }
     HIPCHK(ctx, hipGetLastError());

@@ -1248,6 +1248,17 @@ static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const d
 static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, double* aggB, double* saggA, double* saggB,
                    double* ll) {
     int rcode;
+    if (mode == MODE_PKS) {                     // stand-alone smoother: elements from the given filtered moments
+        a.sagg1 = saggA;
+        if ((rcode = level1(ctx, d, a, 5))) return rcode;
+        double *ssrc = saggA, *sdst = saggB;
+        for (long s = 1; s < a.nchunk; s *= 2) {
+            if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, ssrc, sdst))) return rcode;
+            double* t = ssrc; ssrc = sdst; sdst = t;
+        }
+        a.suf = ssrc;
+        return level1(ctx, d, a, 3);
+    }
     a.agg1 = aggA;
     if ((rcode = level1(ctx, d, a, 0))) return rcode;
     double *src = aggA, *dst = aggB;
@@ -1321,7 +1332,7 @@ int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* ta
 
 static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, int store_f, const int* qslot, double* pmean,
                          double* pvar, int batch, long bs_model) {
-    if (mode != MODE_PKF && mode != MODE_PKFS) return PGPS_E_UNSUPPORTED_DIM;
+    if (mode != MODE_PKF && mode != MODE_PKFS && mode != MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;
     if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     rc::RcArgs a{};
@@ -1358,7 +1369,7 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
     const size_t o_sagA = off;  off = rc_align(off + nc * ns * sizeof(double));
     const size_t o_sagB = off;  off = rc_align(off + nc * ns * sizeof(double));
     const size_t o_ll = off;    off = rc_align(off + nbm * nc * sizeof(double));
-    const size_t o_L = off;     if (mode == MODE_PKFS) off = rc_align(off + (size_t)sa.N * dd * sizeof(double));
+    const size_t o_L = off;     if (mode != MODE_PKF) off = rc_align(off + (size_t)sa.N * dd * sizeof(double));
     int rcode = ensure(ctx, ctx->ws, off);
     if (rcode) return rcode;
     char* base = (char*)ctx->ws.p;

@@ -157,3 +157,31 @@ def test_rowcoop_c5_large_n_vs_c_oracle():
     again = _gpu_all(ssm, y)
     for k in got:
         assert np.array_equal(got[k], again[k]), k
+
+
+@pytest.mark.parametrize("name,n", [("rbf7", 1500), ("c5_qp_m52", 1201), ("periodic7", 700), ("rbf8", 1)])
+def test_rowcoop_standalone_pks(name, n):
+    """pks(lgssm, fms, fPs) (parallel.py:187-196) on its own for d > 6: smoothing elements from GIVEN filtered
+    moments (here the oracle's), against the oracle's smoother."""
+    from pssgp.kalman.parallel import pks
+    sde = _kernels()[name]().get_sde()
+    t = make_times(n, seed=13)
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series(ssm, seed=13, nan_frac=0.2 if n > 4 else 0.0)
+    fms, fPs, _ = O.kf(ssm, y, True)
+    sms_o, sPs_o = O.kfs(ssm, y)
+    sms, sPs = pks(ssm, fms, fPs)
+    assert relerr(sms, sms_o) < 1e-7 and relerr(sPs, sPs_o) < 1e-7
+
+
+def test_rowcoop_standalone_pks_forced_small_d(row_family):
+    from pssgp.kalman.parallel import pks
+    from pssgp.kernels import Matern52
+    row_family.set_chunk(7)
+    t = make_times(2200, seed=4)
+    ssm = O.get_ssm(Matern52(1., 1.).get_sde(), t, 0.1)
+    y = sample_series(ssm, seed=2, nan_frac=0.1)
+    fms, fPs, _ = O.kf(ssm, y, True)
+    sms_o, sPs_o = O.kfs(ssm, y)
+    sms, sPs = pks(ssm, fms, fPs)
+    assert relerr(sms, sms_o) < TOL64 and relerr(sPs, sPs_o) < TOL64
