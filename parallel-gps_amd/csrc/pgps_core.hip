@@ -327,9 +327,12 @@ template <typename T>
 static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
     if constexpr (sizeof(T) == 8) {
         // row-cooperative family: fp64, d <= 16, whole-series filter / filter+smoother
-        const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax && (mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS);
-        // automatic choice from d = 5: at d = 6 the lane-chunk kernels spill (2^18 steps: 1.29 ms against 0.53 ms)
-        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d >= 5))) return launch_scan_rc(ctx, a, d, mode);
+        const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
+        const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
+        // automatic choice from d = 5: at d = 6 the lane-chunk kernels spill (2^18 steps: 1.29 ms against 0.53 ms);
+        // the segment protocol (multi-GPU) moves over where the lane-chunk family ends
+        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && (whole ? d >= 5 : d > PGPS_MAX_DIM_LANE))))
+            return launch_scan_rc(ctx, a, d, mode);
     }
     if (ctx->family == 3) return PGPS_E_UNSUPPORTED_DIM;
     if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_scan_wc<T>(ctx, a, d, mode);

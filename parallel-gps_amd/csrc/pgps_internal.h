@@ -214,8 +214,14 @@ struct RcArgs {
     const double* pre;          // (nchunk, nfilt) inclusive prefixes of agg1
     double* sagg1;              // (nchunk, nsmth) smoothing totals
     const double* suf;          // (nchunk, nsmth) inclusive suffixes of sagg1
+    double *Es, *gs;            // (N, d, d), (N, d) the smoothing elements' E and g: sPs / sms themselves (overwritten
+                                // in place by the smoother) unless those are not there yet (segments, projections)
     double* Lws;                // (N, d, d) the smoothing elements' L
     double* llpart;             // (nchunk,)
+    int seg_first, seg_last;    // this launch covers the first / last step of the whole series (multi-GPU segments)
+    const double* carry;        // !seg_first: compact filter record of everything before the segment
+    const double *halo_F, *halo_Q;  // !seg_last: F, Q of the first step of the next segment
+    const double* carry_back;   // !seg_last: compact smoother record of everything after the segment
     int batch;                  // models evaluated over the same series (blockIdx.y); 0 / 1 = one
     long bs_F, bs_agg, bs_model;    // per-model strides of Fs / Qs, of agg1 / pre, of the model table
     const double* Rs;           // batch entry point: observation noise of model b at Rs[b * bs_model] (else null)
@@ -227,7 +233,10 @@ struct RcArgs {
 template <int D>
 int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase);
 template <int D>
-int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out, int batch, long bstride);
+int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out, int batch, long bstride,
+                 const double* fixed);
+template <int D>
+int launch_rc_seg_carry(pgps_ctx* ctx, int which, const double* gathered, int rank, int nranks, int reclen, double* out);
 template <int D>
 int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, const double* ts, double t0, double* Fs,
                    double* Qs, int batch, long bs_model);

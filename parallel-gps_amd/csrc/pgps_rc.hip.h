@@ -165,13 +165,14 @@ struct GjStep {
 // selects behind them, so they stay in flight until their first use.
 template <int D>
 struct Io {
-    unsigned oc, orw, ov;               // byte offsets of (0, lane), (lane, 0) and vector element `lane`
+    unsigned oc, orw, ov, ro8;          // byte offsets of (0, lane), (lane, 0), vector element `lane`; of the row's step
     bool lv;
     int lane;
     __device__ __forceinline__ void init(int lane_, int row, int Lw) {
         lane = lane_;
         lv = lane < D;
         const unsigned ro = (unsigned)row * (unsigned)Lw * (unsigned)(D * D);
+        ro8 = ro * 8u;
         oc = lv ? (ro + (unsigned)lane) * 8u : 0u;
         orw = lv ? (ro + (unsigned)(lane * D)) * 8u : 0u;
         ov = lv ? ((unsigned)row * (unsigned)Lw * (unsigned)D + (unsigned)lane) * 8u : 0u;
@@ -262,8 +263,9 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         // chunk 0 starts from (0, 0, P0, 0, 0) and takes step 0 with F = I, Q = 0: that is filt_first
-        A[i] = (c != 0 && i == lane) ? 1.0 : 0.0;
-        C[i] = (c == 0 && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
+        const bool head = (c == 0 && a.seg_first);
+        A[i] = (!head && i == lane) ? 1.0 : 0.0;
+        C[i] = (head && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
         J[i] = 0.0;
     }
     double Fc[D], Fr[D], Q[D], y;
@@ -278,7 +280,7 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
             y = a.ys[k];
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
-            const bool real = k < k1 && k != 0;
+            const bool real = k < k1 && !(k == 0 && a.seg_first);
             io.template mat_slow<false>(a.Fs + kc * dd, real, 1.0, Fc);
             io.template mat_slow<true>(a.Fs + kc * dd, real, 1.0, Fr);
             io.template mat_slow<false>(a.Qs + kc * dd, real, 0.0, Q);
@@ -346,8 +348,9 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
     // state entering the chunk: (b, C) of the inclusive prefix of the chunk before (A = 0 there); prior for chunk 0
     double m, P[D];
     {
-        const bool pr = cv && c > 0;
-        const double* rec = a.pre + (pr ? c - 1 : 0) * nfilt(D);
+        // (a later segment of a sharded series enters its first chain with the carry-in of the ranks before it)
+        const bool pr = cv && (c > 0 || !a.seg_first);
+        const double* rec = c > 0 ? a.pre + (cv ? c - 1 : 0) * nfilt(D) : (a.seg_first ? a.pre : a.carry);
         m = (pr && lv) ? rec[3 * dd + lane] : 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -372,10 +375,14 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             y = a.ys[k];
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
-            const bool real = k < a.N;
-            io.template mat_slow<false>(a.Fs + kc * dd, real, 0.0, Fc);
-            io.template mat_slow<true>(a.Fs + kc * dd, real, 0.0, Fr);
-            io.template mat_slow<false>(a.Qs + kc * dd, real, 1.0, Q);
+            // step N of a segment that is not the last: the first step of the next rank (halo), out of its record
+            const bool hal = (k == a.N) && a.halo_F != nullptr;
+            const bool real = k < a.N || hal;
+            const char* bF = hal ? reinterpret_cast<const char*>(a.halo_F) - io.ro8 : reinterpret_cast<const char*>(a.Fs + kc * dd);
+            const char* bQ = hal ? reinterpret_cast<const char*>(a.halo_Q) - io.ro8 : reinterpret_cast<const char*>(a.Qs + kc * dd);
+            io.template mat_slow<false>(reinterpret_cast<const double*>(bF), real, 0.0, Fc);
+            io.template mat_slow<true>(reinterpret_cast<const double*>(bF), real, 0.0, Fr);
+            io.template mat_slow<false>(reinterpret_cast<const double*>(bQ), real, 1.0, Q);
             y = __builtin_nan("");
             if (s < a.Lw && k < k1) y = a.ys[k];
         }
@@ -408,9 +415,9 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             for (int i = 0; i < D; ++i) Ln[i] = P[i] - T[i];
             {
                 const bool st = FAST || (k - 1 < k1);
-                io.st_mat(a.sPs + (ku - 1) * dd, st, En);
+                io.st_mat(a.Es + (ku - 1) * dd, st, En);
                 io.st_mat(a.Lws + (ku - 1) * dd, st, Ln);
-                io.st_vec(a.sms + (ku - 1) * D, st, gn);
+                io.st_vec(a.gs + (ku - 1) * D, st, gn);
             }
             // total <- total (x) element:  E = Ea En, g = Ea gn + ga, L = Ea Ln Ea^T + La
             double E2[D];
@@ -418,10 +425,23 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             zero<D>(T); mm<D>(T, Ec, Ln);
             double Er[D];                       // the total's E in row layout, made where it is used
             transpose<D>(Ec, Er, patch, lane);
-            g = mvr<D>(Er, gn, g);
-            mm<D>(L, T, Er);
-            symmetrise<D>(L, patch, lane);
-            copy<D>(Ec, E2);
+            if (FAST) {
+                g = mvr<D>(Er, gn, g);
+                mm<D>(L, T, Er);
+                symmetrise<D>(L, patch, lane);
+                copy<D>(Ec, E2);
+            } else {
+                // Beyond the end of a segment that is NOT the last of its series there is nothing to fold: the
+                // F = 0 steps would put E = 0 into a total that the ranks after this one still have to extend.
+                const bool fold = a.seg_last || (k - 1 < a.N);
+                const double g2 = mvr<D>(Er, gn, g);
+                double L2[D];
+                copy<D>(L2, L); mm<D>(L2, T, Er);
+                symmetrise<D>(L2, patch, lane);
+                g = fold ? g2 : g;
+#pragma unroll
+                for (int i = 0; i < D; ++i) { L[i] = fold ? L2[i] : L[i]; Ec[i] = fold ? E2[i] : Ec[i]; }
+            }
         }
         if (s < a.Lw) {
             const bool upd = FAST || k < k1;
@@ -433,7 +453,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             if (!FAST && blockIdx.x == 0 && s == 0) {
                 // first step of the series (chain 0 only): the update uses the prior itself (parallel.py:24-30),
                 // the likelihood term above used F0 P0 F0^T + Q0 (parallel.py:136-141)
-                const bool first = (c == 0);
+                const bool first = (c == 0 && a.seg_first);
                 const double u0 = dot_h<D>(P, h);
                 const double S0 = rowsum<D>(hl * u0, a.R), mu0 = rowsum<D>(hl * m, 0.0);
 #pragma unroll
@@ -538,9 +558,9 @@ __device__ __forceinline__ void selem1_body(const RcArgs& a, double* patch, int 
         for (int i = 0; i < D; ++i) Ln[i] = Ps[i] - T[i];
         {
             const bool st = FAST || k < k1;
-            io.st_mat(a.sPs + ku * dd, st, En);
+            io.st_mat(a.Es + ku * dd, st, En);
             io.st_mat(a.Lws + ku * dd, st, Ln);
-            io.st_vec(a.sms + ku * D, st, gn);
+            io.st_vec(a.gs + ku * D, st, gn);
         }
         double E2[D], Er[D];
         zero<D>(E2); mm<D>(E2, Ec, En);
@@ -587,8 +607,10 @@ __device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int
     // last element has E = 0
     double sm, sP[D];
     {
-        const bool nx = c + 1 < a.nchunk;
-        const double* rec = a.suf + (nx ? c + 1 : 0) * nsmth(D);
+        // (the last chain of a segment that is not the last takes what follows from the ranks after it)
+        const bool inner = c + 1 < a.nchunk;
+        const bool nx = inner || (c + 1 == a.nchunk && a.carry_back != nullptr);
+        const double* rec = inner ? a.suf + (c + 1) * nsmth(D) : (a.carry_back ? a.carry_back : a.suf);
         sm = (nx && lv) ? rec[2 * dd + lane] : 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i) sP[i] = (nx && lv) ? rec[dd + i * D + lane] : 0.0;
@@ -606,16 +628,16 @@ __device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int
         const long ku = kw + s, k = k0 + s;
         if (PROJ) { q = -1; if (FAST || k < k1) q = a.qslot[k]; }
         if (FAST) {
-            io.template mat_fast<false>(a.sPs + ku * dd, Ec);
+            io.template mat_fast<false>(a.Es + ku * dd, Ec);
             io.template mat_fast<false>(a.Lws + ku * dd, L);
-            io.vec_fast(a.sms + ku * D, g);
+            io.vec_fast(a.gs + ku * D, g);
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
             const bool real = k < k1;
-            io.template mat_slow<false>(a.sPs + kc * dd, real, 1.0, Ec);
-            io.template mat_slow<true>(a.sPs + kc * dd, real, 1.0, Er);
+            io.template mat_slow<false>(a.Es + kc * dd, real, 1.0, Ec);
+            io.template mat_slow<true>(a.Es + kc * dd, real, 1.0, Er);
             io.template mat_slow<false>(a.Lws + kc * dd, real, 0.0, L);
-            g = io.vec(a.sms + kc * D, real);
+            g = io.vec(a.gs + kc * D, real);
         }
     };
     load(a.Lw - 1);
@@ -699,36 +721,15 @@ __device__ __forceinline__ void st_rec_mat(double* g, bool ok, int lane, const d
     }
 }
 
-// out[c] = in[c - stride] (x) in[c]   (filt_combine of pgps_math.h, parallel.py:100-118), rearranged so that one
-// elimination with a single right-hand side serves everything:
+// e1 (x) e2, the general filtering operator (filt_combine of pgps_math.h, parallel.py:100-118), rearranged so
+// that one elimination with a single right-hand side serves everything:
 //   M = I + C1 J2;  Nm = M^-1 C1 (symmetric);  z = eta2 - J2 b1;  W = J2 A1;  G = M^-1 A1 = A1 - Nm W
 //   A = A2 G;  b = A2 (b1 + Nm z) + b2;  C = sym(A2 Nm A2^T) + C2;  eta = G^T z + eta1;  J = sym(G^T W) + J1
+// Outputs: Ao, bo, eo, and C2 / J1 updated in place to the result's C / J.
 template <int D>
-__global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const double* in, double* out, long bstride) {
-    __shared__ double tl[4 * kPatch];
-    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
-    in += blockIdx.y * bstride;
-    out += blockIdx.y * bstride;
-    constexpr int dd = D * D, nf = 3 * D * D + 2 * D;
-    const long c = (long)blockIdx.x * 4 + row;
-    const bool lv = lane < D, cv = c < n, comb = cv && c >= stride;
-    const bool ok = lv && cv;
-    // later operand (also the pass-through value)
-    double A2[D], C2[D], J2[D], b2 = 0.0, e2 = 0.0;
-    zero<D>(A2); zero<D>(C2); zero<D>(J2);
-    const double* r2 = in + (cv ? c : 0) * nf;
-    ld_rec_mat<D>(r2, ok, lane, A2); ld_rec_mat<D>(r2 + dd, ok, lane, C2); ld_rec_mat<D>(r2 + 2 * dd, ok, lane, J2);
-    if (ok) { b2 = r2[3 * dd + lane]; e2 = r2[3 * dd + D + lane]; }
-    // earlier operand; rows that only pass through combine with the identity (A = I): same arithmetic, result unused
-    double A1[D], C1[D], J1[D], b1 = 0.0, e1 = 0.0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) { A1[i] = (i == lane) ? 1.0 : 0.0; C1[i] = 0.0; J1[i] = 0.0; }
-    const double* r1 = in + (comb ? c - stride : 0) * nf;
-    const bool ok1 = lv && comb;
-    ld_rec_mat<D>(r1, ok1, lane, A1); ld_rec_mat<D>(r1 + dd, ok1, lane, C1); ld_rec_mat<D>(r1 + 2 * dd, ok1, lane, J1);
-    if (ok1) { b1 = r1[3 * dd + lane]; e1 = r1[3 * dd + D + lane]; }
-
+__device__ __forceinline__ void filt_combine_rc(double* patch, int lane, const double* A1, const double* C1, double* J1,
+                                                double b1, double e1, const double* A2, double* C2, const double* J2,
+                                                double b2, double e2, double* Ao, double& bo, double& eo) {
     double M[D], Nm[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) { M[i] = (i == lane) ? 1.0 : 0.0; Nm[i] = C1[i]; }
@@ -740,22 +741,80 @@ __global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const do
     zero<D>(T); mm<D>(T, Nm, W);
 #pragma unroll
     for (int i = 0; i < D; ++i) G[i] = A1[i] - T[i];
-    double Ao[D], X[D], A2r[D], Gt[D];
+    double X[D], A2r[D], Gt[D];
     zero<D>(Ao); mm<D>(Ao, A2, G);
     zero<D>(X); mm<D>(X, A2, Nm);
     transpose<D>(A2, A2r, patch, lane);
     mm<D>(C2, X, A2r);                          // C2 <- C2 + A2 Nm A2^T
     symmetrise<D>(C2, patch, lane);
     const double w = mvr<D>(Nm, z, b1);         // b1 + Nm z   (Nm symmetric: its column layout is its row layout)
-    const double bo = mvr<D>(A2r, w, b2);
-    const double eo = mvr<D>(G, z, e1);         // G^T z + eta1
+    bo = mvr<D>(A2r, w, b2);
+    eo = mvr<D>(G, z, e1);                      // G^T z + eta1
     transpose<D>(G, Gt, patch, lane);
     mm<D>(J1, Gt, W);                           // J1 <- J1 + G^T W
     symmetrise<D>(J1, patch, lane);
+}
+
+// a (x) b in time order (smth_combine, parallel.py:176-184):  E = Ea Eb;  g = Ea gb + ga;  L = sym(Ea Lb Ea^T) + La
+template <int D>
+__device__ __forceinline__ void smth_combine_rc(double* patch, int lane, const double* Ea, const double* La, double ga,
+                                                const double* Eb, const double* Lb, double gb, double* Eo, double* Lo,
+                                                double& go) {
+    double T[D], Ear[D];
+    zero<D>(Eo); mm<D>(Eo, Ea, Eb);
+    zero<D>(T); mm<D>(T, Ea, Lb);
+    transpose<D>(Ea, Ear, patch, lane);
+    go = mvr<D>(Ear, gb, ga);
+    copy<D>(Lo, La); mm<D>(Lo, T, Ear);
+    symmetrise<D>(Lo, patch, lane);
+}
+
+// compact records in global memory: filter [A | C | J | b | eta], smoother [E | L | g]
+template <int D>
+__device__ __forceinline__ void ld_filt(const double* r, bool ok, int lane, double* A, double* C, double* J, double& b,
+                                        double& e) {
+    constexpr int dd = D * D;
+    ld_rec_mat<D>(r, ok, lane, A); ld_rec_mat<D>(r + dd, ok, lane, C); ld_rec_mat<D>(r + 2 * dd, ok, lane, J);
+    if (ok) { b = r[3 * dd + lane]; e = r[3 * dd + D + lane]; }
+}
+template <int D>
+__device__ __forceinline__ void st_filt(double* r, bool ok, int lane, const double* A, const double* C, const double* J,
+                                        double b, double e) {
+    constexpr int dd = D * D;
+    st_rec_mat<D>(r, ok, lane, A); st_rec_mat<D>(r + dd, ok, lane, C); st_rec_mat<D>(r + 2 * dd, ok, lane, J);
+    if (ok) { r[3 * dd + lane] = b; r[3 * dd + D + lane] = e; }
+}
+
+// out[c] = in[c - stride] (x) in[c]; with `fixed` given: out[c] = fixed (x) in[c] for every c (a segment's
+// carry-in combined into all its prefixes)
+template <int D>
+__global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const double* in, double* out, long bstride,
+                                                   const double* fixed) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    in += blockIdx.y * bstride;
+    out += blockIdx.y * bstride;
+    constexpr int dd = D * D, nf = 3 * D * D + 2 * D;
+    const long c = (long)blockIdx.x * 4 + row;
+    const bool lv = lane < D, cv = c < n, comb = cv && (fixed != nullptr || c >= stride);
+    const bool ok = lv && cv;
+    // later operand (also the pass-through value)
+    double A2[D], C2[D], J2[D], b2 = 0.0, e2 = 0.0;
+    zero<D>(A2); zero<D>(C2); zero<D>(J2);
+    const double* r2 = in + (cv ? c : 0) * nf;
+    ld_filt<D>(r2, ok, lane, A2, C2, J2, b2, e2);
+    // earlier operand; rows that only pass through combine with the identity (A = I): same arithmetic, result unused
+    double A1[D], C1[D], J1[D], b1 = 0.0, e1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { A1[i] = (i == lane) ? 1.0 : 0.0; C1[i] = 0.0; J1[i] = 0.0; }
+    const double* r1 = fixed ? fixed : in + (comb ? c - stride : 0) * nf;
+    ld_filt<D>(r1, lv && comb, lane, A1, C1, J1, b1, e1);
+    double Ao[D], bo, eo;
+    filt_combine_rc<D>(patch, lane, A1, C1, J1, b1, e1, A2, C2, J2, b2, e2, Ao, bo, eo);
     double* ro = out + (cv ? c : 0) * nf;
     if (comb) {
-        st_rec_mat<D>(ro, ok, lane, Ao); st_rec_mat<D>(ro + dd, ok, lane, C2); st_rec_mat<D>(ro + 2 * dd, ok, lane, J1);
-        if (ok) { ro[3 * dd + lane] = bo; ro[3 * dd + D + lane] = eo; }
+        st_filt<D>(ro, ok, lane, Ao, C2, J1, bo, eo);
     } else if (ok) {
         // pass-through: reload (C2 was overwritten above) and copy
 #pragma unroll
@@ -769,16 +828,15 @@ __global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const do
     }
 }
 
-// out[c] = in[c] (x) in[c + stride] in time order (smth_combine, parallel.py:176-184):
-//   E = Ea Eb;  g = Ea gb + ga;  L = sym(Ea Lb Ea^T) + La
+// out[c] = in[c] (x) in[c + stride] in time order; with `fixed` given: out[c] = in[c] (x) fixed for every c
 template <int D>
-__global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const double* in, double* out) {
+__global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const double* in, double* out, const double* fixed) {
     __shared__ double tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     double* patch = patch_init(tl, row);
     constexpr int dd = D * D, ns = 2 * D * D + D;
     const long c = (long)blockIdx.x * 4 + row;
-    const bool lv = lane < D, cv = c < n, comb = cv && c + stride < n;
+    const bool lv = lane < D, cv = c < n, comb = cv && (fixed != nullptr || c + stride < n);
     const bool ok = lv && cv, okb = lv && comb;
     double Ea[D], La[D], ga = 0.0;
     zero<D>(Ea); zero<D>(La);
@@ -788,17 +846,11 @@ __global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const 
     double Eb[D], Lb[D], gb = 0.0;
 #pragma unroll
     for (int i = 0; i < D; ++i) { Eb[i] = (i == lane) ? 1.0 : 0.0; Lb[i] = 0.0; }      // identity when passing through
-    const double* rb = in + (comb ? c + stride : 0) * ns;
+    const double* rb = fixed ? fixed : in + (comb ? c + stride : 0) * ns;
     ld_rec_mat<D>(rb, okb, lane, Eb); ld_rec_mat<D>(rb + dd, okb, lane, Lb);
     if (okb) gb = rb[2 * dd + lane];
-    double Eo[D], T[D], Ear[D];
-    zero<D>(Eo); mm<D>(Eo, Ea, Eb);
-    zero<D>(T); mm<D>(T, Ea, Lb);
-    transpose<D>(Ea, Ear, patch, lane);
-    const double go = mvr<D>(Ear, gb, ga);
-    double Lo[D];
-    copy<D>(Lo, La); mm<D>(Lo, T, Ear);
-    symmetrise<D>(Lo, patch, lane);
+    double Eo[D], Lo[D], go;
+    smth_combine_rc<D>(patch, lane, Ea, La, ga, Eb, Lb, gb, Eo, Lo, go);
     double* ro = out + (cv ? c : 0) * ns;
     if (comb) {
         st_rec_mat<D>(ro, ok, lane, Eo); st_rec_mat<D>(ro + dd, ok, lane, Lo);
@@ -807,6 +859,76 @@ __global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const 
         st_rec_mat<D>(ro, ok, lane, Ea); st_rec_mat<D>(ro + dd, ok, lane, La);
         if (ok) ro[2 * dd + lane] = ga;
     }
+}
+
+// ---- segment stitching (multi-GPU, pssgp/distributed.py): the exchanged records are the lane-chunk family's
+// packed ones, filter [A | b | C sym | J sym | eta | F_0 | Q_0], smoother [E | g | L sym | pad | ll] -------------
+template <int D>
+__device__ __forceinline__ int symidx(int i, int j) { return i <= j ? (i * D - (i * (i - 1)) / 2 + (j - i)) : (j * D - (j * (j - 1)) / 2 + (i - j)); }
+
+// carry-in of segment `rank` (> 0): total_0 (x) ... (x) total_{rank-1}, written as a compact filter record.  One
+// wave; the four rows do the same work, row 0 stores.
+template <int D>
+__global__ __launch_bounds__(64) void rc_seg_carry_f(const double* gathered, int rank, int reclen, double* out) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    constexpr int dd = D * D, SYM = D * (D + 1) / 2;
+    const bool lv = lane < D;
+    auto load = [&](int j, double* A, double* C, double* J, double& b, double& e) {
+        const double* r = gathered + (long)j * reclen;
+        zero<D>(A); zero<D>(C); zero<D>(J); b = 0.0; e = 0.0;
+        if (lv) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                A[i] = r[i * D + lane];
+                C[i] = r[dd + D + symidx<D>(i, lane)];
+                J[i] = r[dd + D + SYM + symidx<D>(i, lane)];
+            }
+            b = r[dd + lane];
+            e = r[dd + D + 2 * SYM + lane];
+        }
+    };
+    double A1[D], C1[D], J1[D], b1, e1;
+    load(0, A1, C1, J1, b1, e1);
+    for (int j = 1; j < rank; ++j) {
+        double A2[D], C2[D], J2[D], b2, e2, Ao[D], bo, eo;
+        load(j, A2, C2, J2, b2, e2);
+        filt_combine_rc<D>(patch, lane, A1, C1, J1, b1, e1, A2, C2, J2, b2, e2, Ao, bo, eo);
+        copy<D>(A1, Ao); copy<D>(C1, C2);       // J1 already holds the result's J
+        b1 = bo; e1 = eo;
+    }
+    st_filt<D>(out, lv && row == 0, lane, A1, C1, J1, b1, e1);
+}
+
+// what follows segment `rank` (< nranks - 1): total_{rank+1} (x) ... (x) total_{nranks-1} as a compact smoother record
+template <int D>
+__global__ __launch_bounds__(64) void rc_seg_carry_s(const double* gathered, int rank, int nranks, int reclen, double* out) {
+    __shared__ double tl[4 * kPatch];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    double* patch = patch_init(tl, row);
+    constexpr int dd = D * D;
+    const bool lv = lane < D;
+    auto load = [&](int j, double* E, double* L, double& g) {
+        const double* r = gathered + (long)j * reclen;
+        zero<D>(E); zero<D>(L); g = 0.0;
+        if (lv) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) { E[i] = r[i * D + lane]; L[i] = r[dd + D + symidx<D>(i, lane)]; }
+            g = r[dd + lane];
+        }
+    };
+    double Ea[D], La[D], ga;
+    load(rank + 1, Ea, La, ga);
+    for (int j = rank + 2; j < nranks; ++j) {
+        double Eb[D], Lb[D], gb, Eo[D], Lo[D], go;
+        load(j, Eb, Lb, gb);
+        smth_combine_rc<D>(patch, lane, Ea, La, ga, Eb, Lb, gb, Eo, Lo, go);
+        copy<D>(Ea, Eo); copy<D>(La, Lo); ga = go;
+    }
+    const bool ok = lv && row == 0;
+    st_rec_mat<D>(out, ok, lane, Ea); st_rec_mat<D>(out + dd, ok, lane, La);
+    if (ok) out[2 * dd + lane] = ga;
 }
 
 // ====================================================================================================
@@ -922,10 +1044,11 @@ int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
 
 // one Kogge-Stone step over n records: which = 0 filter totals (prefix), 1 smoothing totals (suffix)
 template <int D>
-int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out, int batch, long bstride) {
+int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out, int batch, long bstride,
+                 const double* fixed) {
     const dim3 blk(64), g((unsigned)((n + 3) / 4), (unsigned)batch);
-    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<D>, g, blk, 0u, n, stride, in, out, bstride);
-    else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<D>, g, blk, 0u, n, stride, in, out);
+    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<D>, g, blk, 0u, n, stride, in, out, bstride, fixed);
+    else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<D>, g, blk, 0u, n, stride, in, out, fixed);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }
@@ -937,6 +1060,15 @@ int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, c
     const long grid = (N + 4L * per - 1) / (4L * per);
     timed_launch(ctx, PGPS_K_DISCRETISE, rc_discretise<D>, dim3((unsigned)grid, (unsigned)batch), dim3(64), 0u, N, per, F, Pinf,
                  ts, t0, Fs, Qs, bs_model);
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+// carry records of a segment from the gathered packed totals: which = 0 carry-in (filter), 1 carry-back (smoother)
+template <int D>
+int launch_rc_seg_carry(pgps_ctx* ctx, int which, const double* gathered, int rank, int nranks, int reclen, double* out) {
+    if (which == 0) hipLaunchKernelGGL(rc_seg_carry_f<D>, dim3(1), dim3(64), 0, ctx->stream, gathered, rank, reclen, out);
+    else hipLaunchKernelGGL(rc_seg_carry_s<D>, dim3(1), dim3(64), 0, ctx->stream, gathered, rank, nranks, reclen, out);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

@@ -5,7 +5,8 @@
 namespace pgps {
 namespace rc {
 template int launch_rc_level1<PGPS_RC_D>(pgps_ctx*, const RcArgs&, int);
-template int launch_rc_ks<PGPS_RC_D>(pgps_ctx*, int, long, long, const double*, double*, int, long);
+template int launch_rc_ks<PGPS_RC_D>(pgps_ctx*, int, long, long, const double*, double*, int, long, const double*);
+template int launch_rc_seg_carry<PGPS_RC_D>(pgps_ctx*, int, const double*, int, int, int, double*);
 template int launch_rc_disc<PGPS_RC_D>(pgps_ctx*, long, const double*, const double*, const double*, double, double*, double*, int, long);
 }  // namespace rc
 }  // namespace pgps

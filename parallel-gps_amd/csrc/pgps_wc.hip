@@ -1234,15 +1234,151 @@ static int level1(pgps_ctx* ctx, int d, const RcArgs& a, int phase) {
 }
 
 static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const double* in, double* out, int batch = 1,
-                   long bstride = 0) {
+                   long bstride = 0, const double* fixed = nullptr) {
     switch (d) {
-#define PGPS_RC_CASE(DV) case DV: return launch_rc_ks<DV>(ctx, which, n, stride, in, out, batch, bstride);
+#define PGPS_RC_CASE(DV) case DV: return launch_rc_ks<DV>(ctx, which, n, stride, in, out, batch, bstride, fixed);
         PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
         PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
         PGPS_RC_CASE(15) PGPS_RC_CASE(16)
 #undef PGPS_RC_CASE
     }
     return PGPS_E_UNSUPPORTED_DIM;
+}
+
+static int seg_carry(pgps_ctx* ctx, int d, int which, const double* gathered, int rank, int nranks, int reclen, double* out) {
+    switch (d) {
+#define PGPS_RC_CASE(DV) case DV: return launch_rc_seg_carry<DV>(ctx, which, gathered, rank, nranks, reclen, out);
+        PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
+        PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
+        PGPS_RC_CASE(15) PGPS_RC_CASE(16)
+#undef PGPS_RC_CASE
+    }
+    return PGPS_E_UNSUPPORTED_DIM;
+}
+
+__host__ __device__ inline int sym_index(int d, int i, int j) {
+    return i <= j ? (i * d - (i * (i - 1)) / 2 + (j - i)) : (j * d - (j * (j - 1)) / 2 + (i - j));
+}
+// this segment's filter record [A | b | C sym | J sym | eta | F_0 | Q_0] from the compact total [A | C | J | b | eta]
+static __global__ __launch_bounds__(256) void seg_pack_f(int d, const double* tot, const double* Fs, const double* Qs, double* rec) {
+    const int dd = d * d, sym = d * (d + 1) / 2;
+    for (int e = threadIdx.x; e < dd; e += 256) {
+        const int i = e / d, j = e % d;
+        rec[e] = tot[e];
+        if (i <= j) {
+            rec[dd + d + sym_index(d, i, j)] = tot[dd + e];
+            rec[dd + d + sym + sym_index(d, i, j)] = tot[2 * dd + e];
+        }
+        rec[dd + 2 * d + 2 * sym + e] = Fs[e];
+        rec[2 * dd + 2 * d + 2 * sym + e] = Qs[e];
+    }
+    for (int e = threadIdx.x; e < d; e += 256) { rec[dd + e] = tot[3 * dd + e]; rec[dd + d + 2 * sym + e] = tot[3 * dd + d + e]; }
+}
+// this segment's smoother record [E | g | L sym | pad | ll partial] from the compact total [E | L | g]
+static __global__ __launch_bounds__(256) void seg_pack_s(int d, const double* tot, const double* llpart, long nchunk, int pad,
+                                                         double* rec) {
+    __shared__ double part[4];
+    const int dd = d * d;
+    for (int e = threadIdx.x; e < dd; e += 256) {
+        const int i = e / d, j = e % d;
+        rec[e] = tot[e];
+        if (i <= j) rec[dd + d + sym_index(d, i, j)] = tot[dd + e];
+    }
+    for (int e = threadIdx.x; e < d; e += 256) rec[dd + e] = tot[2 * dd + e];
+    double t = 0.0;
+    for (long c = threadIdx.x; c < nchunk; c += 256) t += llpart[c];
+    t = wc::wave_sum(t);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) rec[pad] = part[0] + part[1] + part[2] + part[3];
+}
+static __global__ void seg_ll_sum(const double* gathered_s, int nranks, int reclen, int pad, double* ll) {
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int r = 0; r < nranks; ++r) t += gathered_s[(long)r * reclen + pad];
+        *ll = t;
+    }
+}
+
+struct SegInfo {
+    int rank, nranks;
+    double* rec_f; const double* gathered_f;
+    double* rec_s; const double* gathered_s;
+    double *carry_rec, *cb_rec;         // scratch: compact carry-in / carry-back records
+};
+
+// number of Kogge-Stone steps over n records, and the buffer the result ends up in
+static inline double* ks_result(long n, double* A, double* B) {
+    int steps = 0;
+    for (long s = 1; s < n; s *= 2) ++steps;
+    return (steps & 1) ? B : A;
+}
+
+// One phase of the segment protocol (pssgp/distributed.py): scratch (chain totals, their scans, the stored smoothing
+// elements) stays in the context's workspace between the three calls of a pass.
+static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, double* aggB, double* saggA, double* saggB,
+                       const SegInfo& sg, double* ll) {
+    int rcode;
+    const int nf = wc::nfilt(d), ns = wc::nsmth(d);
+    const int rf = seg_rec_f_len(d), rs = seg_rec_s_len(d), pad = seg_rec_s_pad(d);
+    const int nfp = d * d + d + d * (d + 1) + d;            // packed 5-tuple inside the filter record
+    a.seg_first = sg.rank == 0;
+    a.seg_last = sg.rank == sg.nranks - 1;
+    if (mode == MODE_SEG_REDUCE) {
+        a.agg1 = aggA;
+        if ((rcode = level1(ctx, d, a, 0))) return rcode;
+        double *src = aggA, *dst = aggB;
+        for (long s = 1; s < a.nchunk; s *= 2) {
+            if ((rcode = ks_step(ctx, d, 0, a.nchunk, s, src, dst))) return rcode;
+            double* t = src; src = dst; dst = t;
+        }
+        hipLaunchKernelGGL(seg_pack_f, dim3(1), dim3(256), 0, ctx->stream, d, (const double*)(src + (a.nchunk - 1) * nf), a.Fs,
+                           a.Qs, sg.rec_f);
+        HIPCHK(ctx, hipGetLastError());
+        return PGPS_OK;
+    }
+    if (mode == MODE_SEG_FILTER) {
+        double* pre = ks_result(a.nchunk, aggA, aggB);
+        if (!a.seg_first) {
+            // everything before this segment, combined into every local prefix (and the entry state of chain 0)
+            if ((rcode = seg_carry(ctx, d, 0, sg.gathered_f, sg.rank, sg.nranks, rf, sg.carry_rec))) return rcode;
+            double* other = pre == aggA ? aggB : aggA;
+            if ((rcode = ks_step(ctx, d, 0, a.nchunk, 0, pre, other, 1, 0, sg.carry_rec))) return rcode;
+            pre = other;
+            a.carry = sg.carry_rec;
+        }
+        if (!a.seg_last) {
+            a.halo_F = sg.gathered_f + (long)(sg.rank + 1) * rf + nfp;
+            a.halo_Q = a.halo_F + (long)d * d;
+        }
+        a.pre = pre;
+        a.sagg1 = saggA;
+        if ((rcode = level1(ctx, d, a, 1))) return rcode;
+        double *src = saggA, *dst = saggB;
+        for (long s = 1; s < a.nchunk; s *= 2) {
+            if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, src, dst))) return rcode;
+            double* t = src; src = dst; dst = t;
+        }
+        hipLaunchKernelGGL(seg_pack_s, dim3(1), dim3(256), 0, ctx->stream, d, (const double*)src, (const double*)a.llpart,
+                           (long)a.nchunk, pad, sg.rec_s);
+        HIPCHK(ctx, hipGetLastError());
+        return PGPS_OK;
+    }
+    // MODE_SEG_SMOOTHER
+    double* suf = ks_result(a.nchunk, saggA, saggB);
+    if (!a.seg_last) {
+        if ((rcode = seg_carry(ctx, d, 1, sg.gathered_s, sg.rank, sg.nranks, rs, sg.cb_rec))) return rcode;
+        double* other = suf == saggA ? saggB : saggA;
+        if ((rcode = ks_step(ctx, d, 1, a.nchunk, 0, suf, other, 1, 0, sg.cb_rec))) return rcode;
+        suf = other;
+        a.carry_back = sg.cb_rec;
+    }
+    a.suf = suf;
+    if ((rcode = level1(ctx, d, a, 3))) return rcode;
+    if (ll) hipLaunchKernelGGL(seg_ll_sum, dim3(1), dim3(64), 0, ctx->stream, sg.gathered_s, sg.nranks, rs, pad, ll);
+    HIPCHK(ctx, hipGetLastError());
+    (void)ns;
+    return PGPS_OK;
 }
 
 static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, double* aggB, double* saggA, double* saggB,
@@ -1332,7 +1468,7 @@ int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* ta
 
 static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, int store_f, const int* qslot, double* pmean,
                          double* pvar, int batch, long bs_model) {
-    if (mode != MODE_PKF && mode != MODE_PKFS && mode != MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;
+    const bool seg = mode == MODE_SEG_REDUCE || mode == MODE_SEG_FILTER || mode == MODE_SEG_SMOOTHER;
     if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     rc::RcArgs a{};
@@ -1356,6 +1492,7 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs;
     a.store_f = store_f; a.qslot = qslot; a.pmean = pmean; a.pvar = pvar;
+    a.seg_first = 1; a.seg_last = 1;
     const size_t dd = (size_t)d * d, nf = wc::nfilt(d), ns = wc::nsmth(d), nc = (size_t)a.nchunk;
     const size_t nbm = batch > 1 ? (size_t)batch : 1;
     if (bs_model > 0) {                                             // the batch entry point, B >= 1
@@ -1369,14 +1506,28 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
     const size_t o_sagA = off;  off = rc_align(off + nc * ns * sizeof(double));
     const size_t o_sagB = off;  off = rc_align(off + nc * ns * sizeof(double));
     const size_t o_ll = off;    off = rc_align(off + nbm * nc * sizeof(double));
+    const size_t o_cf = off;    off = rc_align(off + nf * sizeof(double));
+    const size_t o_cs = off;    off = rc_align(off + ns * sizeof(double));
     const size_t o_L = off;     if (mode != MODE_PKF) off = rc_align(off + (size_t)sa.N * dd * sizeof(double));
+    // segments: the smoothing elements wait in scratch until the smoother phase brings sms / sPs
+    const size_t o_E = off;     if (seg) off = rc_align(off + (size_t)sa.N * dd * sizeof(double));
+    const size_t o_g = off;     if (seg) off = rc_align(off + (size_t)sa.N * d * sizeof(double));
     int rcode = ensure(ctx, ctx->ws, off);
     if (rcode) return rcode;
     char* base = (char*)ctx->ws.p;
     a.llpart = (double*)(base + o_ll);
     a.Lws = (double*)(base + o_L);
+    a.Es = seg ? (double*)(base + o_E) : a.sPs;
+    a.gs = seg ? (double*)(base + o_g) : a.sms;
     double* aggA = (double*)(base + o_aggA); double* aggB = (double*)(base + o_aggB);
     double* sagA = (double*)(base + o_sagA); double* sagB = (double*)(base + o_sagB);
+    if (seg) {
+        rc::SegInfo sg{};
+        sg.rank = sa.rank; sg.nranks = sa.nranks;
+        sg.rec_f = sa.rec_f; sg.gathered_f = sa.gathered_f; sg.rec_s = sa.rec_s; sg.gathered_s = sa.gathered_s;
+        sg.carry_rec = (double*)(base + o_cf); sg.cb_rec = (double*)(base + o_cs);
+        return rc::scan_rc_seg(ctx, d, a, mode, aggA, aggB, sagA, sagB, sg, sa.ll);
+    }
     return rc::scan_rc(ctx, d, a, mode, aggA, aggB, sagA, sagB, sa.ll);
 }
 

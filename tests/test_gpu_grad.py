@@ -81,10 +81,15 @@ def test_gradient_descends():
 
 
 def test_gradient_rejects_unsupported():
-    """Kernels outside the closed-form (Matern) discretisation have no gradient path yet: loud error."""
-    from pssgp.kernels import RBF
+    """Outside the dual-number (Matern) path and the batched-difference path (fp64, d <= 16) there is no gradient:
+    loud error, e.g. Periodic order 10 (d = 22) or the sequential model."""
+    from pssgp.kernels import Periodic, RBF, SquaredExponential
     from pssgp.model import StateSpaceGP
     t = np.linspace(0.0, 1.0, 50)
-    m = StateSpaceGP((t[:, None], np.sin(t)[:, None]), RBF(1.0, 1.0, order=6, balancing_iter=5), 0.1, parallel=True)
+    m = StateSpaceGP((t[:, None], np.sin(t)[:, None]), Periodic(SquaredExponential(1., 0.5), period=0.5, order=10), 0.1,
+                     parallel=True)
+    with pytest.raises(NotImplementedError):
+        m.log_likelihood_and_grad()
+    m = StateSpaceGP((t[:, None], np.sin(t)[:, None]), RBF(1.0, 1.0, order=6, balancing_iter=5), 0.1, parallel=False)
     with pytest.raises(NotImplementedError):
         m.log_likelihood_and_grad()
