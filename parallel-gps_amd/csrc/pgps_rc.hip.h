@@ -979,27 +979,49 @@ __global__ __launch_bounds__(64) void rc_discretise(long N, int per, const doubl
         zero<D>(A2); mm<D>(A2, A, A);
         zero<D>(A4); mm<D>(A4, A2, A2);
         zero<D>(A6); mm<D>(A6, A4, A2);
-        // U = A (A6 (b13 A6 + b11 A4 + b9 A2) + b7 A6 + b5 A4 + b3 A2 + b1 I)
+        // Degree of the approximant, as tf.linalg.expm chooses it from the 1-norm (theta_7 = 0.95, else 13); one
+        // choice per wave -- the largest norm of its four rows decides.
+        double nmax = nrm;
+        nmax = fmax(nmax, __shfl_xor(nmax, 16, 64));
+        nmax = fmax(nmax, __shfl_xor(nmax, 32, 64));
+        double U[D], V[D], R[D];
+        if (nmax <= 0.9504178996162932) {
+            // Pade-7: U = A (c7 A6 + c5 A4 + c3 A2 + c1 I), V = c6 A6 + c4 A4 + c2 A2 + c0 I
+            const double c[8] = {17297280., 8648640., 1995840., 277200., 25200., 1512., 56., 1.};
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            W[i] = b[13] * A6[i] + b[11] * A4[i] + b[9] * A2[i];
-            Z[i] = b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i] + ((i == lane) ? b[1] : 0.0);
+            for (int i = 0; i < D; ++i) {
+                Z[i] = c[7] * A6[i] + c[5] * A4[i] + c[3] * A2[i] + ((i == lane) ? c[1] : 0.0);
+                V[i] = c[6] * A6[i] + c[4] * A4[i] + c[2] * A2[i] + ((i == lane) ? c[0] : 0.0);
+            }
+            zero<D>(U); mm<D>(U, A, Z);
+            // |A|_1 <= theta_7 makes (V - U) / c0 = I - E with |E|_1 <= e^{0.48} - 1 < 1: strictly column diagonally
+            // dominant, elimination without pivoting is stable (lanes >= D: give their zero columns a unit diagonal)
+            double M[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { M[i] = V[i] - U[i] + ((i == lane && !lv) ? 1.0 : 0.0); R[i] = V[i] + U[i]; }
+            GjStep<D, 0>::run(M, R);
+        } else {
+            // Pade-13: U = A (A6 (b13 A6 + b11 A4 + b9 A2) + b7 A6 + b5 A4 + b3 A2 + b1 I)
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                W[i] = b[13] * A6[i] + b[11] * A4[i] + b[9] * A2[i];
+                Z[i] = b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i] + ((i == lane) ? b[1] : 0.0);
+            }
+            mm<D>(Z, A6, W);
+            zero<D>(U); mm<D>(U, A, Z);
+            // V = A6 (b12 A6 + b10 A4 + b8 A2) + b6 A6 + b4 A4 + b2 A2 + b0 I
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                W[i] = b[12] * A6[i] + b[10] * A4[i] + b[8] * A2[i];
+                V[i] = b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i] + ((i == lane) ? b[0] : 0.0);
+            }
+            mm<D>(V, A6, W);
+            // (V - U) R = V + U, partial pivoting (lanes >= D: zero columns, they never pivot)
+            double M[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { M[i] = V[i] - U[i]; R[i] = V[i] + U[i]; }
+            GjPivStep<D, 0>::run(M, R);
         }
-        mm<D>(Z, A6, W);
-        double U[D], V[D];
-        zero<D>(U); mm<D>(U, A, Z);
-        // V = A6 (b12 A6 + b10 A4 + b8 A2) + b6 A6 + b4 A4 + b2 A2 + b0 I
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            W[i] = b[12] * A6[i] + b[10] * A4[i] + b[8] * A2[i];
-            V[i] = b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i] + ((i == lane) ? b[0] : 0.0);
-        }
-        mm<D>(V, A6, W);
-        // (V - U) R = V + U; lanes >= D get a unit diagonal nowhere (their columns are zero and never pivot)
-        double M[D], R[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) { M[i] = V[i] - U[i]; R[i] = V[i] + U[i]; }
-        GjPivStep<D, 0>::run(M, R);
         // squarings: the count differs between the rows of a wave
         int smax = sq;
         smax = max(smax, __shfl_xor(smax, 16, 64));
