@@ -63,7 +63,8 @@ int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
  * 0 = off (three-launch reduce-then-scan), 1 = on; window = tiles per look-back window (1..256, 0 = keep). */
 int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
 /* Kernel family: 0 = automatic (lane-chunk for d <= 4 and for fp32 up to PGPS_MAX_DIM_LANE; row-cooperative for
- * fp64 with 5 <= d <= 16 in whole-series pkf / pkfs calls; wave-cooperative otherwise, d <= 32),
+ * fp64 with 5 <= d <= 16 -- fp32 series at 7 <= d <= 16 are widened to fp64 for it, segments use it above d = 6;
+ * wave-cooperative otherwise, d <= 32),
  * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64, 2 <= d <= 16). */
 int pgps_set_family(pgps_ctx* ctx, int family);
 /* LDS staging of the lane-chunk kernels: -1 = automatic, 0 = off (direct global accesses),

@@ -1,6 +1,7 @@
 // pgps_core.hip -- the C ABI of libpgps.so (include/pgps.h): context, scratch, staging and
 // dimension dispatch.  The kernels live in pgps_inst.hip (one unit per dtype x state dim).
 // No PyTorch, no TensorFlow: HIP runtime only.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 #include <cstdio>
@@ -323,8 +324,57 @@ extern "C" int pgps_get_chunk(pgps_ctx* ctx, long N, int* Lc, int* nb) {
     return PGPS_OK;
 }
 
+// fp32 series at 7 <= d <= 16 (whole-series calls): widened to fp64 scratch, run on the row-cooperative kernels,
+// narrowed back.  Three to four times faster than the fp32 wave-cooperative kernels at d = 15 despite the two
+// conversion passes, and the arithmetic is then exact to fp32 rounding of inputs and outputs.
+namespace pgps {
+static __global__ void k_widen(long n, const float* in, double* out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (double)in[i];
+}
+static __global__ void k_narrow(long n, const double* in, float* out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+}  // namespace pgps
+
+static int scan_f32_via_f64(pgps_ctx* ctx, int d, const ScanArgs<float>& a, Mode mode) {
+    const size_t N = (size_t)a.N, dd = (size_t)d * d;
+    const bool pks = mode == MODE_PKS, smooth = mode != MODE_PKF;
+    // one scratch block: [P0 | H | Fs | Qs | ys | fms | fPs | sms | sPs]
+    const size_t n_small = dd + d, n_in = 2 * N * dd + N, n_f = N * d + N * dd, n_s = smooth ? N * d + N * dd : 0;
+    int rc_ = ensure(ctx, ctx->lti[6], (n_small + n_in + n_f + n_s) * sizeof(double));
+    if (rc_) return rc_;
+    double* base = (double*)ctx->lti[6].p;
+    double *P0 = base, *H = P0 + dd, *Fs = H + d, *Qs = Fs + N * dd, *ys = Qs + N * dd, *fms = ys + N, *fPs = fms + N * d,
+           *sms = fPs + N * dd, *sPs = sms + N * d;
+    auto widen = [&](const float* in, double* out, size_t n) {
+        if (in && n) hipLaunchKernelGGL(pgps::k_widen, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
+                                        (long)n, in, out);
+    };
+    auto narrow = [&](const double* in, float* out, size_t n) {
+        if (out && n) hipLaunchKernelGGL(pgps::k_narrow, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
+                                         (long)n, in, out);
+    };
+    widen(a.P0, P0, dd); widen(a.H, H, d);
+    widen(a.Fs, Fs, N * dd); widen(a.Qs, Qs, N * dd); widen(a.ys, ys, N);
+    if (pks) { widen(a.fms, fms, N * d); widen(a.fPs, fPs, N * dd); }
+    ScanArgs<double> b{};
+    b.N = a.N; b.seg_first = 1; b.seg_last = 1;
+    b.P0 = a.P0 ? P0 : nullptr; b.H = a.H ? H : nullptr; b.R = (double)a.R; b.Fs = Fs; b.Qs = Qs; b.ys = a.ys ? ys : nullptr;
+    b.fms = fms; b.fPs = fPs; b.sms = smooth ? sms : nullptr; b.sPs = smooth ? sPs : nullptr; b.ll = a.ll;
+    rc_ = launch_scan_rc(ctx, b, d, mode);
+    if (rc_) return rc_;
+    if (!pks) { narrow(fms, a.fms, N * d); narrow(fPs, a.fPs, N * dd); }
+    if (smooth) { narrow(sms, a.sms, N * d); narrow(sPs, a.sPs, N * dd); }
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
 template <typename T>
 static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
+    if constexpr (sizeof(T) == 4) {
+        const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
+        if (whole && ctx->family == 0 && d > PGPS_MAX_DIM_LANE && d <= rc::kDimMax) return scan_f32_via_f64(ctx, d, a, mode);
+    }
     if constexpr (sizeof(T) == 8) {
         // row-cooperative family: fp64, d <= 16, whole-series filter / filter+smoother
         const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
@@ -402,6 +452,26 @@ static int disc_dev(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, con
         const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
         if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)))
             return launch_disc_rc(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
+    } else {
+        if (ctx->family == 0 && d > PGPS_MAX_DIM_LANE && d <= rc::kDimMax) {
+            // fp32 at 7 <= d <= 16: the arithmetic is fp64 in every discretisation kernel anyway; widen the inputs,
+            // run the row-cooperative kernel, narrow the results
+            const size_t n = (size_t)N, dd = (size_t)d * d;
+            int rc_ = ensure(ctx, ctx->lti[7], (2 * dd + n + 2 * n * dd) * sizeof(double));
+            if (rc_) return rc_;
+            double* base = (double*)ctx->lti[7].p;
+            double *F64 = base, *P64 = F64 + dd, *t64 = P64 + dd, *Fs64 = t64 + n, *Qs64 = Fs64 + n * dd;
+            auto grid = [](size_t m) { return dim3((unsigned)std::min<size_t>(4096, (m + 255) / 256)); };
+            hipLaunchKernelGGL(pgps::k_widen, grid(dd), dim3(256), 0, ctx->stream, (long)dd, (const float*)F, F64);
+            hipLaunchKernelGGL(pgps::k_widen, grid(dd), dim3(256), 0, ctx->stream, (long)dd, (const float*)Pinf, P64);
+            hipLaunchKernelGGL(pgps::k_widen, grid(n), dim3(256), 0, ctx->stream, (long)n, (const float*)ts, t64);
+            rc_ = launch_disc_rc(ctx, N, d, F64, P64, t64, (double)t0, Fs64, Qs64);
+            if (rc_) return rc_;
+            hipLaunchKernelGGL(pgps::k_narrow, grid(n * dd), dim3(256), 0, ctx->stream, (long)(n * dd), (const double*)Fs64, (float*)Fs);
+            hipLaunchKernelGGL(pgps::k_narrow, grid(n * dd), dim3(256), 0, ctx->stream, (long)(n * dd), (const double*)Qs64, (float*)Qs);
+            HIPCHK(ctx, hipGetLastError());
+            return PGPS_OK;
+        }
     }
     if (ctx->family == 3) return PGPS_E_UNSUPPORTED_DIM;
     if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_disc_wc<T>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);

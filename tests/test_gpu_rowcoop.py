@@ -185,3 +185,31 @@ def test_rowcoop_standalone_pks_forced_small_d(row_family):
     sms_o, sPs_o = O.kfs(ssm, y)
     sms, sPs = pks(ssm, fms, fPs)
     assert relerr(sms, sms_o) < TOL64 and relerr(sPs, sPs_o) < TOL64
+
+
+@pytest.mark.parametrize("name", ["rbf8", "c5_qp_m52", "rbf13"])
+def test_fp32_series_at_large_d_run_through_fp64(name):
+    """fp32 arrays at 7 <= d <= 16: widened, run on the fp64 row-cooperative kernels, narrowed (csrc/pgps_core.hip
+    scan_f32_via_f64) -- pkf, pkfs, stand-alone pks and discretise, against the fp64 oracle at fp32 tolerance."""
+    from pssgp import _backend as B
+    from pssgp.kalman.parallel import pkf, pkfs, pks
+    sde = _kernels()[name]().get_sde()
+    t = make_times(1300, seed=6)
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series(ssm, seed=6, nan_frac=0.2)
+    want = _oracle_all(ssm, y)
+    ssm32 = tuple(np.asarray(a, np.float32) for a in ssm)
+    y32 = y.astype(np.float32)
+    tol = 2e-3
+    fms, fPs, ll = pkf(ssm32, y32[:, None], return_loglikelihood=True)
+    assert fms.dtype == np.float32 and relerr(fms, want["fms"]) < tol and relerr(fPs, want["fPs"]) < tol
+    assert abs(float(ll) - want["ll"][0]) < tol * abs(want["ll"][0])
+    sms, sPs = pkfs(ssm32, y32[:, None])
+    assert sms.dtype == np.float32 and relerr(sms, want["sms"]) < tol and relerr(sPs, want["sPs"]) < tol
+    sms2, sPs2 = pks(ssm32, fms, fPs)
+    assert relerr(sms2, want["sms"]) < tol and relerr(sPs2, want["sPs"]) < tol
+    gFs, gQs = B.discretise(np.asarray(sde.F, np.float32), np.asarray(sde.P0, np.float32), t.astype(np.float32), 0.0)
+    assert gFs.dtype == np.float32
+    # time stamps rounded to fp32 (eps * t ~ 4e-6 on steps of 0.05) bound what any fp32 discretisation can reach
+    assert np.max(np.abs(gFs - ssm[1])) < 1e-3 * max(1.0, float(np.max(np.abs(ssm[1]))))
+    assert np.max(np.abs(gQs - ssm[2])) < 1e-3 * max(1.0, float(np.max(np.abs(ssm[0]))))
