@@ -972,9 +972,10 @@ static int lti_dev(pgps_ctx* ctx, long N, long K, int d, const double* F, const 
         TRY(launch_merge<double>(ctx, N, K, ts, ys, tq, tsm, ysm, qslot));
         ts_m = tsm; ys_m = ysm;
     }
-    double *Fs, *Qs, *dll;
+    double *Fs, *Qs = nullptr, *dll;
     TRY(stage_in<double>(ctx, ctx->lti[4], nullptr, m * dd, &Fs));
-    TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, m * dd, &Qs));
+    // log-likelihood only: the process noise stays implicit (Q_k = Pinf - F_k Pinf F_k^T inside the predict)
+    if (K > 0) TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, m * dd, &Qs));
     TRY(stage_in<double>(ctx, ctx->st[11], nullptr, 2, &dll));
     TRY(launch_disc_rc(ctx, (long)m, d, model, model + dd, ts_m, t0, Fs, Qs));
     ScanArgs<double> a{};
@@ -1023,12 +1024,11 @@ static int lti_ll_batch_dev(pgps_ctx* ctx, int B, long N, int d, const double* m
     if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t dd = (size_t)d * d, ms = 2 * dd + d + 1;
-    double *table, *Fs, *Qs;
+    double *table, *Fs;
     TRY(stage_in<double>(ctx, ctx->lti[0], models, (size_t)B * ms, &table));
     TRY(stage_in<double>(ctx, ctx->lti[4], nullptr, (size_t)B * (size_t)N * dd, &Fs));
-    TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, (size_t)B * (size_t)N * dd, &Qs));
-    TRY(launch_disc_rc(ctx, N, d, table, table + dd, ts, t0, Fs, Qs, B, (long)ms));
-    return launch_ll_batch_rc(ctx, N, d, B, table, (long)ms, Fs, Qs, ys, ll);
+    TRY(launch_disc_rc(ctx, N, d, table, table + dd, ts, t0, Fs, nullptr, B, (long)ms));     // implicit process noise
+    return launch_ll_batch_rc(ctx, N, d, B, table, (long)ms, Fs, nullptr, ys, ll);
 }
 
 static int lti_ll_batch_host(pgps_ctx* ctx, int B, long N, int d, const double* models, const double* ts, const double* ys,

@@ -191,6 +191,7 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);
 int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode);
 // the same with nothing written per step: MODE_PKF = log-likelihood only; MODE_PKFS = H sm, H sP H^T at the steps
 // qslot marks (a.sPs / a.sms are then scratch of N d^2 / N d doubles for the smoothing elements)
+// (MODE_PKF with a.Qs == nullptr: implicit process noise Q_k = P0 - F_k P0 F_k^T, P0 must be stationary)
 int launch_scan_rc_proj(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode, const int* qslot, double* pmean,
                         double* pvar);
 int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* ts, double t0,
@@ -225,6 +226,7 @@ struct RcArgs {
     int batch;                  // models evaluated over the same series (blockIdx.y); 0 / 1 = one
     long bs_F, bs_agg, bs_model;    // per-model strides of Fs / Qs, of agg1 / pre, of the model table
     const double* Rs;           // batch entry point: observation noise of model b at Rs[b * bs_model] (else null)
+    int implicit_q;             // Qs is not there: Q_k = P0 - F_k P0 F_k^T is folded into the predict (P0 stationary)
     int store_f;                // write fms / fPs (0: log-likelihood-only and projected-posterior calls)
     const int* qslot;           // projected-posterior mode: (N,) slot of step k in pmean / pvar, or -1
     double *pmean, *pvar;       // (K,) H sm and H sP H^T at the query steps

@@ -229,7 +229,8 @@ __device__ __forceinline__ RcArgs model_view(const RcArgs& a) {
     RcArgs b = a;
     if (a.Rs) {
         const long mb = blockIdx.y;
-        b.Fs += mb * a.bs_F; b.Qs += mb * a.bs_F;
+        b.Fs += mb * a.bs_F;
+        if (b.Qs) b.Qs += mb * a.bs_F;
         b.P0 += mb * a.bs_model; b.H += mb * a.bs_model;
         b.R = a.Rs[mb * a.bs_model];
         b.agg1 += mb * a.bs_agg;
@@ -270,20 +271,26 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
     }
     double Fc[D], Fr[D], Q[D], y;
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
+    // Implicit process noise (general-LTI log-likelihood calls): Q_k = Pinf - F_k Pinf F_k^T is never formed --
+    // F C F^T + Q = F (C - Pinf) F^T + Pinf -- so the (N, d, d) array Qs does not exist; F = I gives Q = 0 by itself.
+    const bool impq = a.implicit_q != 0;
+    double Pinf[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
     // inputs of this row's step kw + row Lw + s; steps outside the chunk and step 0 of the series run as F = I, Q = 0
     auto load = [&](int s) {
         const long ku = kw + s, k = k0 + s;
         if (FAST) {
             io.template mat_fast<false>(a.Fs + ku * dd, Fc);
             io.template mat_fast<true>(a.Fs + ku * dd, Fr);
-            io.template mat_fast<false>(a.Qs + ku * dd, Q);
+            if (!impq) io.template mat_fast<false>(a.Qs + ku * dd, Q);
             y = a.ys[k];
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
             const bool real = k < k1 && !(k == 0 && a.seg_first);
             io.template mat_slow<false>(a.Fs + kc * dd, real, 1.0, Fc);
             io.template mat_slow<true>(a.Fs + kc * dd, real, 1.0, Fr);
-            io.template mat_slow<false>(a.Qs + kc * dd, real, 0.0, Q);
+            if (!impq) io.template mat_slow<false>(a.Qs + kc * dd, real, 0.0, Q);
             y = __builtin_nan("");
             if (k < k1) y = a.ys[k];
         }
@@ -292,8 +299,17 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
     for (int s = 0; s < a.Lw; ++s) {
         double Ap[D], FC[D], Cp[D];
         zero<D>(Ap); mm<D>(Ap, Fc, A);
-        zero<D>(FC); mm<D>(FC, Fc, C);
-        copy<D>(Cp, Q); mm<D>(Cp, FC, Fr);
+        if (impq) {
+            double Cm[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) Cm[i] = C[i] - Pinf[i];
+            zero<D>(FC); mm<D>(FC, Fc, Cm);
+            copy<D>(Cp, Pinf);
+        } else {
+            zero<D>(FC); mm<D>(FC, Fc, C);
+            copy<D>(Cp, Q);
+        }
+        mm<D>(Cp, FC, Fr);
         const double bp = mvr<D>(Fr, b, 0.0);
         const double yk = y;
         if (s + 1 < a.Lw) load(s + 1);          // next step's inputs: their registers are free from here on
@@ -364,6 +380,10 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
     LogLik ll;
     double Fc[D], Fr[D], Q[D], y;
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
+    const bool impq = !SMOOTH && a.implicit_q != 0;     // see rc_reduce1; the smoothing elements need F P itself
+    double Pinf[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
     // steps at or beyond N run with F = 0, Q = I: the element built from them is (0, m, P), i.e. the last
     // element of the series (parallel.py:155-156), and a total whose E is 0 absorbs whatever follows unchanged
     auto load = [&](int s) {
@@ -371,7 +391,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
         if (FAST) {
             io.template mat_fast<false>(a.Fs + ku * dd, Fc);
             io.template mat_fast<true>(a.Fs + ku * dd, Fr);
-            io.template mat_fast<false>(a.Qs + ku * dd, Q);
+            if (!impq) io.template mat_fast<false>(a.Qs + ku * dd, Q);
             y = a.ys[k];
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
@@ -382,7 +402,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             const char* bQ = hal ? reinterpret_cast<const char*>(a.halo_Q) - io.ro8 : reinterpret_cast<const char*>(a.Qs + kc * dd);
             io.template mat_slow<false>(reinterpret_cast<const double*>(bF), real, 0.0, Fc);
             io.template mat_slow<true>(reinterpret_cast<const double*>(bF), real, 0.0, Fr);
-            io.template mat_slow<false>(reinterpret_cast<const double*>(bQ), real, 1.0, Q);
+            if (!impq) io.template mat_slow<false>(reinterpret_cast<const double*>(bQ), real, 1.0, Q);
             y = __builtin_nan("");
             if (s < a.Lw && k < k1) y = a.ys[k];
         }
@@ -393,8 +413,17 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
         const long ku = kw + s, k = k0 + s;
         // predict
         double FP[D], Pp[D];
-        zero<D>(FP); mm<D>(FP, Fc, P);
-        copy<D>(Pp, Q); mm<D>(Pp, FP, Fr);
+        if (impq) {
+            double Pm[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) Pm[i] = P[i] - Pinf[i];
+            zero<D>(FP); mm<D>(FP, Fc, Pm);
+            copy<D>(Pp, Pinf);
+        } else {
+            zero<D>(FP); mm<D>(FP, Fc, P);
+            copy<D>(Pp, Q);
+        }
+        mm<D>(Pp, FP, Fr);
         const double mp = mvr<D>(Fr, m, 0.0);
         const double yk = y;
         // Next step's inputs.  The filter-only kernel has the registers to fetch them a whole step ahead; with
@@ -945,7 +974,8 @@ __global__ __launch_bounds__(64) void rc_discretise(long N, int per, const doubl
     double* patch = patch_init(tl, row);
     constexpr int dd = D * D;
     Fg += blockIdx.y * bs_model; Pg += blockIdx.y * bs_model;         // batched: one model per blockIdx.y
-    Fs += blockIdx.y * N * dd; Qs += blockIdx.y * N * dd;
+    Fs += blockIdx.y * N * dd;
+    if (Qs) Qs += blockIdx.y * N * dd;
     const bool lv = lane < D;
     const double b[14] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
                           129060195264000., 10559470521600., 670442572800., 33522128640.,
@@ -1032,6 +1062,13 @@ __global__ __launch_bounds__(64) void rc_discretise(long N, int per, const doubl
             const bool on = t < sq;
 #pragma unroll
             for (int i = 0; i < D; ++i) R[i] = on ? R2[i] : R[i];
+        }
+        if (Qs == nullptr) {                    // implicit process noise: only F_k is wanted
+            if (lv && kv) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) Fs[k * dd + i * D + lane] = R[i];
+            }
+            continue;
         }
         // Q = Pinf - sym(R Pinf R^T)
         double T[D], Rr[D], X[D];

@@ -1455,7 +1455,7 @@ int launch_scan_rc_proj(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, co
 
 int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* table, long bs_model, const double* Fs,
                        const double* Qs, const double* ys, double* ll) {
-    if (batch < 1 || !table || !Fs || !Qs || !ys || !ll) return PGPS_E_INVALID;
+    if (batch < 1 || !table || !Fs || !ys || !ll) return PGPS_E_INVALID;      // Qs == nullptr: implicit process noise
     const long dd = (long)d * d;
     ScanArgs<double> a{};
     a.N = N; a.seg_first = 1; a.seg_last = 1;
@@ -1493,6 +1493,8 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs;
     a.store_f = store_f; a.qslot = qslot; a.pmean = pmean; a.pvar = pvar;
     a.seg_first = 1; a.seg_last = 1;
+    a.implicit_q = (sa.Qs == nullptr);
+    if (a.implicit_q && (mode != MODE_PKF || store_f)) return PGPS_E_INVALID;
     const size_t dd = (size_t)d * d, nf = wc::nfilt(d), ns = wc::nsmth(d), nc = (size_t)a.nchunk;
     const size_t nbm = batch > 1 ? (size_t)batch : 1;
     if (bs_model > 0) {                                             // the batch entry point, B >= 1
