@@ -84,9 +84,11 @@ class StateSpaceGP:
         return sde, form
 
     def _lti_form(self):
-        """The kernel's SDE when the general-LTI device path applies (parallel=True, fp64, state dimension
-        2..16, P0 stationary -- the GPU discretisation forms Q = P0 - F_k P0 F_k^T), else None."""
-        if not self.parallel or np.dtype(config.default_float()) != np.float64:
+        """The kernel's SDE when the general-LTI device path applies (parallel=True, state dimension 2..16, P0
+        stationary -- the GPU discretisation forms Q = P0 - F_k P0 F_k^T), else None.  The path computes in fp64;
+        a float32 model hands over its times and observations widened (N scalars each) and gets results rounded
+        to float32 -- less traffic and better arithmetic than fp32 (N, d, d) arrays."""
+        if not self.parallel:
             return None
         from . import _backend
         sde = self.kernel.get_sde()
@@ -162,7 +164,8 @@ class StateSpaceGP:
         lti = self._lti_form()
         if lti is not None:
             from . import _backend
-            return _backend.lti_ll(lti.F, lti.P0, lti.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))
+            ll = _backend.lti_ll(lti.F, lti.P0, lti.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))
+            return config.default_float()(ll)
         ssm = self._make_model(ts)
         _, _, ll = self._kf(ssm, Y)
         return ll

@@ -185,3 +185,27 @@ def test_gradients_of_general_kernels_vs_dense_gp():
     want = np.array([fd(f, x0, i, 1e-3 * x0[i]) for i in range(3)])
     assert abs(ll - f(x0)) < 1e-2 * abs(f(x0))
     assert np.max(np.abs(g - want)) < 1e-2 * np.max(np.abs(want))
+
+
+def test_float32_model_uses_the_lti_path_in_fp64():
+    from pssgp import config
+    from pssgp.kernels import RBF
+    from pssgp.model import StateSpaceGP
+    t, y = _series(900, 31)
+    tq = np.sort(np.random.default_rng(1).uniform(t[0], t[-1], 120))
+    sde = RBF(1., 0.5, order=8, balancing_iter=10).get_sde()
+    ll_o = O.ssgp_log_likelihood(sde, t, y, 0.1, parallel=False)
+    mean_o, var_o = O.ssgp_predict_f(sde, t, y, 0.1, tq, parallel=False)
+    old = config.default_float()
+    config.set_default_float(np.float32)
+    try:
+        m = StateSpaceGP((t[:, None].astype(np.float32), y[:, None].astype(np.float32)),
+                         RBF(1., 0.5, order=8, balancing_iter=10), noise_variance=0.1, parallel=True)
+        ll = m.maximum_log_likelihood_objective()
+        mean, var = m.predict_f(tq[:, None].astype(np.float32))
+    finally:
+        config.set_default_float(old)
+    assert mean.dtype == np.float32 and var.dtype == np.float32
+    assert abs(float(ll) - ll_o) < 1e-3 * abs(ll_o)
+    assert np.max(np.abs(mean[:, 0] - mean_o)) < 1e-3 * max(1.0, float(np.max(np.abs(mean_o))))
+    assert np.max(np.abs(var[:, 0] - var_o)) < 1e-3 * max(1.0, float(np.max(var_o)))
