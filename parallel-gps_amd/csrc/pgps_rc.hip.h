@@ -1,5 +1,6 @@
 // pgps_rc.hip.h -- the "row-cooperative" scan family: fp64, state dimensions 2..16, one instantiation per d.
-// Compiled by pgps_rc_inst.hip (-DPGPS_RC_D=d); the upper scan levels and the host driver are in pgps_wc.hip.
+// Compiled by pgps_rc_inst.hip (-DPGPS_RC_D=d); the host driver that strings the launches together is in pgps_wc.hip
+// (scan_rc / scan_rc_seg / launch_disc_rc).
 //
 // Between the lane-chunk family (one lane owns whole d x d operands, d <= 6) and the wave-cooperative one
 // (64 lanes share LDS-resident operands, d <= 32) sits the case the c5 config (d = 11) and RBF order 15 live in:
@@ -11,19 +12,23 @@
 //     Z_i(lane j) += bcast_k(X_i) * Y_k(lane j)          (pgps_rc_asm.h, generated)
 // Products with a transposed right operand take that operand in row layout (lane j holds row j), which for the
 // per-step inputs is simply a second load of the same 8 d^2 bytes; only three or four operands per step go
-// through a 2 KB LDS patch to be transposed.  Rank-one updates, matrix-vector products and the Gauss-Jordan
-// elimination of the smoother gain are the same broadcast-fmac pattern.  Lanes >= D of a row hold zeros (their
-// loads are masked off by EXEC and nothing else ever writes them).  MFMA is not used.
+// through a 2 KB LDS patch to be transposed.  Rank-one updates, matrix-vector products, row sums and the
+// Gauss-Jordan eliminations are the same broadcast-fmac pattern.  Lanes >= D of a row hold zeros (their loads are
+// masked off by EXEC and nothing else ever writes them).  MFMA is not used.
 //
-// Scan structure (same algebra as pgps_math.h, reference pssgp/kalman/parallel.py:13-196):
-//   rc_reduce1   chain = chunk of Lw steps: filt_extend per step           -> chunk totals (A, b, C, J, eta)
-//   ks_filter    Kogge-Stone inclusive scan of the totals (wc::combine in LDS, ceil(log2 nchunk) launches)
-//   rc_apply1    Kalman pass from the prefix's (b, C) [every prefix has A = 0]: fms, fPs, log-lik partials;
-//                per step the smoothing element (E, g, L) is built ONCE, stored (E -> sPs, g -> sms, L ->
-//                workspace) and folded into the chunk's smoothing total
-//   ks_smoother  Kogge-Stone inclusive suffix scan of the smoothing totals (wc::scombine)
-//   rc_smooth1   backward pass  sm = E sm' + g,  sP = E sP' E^T + L  from the stored elements (two products
-//                per step instead of predict + gain solve + two products), overwriting sms / sPs in place
+// Kernels (same algebra as pgps_math.h, reference pssgp/kalman/parallel.py:13-196):
+//   rc_discretise   Fs, Qs from the time stamps (Pade scaling and squaring, one row per step)
+//   rc_reduce1      chain of Lw steps: filt_extend per step                    -> chain totals (A, b, C, J, eta)
+//   rc_ks_filter    one Kogge-Stone step over the totals, one row per record (general operator, pivoted elimination);
+//                   with a fixed left operand: a segment's carry-in combined into every prefix
+//   rc_apply1       Kalman pass from the prefix's (b, C) [every prefix has A = 0]: fms, fPs, log-lik partials;
+//                   per step the smoothing element (E, g, L) is built ONCE, stored and folded into the chain's
+//                   smoothing total
+//   rc_selem1       the element part of rc_apply1 from GIVEN filtered moments (stand-alone pks)
+//   rc_ks_smoother  one Kogge-Stone step over the smoothing totals (suffix direction)
+//   rc_smooth1      backward pass  sm = E sm' + g,  sP = E sP' E^T + L  from the stored elements (two products
+//                   per step instead of predict + gain solve + two products); PROJ: only H sm, H sP H^T at marked steps
+//   rc_seg_carry_f / _s   carry records of a segment from the gathered totals of the other ranks (multi-GPU)
 #pragma once
 
 #include <hip/hip_runtime.h>
