@@ -223,21 +223,25 @@ class StateSpaceGP:
                 setattr(owner, name, x0)
         return blocks
 
-    def log_likelihood_and_grad(self):
+    def log_likelihood_and_grad(self, wrt=None):
         """(ll, grad): the marginal log-likelihood and its gradient with respect to
-        `trainable_parameters()`, in ONE pass of the parallel filter on dual numbers -- what the
-        reference obtains from tf.GradientTape over maximum_log_likelihood_objective
-        (tests/test_gp_vs_kfs.py:53-78).  parallel=True, the Matern family (d <= 3), fp64."""
+        `trainable_parameters()` -- what the reference obtains from tf.GradientTape over
+        maximum_log_likelihood_objective (tests/test_gp_vs_kfs.py:53-78).  parallel=True.  Matern family (d <= 3):
+        ONE pass of the parallel filter on dual numbers, exact.  Every other kernel: Richardson central differences,
+        batched into one device call up to d = 16 (`wrt`: differentiate only these parameter indices, the others
+        get 0 -- each one costs four likelihood evaluations)."""
         if not self.parallel:
             raise NotImplementedError("gradients run on the parallel (HIP) path: construct with parallel=True")
         from . import _backend
         ts, Y = self.data
-        if self._fused_form() is None and self._lti_form() is not None:
-            return self._lti_ll_and_grad()
+        if self._fused_form() is None:
+            # no dual-number path: batched differences on the general-LTI kernels (d <= 16), one evaluation at a
+            # time above that (e.g. the CO2 kernel at its reference order, d = 18)
+            return self._lti_ll_and_grad(batched=self._lti_form() is not None, wrt=wrt)
         ll, g = _backend.gp_ll_grad(self._grad_blocks(), ts.reshape(-1), Y.reshape(-1))
         return ll, g
 
-    def _lti_ll_and_grad(self, rel_step=1e-3):
+    def _lti_ll_and_grad(self, rel_step=1e-3, batched=True, wrt=None):
         """Kernels without the closed-form discretisation (RBF, Periodic, sums, products; d <= 16): the gradient by
         Richardson-extrapolated central differences -- 4 P + 1 likelihood evaluations, ALL IN ONE batched device call
         (pgps_lti_ll_batch_*), so its cost is that of one launch set, not of 4 P + 1.  Truncation error O(h^4):
@@ -247,15 +251,28 @@ class StateSpaceGP:
         x0 = np.array([getattr(o, n) for o, n in params], np.float64)
         rows = [x0]
         hs = rel_step * np.maximum(np.abs(x0), 1e-3)
-        for i in range(len(params)):
+        idx = list(range(len(params))) if wrt is None else [int(i) for i in wrt]   # `wrt`: only these parameters
+        for i in idx:
             for mult in (1.0, -1.0, 0.5, -0.5):
                 x = x0.copy()
                 x[i] += mult * hs[i]
                 rows.append(x)
-        lls = self.log_likelihood_batch(np.stack(rows))
-        grad = np.empty(len(params))
-        for i in range(len(params)):
-            up, dn, up2, dn2 = lls[1 + 4 * i:5 + 4 * i]
+        if batched:
+            lls = self.log_likelihood_batch(np.stack(rows))
+        else:
+            lls = []
+            try:
+                for row in rows:
+                    for (o, n), v in zip(params, row):
+                        setattr(o, n, float(v))
+                    lls.append(float(self.maximum_log_likelihood_objective()))
+            finally:
+                for (o, n), v in zip(params, x0):
+                    setattr(o, n, float(v))
+            lls = np.array(lls)
+        grad = np.zeros(len(params))
+        for j, i in enumerate(idx):
+            up, dn, up2, dn2 = lls[1 + 4 * j:5 + 4 * j]
             d1 = (up - dn) / (2.0 * hs[i])
             d2 = (up2 - dn2) / hs[i]
             grad[i] = (4.0 * d2 - d1) / 3.0

@@ -80,3 +80,92 @@ def test_hmc_samples_the_posterior():
     assert np.all(samples > 0) and samples.std(axis=0).min() > 0
     lls = gp.log_likelihood_batch(np.vstack([samples.mean(axis=0), [1.0, 1.0, 0.5], [5.0, 0.05, 2.0]]))
     assert lls[0] > lls[1] - 5.0 and lls[0] > lls[2]
+
+
+# ---- real-data drivers (pssgp/experiments/real_data.py) on synthetic files in the reference's formats -------------
+def _write_sunspots(path, n=420, seed=0):
+    rng = np.random.default_rng(seed)
+    months = np.arange(np.datetime64("1749-01"), np.datetime64("1749-01") + np.timedelta64(n, "M"), np.timedelta64(1, "M"))
+    days = (months + np.timedelta64(1, "M")).astype("datetime64[D]") - np.timedelta64(1, "D")     # month ends
+    t = (days - days[0]).astype(float) / 365.2425
+    vals = np.maximum(0.0, 80.0 + 70.0 * np.sin(2 * np.pi * t / 11.0) + 25.0 * rng.standard_normal(n))
+    with open(path / "sunspots.csv", "w") as f:
+        f.write("id,date,sunspots\n")
+        for i, (d, v) in enumerate(zip(days, vals)):
+            f.write(f"{i},{d},{v:.1f}\n")
+    return t, vals
+
+
+def _write_co2(path, seed=1):
+    rng = np.random.default_rng(seed)
+    tw = 1990.0 + np.arange(300) / 52.0
+    tm = 1975.0 + np.arange(200) / 12.0
+    co2 = lambda t: 330.0 + 1.6 * (t - 1975.0) + 3.0 * np.sin(2 * np.pi * t) + 0.3 * rng.standard_normal(t.shape)
+    yw, ym = co2(tw), co2(tm)
+    yw[[7, 90]] = -999.99                                     # NOAA's missing-value marker
+    with open(path / "co2_weekly_mlo.txt", "w") as f:
+        f.write("# synthetic file in the column layout of NOAA's weekly record: yr mon day decimal ppm ...\n")
+        for t, v in zip(tw, yw):
+            f.write(f"{int(t)} 1 1 {t:.4f} {v:.2f} 7 0.0 0.0 0.0\n")
+    with open(path / "co2_mm_mlo.txt", "w") as f:
+        f.write("# synthetic file in the column layout of NOAA's monthly record: yr mon decimal average ...\n")
+        for t, v in zip(tm, ym):
+            f.write(f"{int(t)} 1 {t:.4f} {v:.2f} {v:.2f} 30 0.1 0.1\n")
+    return tw, yw, tm, ym
+
+
+def test_real_data_loaders(tmp_path):
+    from pssgp.experiments import real_data as RD
+    t_all, vals = _write_sunspots(tmp_path)
+    t, y = RD.load_sunspots(str(tmp_path), 100)
+    assert t.shape == (100, 1) and y.shape == (100, 1)
+    assert np.allclose(t[:, 0], t_all[-100:], atol=1e-9) and np.allclose(y[:, 0], np.round(vals[-100:], 1))
+    tw, yw, tm, ym = _write_co2(tmp_path)
+    t, y = RD.load_co2(str(tmp_path), 10000)
+    assert t.shape[0] == 300 + 200 - 2 and np.all(np.diff(t[:, 0]) >= 0) and np.all(y > 0)
+    t2, y2 = RD.load_co2(str(tmp_path), 50)
+    assert np.array_equal(t2, t[-50:]) and np.array_equal(y2, y[-50:])
+
+
+def test_co2_model_setup():
+    """Kernel structure, state dimension and the trained / fixed split of co2/mcmc.py:35-65."""
+    from pssgp.experiments import real_data as RD
+    from pssgp.model import StateSpaceGP
+    t = np.linspace(2000.0, 2001.0, 20)[:, None]
+    gp = StateSpaceGP((t, np.zeros_like(t)), RD.co2_covariance(3), 0.05, parallel=False)
+    assert gp.kernel.get_sde().F.shape[0] == 18
+    names = [(type(o).__name__, n) for o, n in gp.trainable_parameters()]
+    assert names == [("Periodic", "period"), ("SquaredExponential", "variance"), ("SquaredExponential", "lengthscales"),
+                     ("Matern32", "variance"), ("Matern32", "lengthscales"), ("Matern32", "variance"),
+                     ("Matern32", "lengthscales"), ("StateSpaceGP", "noise_variance")]
+    priors, fixed = RD.co2_setup(gp)
+    assert fixed == {0, 1, 7}
+    assert priors == {2: (5., 1.), 3: (1e-1, 1e-3), 4: (50., 10.), 5: (1., 0.1), 6: (100., 50.)}
+    assert RD.co2_covariance(2).get_sde().F.shape[0] == 14
+
+
+@pytest.mark.gpu
+def test_sunspot_map_and_co2_hmc_on_synthetic_files(tmp_path):
+    from pssgp.experiments import real_data as RD
+    from pssgp.model import StateSpaceGP
+    _write_sunspots(tmp_path, n=600, seed=3)
+    _write_co2(tmp_path)
+    # MAP: the posterior density rises, the optimiser ends at a stationary point, predict_f runs on 30 x N points
+    t, y = RD.load_sunspots(str(tmp_path), 500)
+    gp = StateSpaceGP((t, y), RD.sunspot_covariance(), 10.0, parallel=True)
+    post = RD.Posterior(gp, RD.sunspot_priors(10.0))
+    lp0, g0 = post(post.u0())
+    # the objective's own gradient against central differences of its value
+    u = post.u0()
+    for i in range(3):
+        e = np.zeros(3); e[i] = 1e-4
+        fd = (post(u + e)[0] - post(u - e)[0]) / 2e-4
+        assert abs(fd - g0[i]) < 1e-4 * max(1.0, abs(g0[i]))
+    out = RD.sunspot_map(str(tmp_path), n_training=500, maxiter=60)
+    assert -out["neg_log_posterior"] > lp0 and out["predict_points"] == 500 * 30
+    assert 0.0 < out["lengthscales"] < 100.0 and out["noise_variance"] > 0.0 and np.isfinite(out["max_std"])
+    # CO2 kernel at order 1 (d = 10) on the general-LTI path: a few HMC iterations move, fixed parameters stay
+    res = RD.co2_hmc(str(tmp_path), n_training=300, qp_order=1, n_samples=6, n_burnin=4, step_size=0.002)
+    assert res["state_dim"] == 10 and len(res["posterior_mean"]) == 8
+    assert res["posterior_mean"][0] == 1.0 and res["posterior_std"][0] == 0.0        # the period is not trained
+    assert abs(res["posterior_mean"][7] - 0.05) < 1e-12 and all(np.isfinite(res["posterior_mean"]))

@@ -81,15 +81,12 @@ def test_gradient_descends():
 
 
 def test_gradient_rejects_unsupported():
-    """Outside the dual-number (Matern) path and the batched-difference path (fp64, d <= 16) there is no gradient:
-    loud error, e.g. Periodic order 10 (d = 22) or the sequential model."""
-    from pssgp.kernels import Periodic, RBF, SquaredExponential
+    """Gradients run on the parallel (HIP) path only: the sequential model says so loudly.  (Every kernel has a
+    gradient there: dual numbers for the Matern family, batched differences up to d = 16, one evaluation at a time
+    above -- tests/test_gpu_lti.py.)"""
+    from pssgp.kernels import RBF
     from pssgp.model import StateSpaceGP
     t = np.linspace(0.0, 1.0, 50)
-    m = StateSpaceGP((t[:, None], np.sin(t)[:, None]), Periodic(SquaredExponential(1., 0.5), period=0.5, order=10), 0.1,
-                     parallel=True)
-    with pytest.raises(NotImplementedError):
-        m.log_likelihood_and_grad()
     m = StateSpaceGP((t[:, None], np.sin(t)[:, None]), RBF(1.0, 1.0, order=6, balancing_iter=5), 0.1, parallel=False)
     with pytest.raises(NotImplementedError):
         m.log_likelihood_and_grad()
