@@ -1,0 +1,75 @@
+"""Randomised parity of the row-cooperative family and the general-LTI entry points: random stable SDEs of random state
+dimension (2..16), random series lengths (1..2600, ragged against the chain length), random chain lengths, random
+fractions of missing observations -- filter, smoother, log-likelihood, stand-alone smoother, device predict and the
+batched log-likelihood against the numpy oracle."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests.conftest import make_times, relerr, sample_series
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_model(rng, d):
+    from scipy.linalg import solve_continuous_lyapunov
+    M = rng.standard_normal((d, d)) * 0.6
+    F = -(1.0 + rng.uniform(0, 1)) * np.eye(d) + 0.5 * (M - M.T) + np.tril(rng.standard_normal((d, d)) * 0.2, -1)
+    Lq = rng.standard_normal((d, max(1, d // 2)))
+    P = solve_continuous_lyapunov(F, -(Lq @ Lq.T + 0.05 * np.eye(d)))
+    return F, 0.5 * (P + P.T), rng.standard_normal((1, d))
+
+
+def _ssm(F, P, H, t, R):
+    from scipy.linalg import expm
+    dts = np.diff(np.concatenate([[0.0], t]))
+    Fs = np.stack([expm(dt * F) for dt in dts])
+    Qs = P[None] - np.einsum("kij,jl,kml->kim", Fs, P, Fs)
+    return (P, Fs, 0.5 * (Qs + np.transpose(Qs, (0, 2, 1))), H, np.array([[R]]))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_models_sizes_and_chains(seed):
+    from pssgp import _backend as B
+    rng = np.random.default_rng(1000 + seed)
+    ctx = B.get_context()
+    try:
+        for case in range(6):
+            d = int(rng.integers(2, 17))
+            n = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 64, 100, 257, 700, 1500, 2600]))
+            chunk = int(rng.choice([0, 1, 2, 3, 5, 8, 13, 32, 100]))
+            F, P, H = _random_model(rng, d)
+            t = make_times(n, seed=seed * 100 + case)
+            ssm = _ssm(F, P, H, t, 0.2)
+            y = sample_series(ssm, seed=case, nan_frac=float(rng.choice([0.0, 0.2, 0.6])) if n > 3 else 0.0)
+            ctx.set_family(3)
+            ctx.set_chunk(chunk)
+            sms, sPs, fms, fPs, ll = B.pkfs(ssm, y, return_filtered=True, return_loglikelihood=True)
+            of, oP, oll = O.kf(ssm, y, True)
+            os_, osP = O.kfs(ssm, y)
+            tag = f"d={d} n={n} chunk={chunk}"
+            assert relerr(fms, of) < 1e-7 and relerr(fPs, oP) < 1e-7, tag
+            assert relerr(sms, os_) < 1e-7 and relerr(sPs, osP) < 1e-7, tag
+            assert abs(float(ll) - oll) <= 1e-8 * abs(oll) + 1e-12, tag
+            s2, sP2 = B.pks(ssm, of, oP)
+            assert relerr(s2, os_) < 1e-7 and relerr(sP2, osP) < 1e-7, tag
+            # general-LTI entry points on the same model (they discretise on the device)
+            ctx.set_chunk(0)
+            assert abs(B.lti_ll(F, P, H.reshape(-1), 0.2, t, y) - oll) <= 1e-8 * abs(oll) + 1e-12, tag
+            k = int(rng.choice([1, 7, 90]))
+            tq = np.sort(rng.uniform(-0.2, t[-1] + 0.3, k))
+            tq[tq < 0] = 0.0
+            mean, var, ll3 = B.lti_predict(F, P, H.reshape(-1), 0.2, t, y, tq)
+            all_t, all_y, flags = O.merge_sorted(t, tq, (y, np.full(tq.shape, np.nan)),
+                                                 (np.zeros(t.shape, bool), np.ones(tq.shape, bool)))
+            ms, Ps = O.kfs(_ssm(F, P, H, all_t, 0.2), all_y)
+            h = H.reshape(-1)
+            assert np.max(np.abs(mean - ms[flags] @ h)) < 1e-7 * max(1.0, float(np.max(np.abs(ms)))), tag
+            assert np.max(np.abs(var - np.einsum("i,nij,j->n", h, Ps[flags], h))) < 1e-7 * max(1.0, float(np.max(np.abs(Ps)))), tag
+            lls = B.lti_ll_batch([(F, P, h, 0.2), (0.7 * F, 1.3 * P, h, 0.4)], t, y)
+            assert abs(lls[0] - oll) <= 1e-8 * abs(oll) + 1e-12, tag
+            oll2 = O.kf(_ssm(0.7 * F, 1.3 * P, H, t, 0.4), y, True)[2]
+            assert abs(lls[1] - oll2) <= 1e-8 * abs(oll2) + 1e-12, tag
+    finally:
+        ctx.set_family(0)
+        ctx.set_chunk(0)
