@@ -72,6 +72,38 @@ def small_d():
     print("small_d done")
 
 
+def large_d():
+    """Sequential-oracle outputs (N = 1024, 20 % missing) for config c5's kernel
+    `Periodic(SE(1, 1), period 1, order 1) * Matern32 + Matern52` (d = 11) and RBF order 15 (d = 15): the state
+    dimensions of the row-cooperative kernels.  Stored as projections (H m, H P H^T) plus the filtered / smoothed
+    moments of a few steps in full."""
+    from pssgp.kernels import Matern32, Matern52, Periodic, RBF, SquaredExponential
+    rng = np.random.default_rng(2)
+    n = 1024
+    t = np.cumsum(0.05 * rng.uniform(0.5, 1.5, n))
+    y = np.sin(0.9 * t) + 0.4 * np.cos(2 * np.pi * t) + 0.3 * rng.standard_normal(n)
+    y[rng.random(n) < 0.2] = np.nan
+    out = {"t": t, "y": y, "full_steps": np.array([0, 1, 511, 1022, 1023])}
+    kernels = {"c5": Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.),
+               "rbf15": RBF(1., 0.5, order=15, balancing_iter=10)}
+    for name, k in kernels.items():
+        ssm = O.get_ssm(k.get_sde(), t, 0.1)
+        fms, fPs, ll = O.kf(ssm, y, True)
+        sms, sPs = O.kfs(ssm, y)
+        h = ssm[3].reshape(-1)
+        out[name + "/ll"] = ll
+        out[name + "/fmean"] = fms @ h
+        out[name + "/fvar"] = np.einsum("i,nij,j->n", h, fPs, h)
+        out[name + "/smean"] = sms @ h
+        out[name + "/svar"] = np.einsum("i,nij,j->n", h, sPs, h)
+        out[name + "/fPs_full"] = fPs[out["full_steps"]]
+        out[name + "/sPs_full"] = sPs[out["full_steps"]]
+        out[name + "/sms_full"] = sms[out["full_steps"]]
+    np.savez_compressed(os.path.join(HERE, "large_d_n1024.npz"), **out)
+    print("large_d done")
+
+
 if __name__ == "__main__":
     c1()
     small_d()
+    large_d()

@@ -213,3 +213,36 @@ def test_fp32_series_at_large_d_run_through_fp64(name):
     # time stamps rounded to fp32 (eps * t ~ 4e-6 on steps of 0.05) bound what any fp32 discretisation can reach
     assert np.max(np.abs(gFs - ssm[1])) < 1e-3 * max(1.0, float(np.max(np.abs(ssm[1]))))
     assert np.max(np.abs(gQs - ssm[2])) < 1e-3 * max(1.0, float(np.max(np.abs(ssm[0]))))
+
+
+@pytest.mark.parametrize("name", ["c5", "rbf15"])
+def test_golden_large_d(name):
+    """The committed sequential-oracle vectors for d = 11 (config c5's kernel) and d = 15 (tests/golden/
+    large_d_n1024.npz, written by tests/golden/make_golden.py): through pkf / pkfs on the arrays and through the
+    general-LTI device path."""
+    import os
+    from pssgp import _backend as B
+    from pssgp.kalman.parallel import pkf, pkfs
+    from pssgp.kernels import Matern32, Matern52, Periodic, RBF, SquaredExponential
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "large_d_n1024.npz"))
+    k = {"c5": Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.),
+         "rbf15": RBF(1., 0.5, order=15, balancing_iter=10)}[name]
+    ssm = k.get_ssm(g["t"][:, None], 0.1)
+    fms, fPs, ll = pkf(ssm, g["y"][:, None], return_loglikelihood=True)
+    sms, sPs = pkfs(ssm, g["y"][:, None])
+    h = np.asarray(ssm.H).reshape(-1)
+    steps = g["full_steps"]
+    tol = 1e-7
+    assert abs(float(ll) - float(g[name + "/ll"])) < tol * abs(float(g[name + "/ll"]))
+    assert relerr(fms @ h, g[name + "/fmean"]) < tol and relerr(np.einsum("i,nij,j->n", h, fPs, h), g[name + "/fvar"]) < tol
+    assert relerr(sms @ h, g[name + "/smean"]) < tol and relerr(np.einsum("i,nij,j->n", h, sPs, h), g[name + "/svar"]) < tol
+    assert relerr(fPs[steps], g[name + "/fPs_full"]) < tol and relerr(sPs[steps], g[name + "/sPs_full"]) < tol
+    assert relerr(sms[steps], g[name + "/sms_full"]) < tol
+    sde = k.get_sde()
+    assert abs(B.lti_ll(sde.F, sde.P0, sde.H, 0.1, g["t"], g["y"]) - float(g[name + "/ll"])) < tol * abs(float(g[name + "/ll"]))
+    mean, var, _ = B.lti_predict(sde.F, sde.P0, sde.H, 0.1, g["t"], g["y"], g["t"][100:900:7])
+    # a query AT a training time comes before it on ties, so it is smoothed with that observation still to come:
+    # its posterior equals the smoothed moments of the training row only where that row is missing
+    miss = np.isnan(g["y"][100:900:7])
+    assert np.max(np.abs(mean[miss] - g[name + "/smean"][100:900:7][miss])) < 1e-6 * max(1.0, float(np.max(np.abs(g[name + "/smean"]))))
+    assert np.max(np.abs(var[miss] - g[name + "/svar"][100:900:7][miss])) < 1e-6 * max(1.0, float(np.max(g[name + "/svar"])))

@@ -150,3 +150,15 @@ def test_golden_fixtures_reproduce():
     mean, var = O.ssgp_predict_f(sde, g["t"], g["y"], float(g["noise"]), g["tq"], parallel=False)
     assert np.max(np.abs(mean - g["mean_dense"])) < 1e-8
     assert np.max(np.abs(var - g["var_dense"])) < 1e-8
+    # large_d: the sequential oracle reproduces its own stored vectors (drift guard), and its parallel-scan
+    # restatement agrees with them
+    g = np.load(os.path.join(GOLD, "large_d_n1024.npz"))
+    from pssgp.kernels import Matern52, Periodic, SquaredExponential
+    k = Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.)
+    ssm = O.get_ssm(k.get_sde(), g["t"], 0.1)
+    fms, fPs, ll = O.kf(ssm, g["y"], True)
+    assert abs(ll - float(g["c5/ll"])) < 1e-10 * abs(float(g["c5/ll"]))
+    pf, pP, pll = O.pkf(ssm, g["y"], True)
+    assert abs(pll - float(g["c5/ll"])) < 1e-9 * abs(float(g["c5/ll"]))
+    h = ssm[3].reshape(-1)
+    assert np.max(np.abs(pf @ h - g["c5/fmean"])) < 1e-9
