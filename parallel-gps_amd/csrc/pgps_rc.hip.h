@@ -278,7 +278,7 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
     // Implicit process noise (general-LTI log-likelihood calls): Q_k = Pinf - F_k Pinf F_k^T is never formed --
     // F C F^T + Q = F (C - Pinf) F^T + Pinf -- so the (N, d, d) array Qs does not exist; F = I gives Q = 0 by itself.
-    const bool impq = a.implicit_q != 0;
+    const bool impq = a.implicit_q != 0;         // bit 0: Qs absent; bit 1: Qs there, but P0 known stationary -- skip reading it
     double Pinf[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
@@ -385,7 +385,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
     LogLik ll;
     double Fc[D], Fr[D], Q[D], y;
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
-    const bool impq = !SMOOTH && a.implicit_q != 0;     // see rc_reduce1; the smoothing elements need F P itself
+    const bool impq = !SMOOTH && (a.implicit_q & 1);    // see rc_reduce1; the smoothing elements need F P itself
     double Pinf[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;

@@ -1493,8 +1493,11 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs;
     a.store_f = store_f; a.qslot = qslot; a.pmean = pmean; a.pvar = pvar;
     a.seg_first = 1; a.seg_last = 1;
-    a.implicit_q = (sa.Qs == nullptr);
+    a.implicit_q = (sa.Qs == nullptr) ? 1 : 0;
     if (a.implicit_q && (mode != MODE_PKF || store_f)) return PGPS_E_INVALID;
+    // projected-posterior calls come from the general-LTI entry points, whose Qs is Pinf - F Pinf F^T by
+    // construction: the reduce pass need not read it
+    if (qslot && !a.implicit_q) a.implicit_q = 2;
     const size_t dd = (size_t)d * d, nf = wc::nfilt(d), ns = wc::nsmth(d), nc = (size_t)a.nchunk;
     const size_t nbm = batch > 1 ? (size_t)batch : 1;
     if (bs_model > 0) {                                             // the batch entry point, B >= 1
