@@ -180,7 +180,9 @@ int pgps_gp_f32(pgps_ctx*, long N, int d, double lam, const double* N1, const do
                 const double* H, double R, const float* ts, double t0, const float* ys, float* fms, float* fPs,
                 float* sms, float* sPs, double* ll);
 
-/* ---- general LTI models on the device: any kernel, fp64, 2 <= d <= 16 ------------------------------
+/* ---- general LTI models on the device: any kernel, fp64, 2 <= d <= 32 ------------------------------
+ * (row-cooperative kernels up to d = 16; 17..32 on the wave-cooperative kernels, with whole moments in device scratch
+ * and the projection at the query rows by a separate kernel; the batch entry points cover d <= 16)
  * The chain  _get_ssm (pssgp/kernels/base.py:29-47) -> pkf / pkfs (parallel.py:121-201) that StateSpaceGP runs
  * (pssgp/model.py:92-117) for kernels without the closed-form discretisation (RBF, Periodic, sums, products),
  * with only the results leaving the GPU.  The model F (d,d), Pinf (d,d) (= P0, the stationary covariance: Qs =

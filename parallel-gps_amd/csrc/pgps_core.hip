@@ -943,13 +943,65 @@ PGPS_DEFINE_PREDICT(f32, float)
 // general LTI models on the device (fp64, 2 <= d <= 16): _get_ssm -> pkf / pkfs for any kernel, with
 // nothing but the results leaving the GPU (row-cooperative kernels, pgps_rc.hip.h)
 // ---------------------------------------------------------------------------------------------
+// H sm and H sP H^T at the query rows of a merged series (the general-LTI predict path above d = 16, where the smoother
+// writes whole moments): one thread per merged step
+__global__ void k_project_rows(long m, int d, const int* __restrict__ qslot, const double* __restrict__ H,
+                               const double* __restrict__ sms, const double* __restrict__ sPs, double* __restrict__ mean,
+                               double* __restrict__ var) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int q = qslot[k];
+    if (q < 0) return;
+    const double* sm = sms + k * d;
+    const double* sP = sPs + k * (long)d * d;
+    double mu = 0.0, v = 0.0;
+    for (int i = 0; i < d; ++i) {
+        mu += H[i] * sm[i];
+        double r = 0.0;
+        for (int j = 0; j < d; ++j) r += sP[(long)i * d + j] * H[j];
+        v += H[i] * r;
+    }
+    mean[q] = mu;
+    var[q] = v;
+}
+
+// 16 < d <= 32: the same chain on the wave-cooperative kernels -- discretisation with Qs written out, whole filtered (and
+// smoothed) moments into scratch, projection at the query rows by k_project_rows.  Everything stays on the device.
+static int lti_dev_wc(pgps_ctx* ctx, size_t m, int d, const double* model, double R, const double* ts_m, const double* ys_m,
+                      double t0, const int* qslot, double* mean, double* var, double* ll) {
+    const size_t dd = (size_t)d * d;
+    double *Fs, *Qs, *fms, *fPs;
+    TRY(stage_in<double>(ctx, ctx->lti[4], nullptr, m * dd, &Fs));
+    TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, m * dd, &Qs));
+    TRY(launch_disc_wc<double>(ctx, (long)m, d, model, model + dd, ts_m, t0, Fs, Qs));
+    ScanArgs<double> a{};
+    a.N = (long)m; a.seg_first = 1; a.seg_last = 1;
+    a.P0 = model + dd; a.H = model + 2 * dd; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys_m;
+    a.ll = ll;
+    TRY(stage_in<double>(ctx, ctx->lti[6], nullptr, m * dd, &fPs));
+    TRY(stage_in<double>(ctx, ctx->lti[7], nullptr, m * d, &fms));
+    a.fms = fms; a.fPs = fPs;
+    if (!qslot) return launch_scan_wc<double>(ctx, a, d, MODE_PKF);
+    // smoothed moments in place of the filtered ones is not possible (the smoother reads both): two more buffers
+    double *sms, *sPs;
+    TRY(stage_in<double>(ctx, ctx->lti[8], nullptr, m * dd, &sPs));
+    TRY(stage_in<double>(ctx, ctx->lti[9], nullptr, m * d, &sms));
+    a.sms = sms; a.sPs = sPs;
+    TRY(launch_scan_wc<double>(ctx, a, d, MODE_PKFS));
+    const int block = 256;
+    hipLaunchKernelGGL(k_project_rows, dim3((unsigned)((m + block - 1) / block)), dim3(block), 0, ctx->stream, (long)m, d,
+                       qslot, a.H, (const double*)sms, (const double*)sPs, mean, var);
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
 static int lti_dev(pgps_ctx* ctx, long N, long K, int d, const double* F, const double* Pinf, const double* H, double R,
                    const double* ts, const double* ys, double t0, const double* tq, double* mean, double* var,
                    double* ll) {
     if (!ctx || N < 1 || K < 0 || !F || !Pinf || !H || !ts || !ys) return PGPS_E_INVALID;
     if (K > 0 && (!tq || !mean || !var)) return PGPS_E_INVALID;
     if (K == 0 && !ll) return PGPS_E_INVALID;
-    if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
+    if (d < rc::kDimMin || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     if (N + K > 0x7fffffffL) return PGPS_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t m = (size_t)(N + K), dd = (size_t)d * d;
@@ -973,10 +1025,11 @@ static int lti_dev(pgps_ctx* ctx, long N, long K, int d, const double* F, const 
         ts_m = tsm; ys_m = ysm;
     }
     double *Fs, *Qs = nullptr, *dll;
+    TRY(stage_in<double>(ctx, ctx->st[11], nullptr, 2, &dll));
+    if (d > rc::kDimMax) return lti_dev_wc(ctx, m, d, model, R, ts_m, ys_m, t0, qslot, mean, var, ll ? ll : dll);
     TRY(stage_in<double>(ctx, ctx->lti[4], nullptr, m * dd, &Fs));
     // log-likelihood only: the process noise stays implicit (Q_k = Pinf - F_k Pinf F_k^T inside the predict)
     if (K > 0) TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, m * dd, &Qs));
-    TRY(stage_in<double>(ctx, ctx->st[11], nullptr, 2, &dll));
     TRY(launch_disc_rc(ctx, (long)m, d, model, model + dd, ts_m, t0, Fs, Qs));
     ScanArgs<double> a{};
     a.N = (long)m; a.seg_first = 1; a.seg_last = 1;

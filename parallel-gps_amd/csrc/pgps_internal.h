@@ -27,7 +27,7 @@ struct pgps_ctx {
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
-    DevBuf lti[8];                      // general-LTI entry points: model, merged series, Fs, Qs, E, g
+    DevBuf lti[10];                     // general-LTI entry points: model, merged series, Fs, Qs, E, g (d > 16: moments)
     DevBuf stamps;                      // diagnostic build only
     int* status_word = nullptr;         // device word kernels raise flags in (pgps_status)
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i

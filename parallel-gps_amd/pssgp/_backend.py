@@ -401,7 +401,9 @@ def gp_predict(form, Pinf, H, R, ts, ys, tq, t0=0.0, device=0):
     return mean, var, ll.value
 
 
-LTI_DIM_MIN, LTI_DIM_MAX = 2, 16          # state dimensions of the general-LTI device path (row-cooperative kernels)
+# state dimensions of the general-LTI device path: row-cooperative kernels up to 16 (batched evaluation only there),
+# wave-cooperative kernels from 17 to 32
+LTI_DIM_MIN, LTI_DIM_MAX, LTI_BATCH_DIM_MAX = 2, 32, 16
 
 
 def _lti_model(F, Pinf, H):
@@ -454,6 +456,8 @@ def lti_ll_batch(models, ts, ys, t0=0.0, device=0):
     rows, d = [], None
     for F, Pinf, H, R in models:
         F, Pinf, H, dm = _lti_model(F, Pinf, H)
+        if dm > LTI_BATCH_DIM_MAX:
+            raise ValueError(f"batched general-LTI evaluation covers state dimensions up to {LTI_BATCH_DIM_MAX}, got {dm}")
         if d is None:
             d = dm
         if dm != d:

@@ -84,7 +84,7 @@ class StateSpaceGP:
         return sde, form
 
     def _lti_form(self):
-        """The kernel's SDE when the general-LTI device path applies (parallel=True, state dimension 2..16, P0
+        """The kernel's SDE when the general-LTI device path applies (parallel=True, state dimension 2..32, P0
         stationary -- the GPU discretisation forms Q = P0 - F_k P0 F_k^T), else None.  The path computes in fp64;
         a float32 model hands over its times and observations widened (N scalars each) and gets results rounded
         to float32 -- less traffic and better arithmetic than fp32 (N, d, d) arrays."""
@@ -310,10 +310,13 @@ class StateSpaceGP:
         if len(models) == len(general):
             return _backend.gp_ll_batch(models, ts.reshape(-1), Y.reshape(-1))
         d = general[0][0].shape[0]
-        if not (_backend.LTI_DIM_MIN <= d <= _backend.LTI_DIM_MAX):
-            raise NotImplementedError(f"batched evaluation covers the Matern family and state dimensions "
-                                      f"{_backend.LTI_DIM_MIN}..{_backend.LTI_DIM_MAX}; this kernel has d = {d}")
-        return _backend.lti_ll_batch(general, ts.reshape(-1), Y.reshape(-1))
+        if _backend.LTI_DIM_MIN <= d <= _backend.LTI_BATCH_DIM_MAX:
+            return _backend.lti_ll_batch(general, ts.reshape(-1), Y.reshape(-1))
+        if d <= _backend.LTI_DIM_MAX:
+            # 17..32: one device evaluation per setting (wave-cooperative kernels; nothing but ts, ys and the model moves)
+            return np.array([_backend.lti_ll(F, P0, H, R, ts.reshape(-1), Y.reshape(-1)) for F, P0, H, R in general])
+        raise NotImplementedError(f"batched evaluation covers the Matern family and state dimensions "
+                                  f"{_backend.LTI_DIM_MIN}..{_backend.LTI_DIM_MAX}; this kernel has d = {d}")
 
     def log_posterior_density(self):
         return self.maximum_log_likelihood_objective()
