@@ -67,39 +67,35 @@ class StateSpaceGP:
             self._kf = lambda ssm, y: pkf(ssm, y, return_loglikelihood=True, max_parallel=ts.shape[0])
             self._kfs = lambda ssm, y: pkfs(ssm, y, max_parallel=max_parallel)
 
-    def _fused_form(self):
-        """(sde, (lam, N1, N2)) when the kernel's SDE has the closed-form discretisation the fused HIP
-        path uses (F = -lam I + N, N nilpotent, d <= 3: the Matern family), else None."""
+    def _device_forms(self):
+        """(fused, lti) from ONE get_sde() (for composite kernels that call is the host cost of an evaluation):
+        `fused` = (sde, (lam, N1, N2)) when the SDE has the closed-form discretisation of the fused HIP path
+        (F = -lam I + N, N nilpotent, d <= 3: the Matern family), `lti` = the SDE when the general-LTI device path applies
+        (state dimension 2..32); both need parallel=True and a stationary P0 -- the GPU discretisation forms
+        Q = P0 - F_k P0 F_k^T.  The general-LTI path computes in fp64; a float32 model hands over its times and
+        observations widened (N scalars each) and gets results rounded to float32 -- less traffic and better
+        arithmetic than fp32 (N, d, d) arrays."""
         if not self.parallel:
-            return None
-        from . import _backend
-        sde = self.kernel.get_sde()
-        form = _backend.nilpotent_form(sde.F)
-        if form is None:
-            return None
-        F, P0 = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64)
-        LQL = np.asarray(sde.L, np.float64) @ np.atleast_2d(np.asarray(sde.Q, np.float64)) @ np.asarray(sde.L, np.float64).T
-        if np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) > 1e-8 * max(1.0, float(np.max(np.abs(LQL)))):
-            return None
-        return sde, form
-
-    def _lti_form(self):
-        """The kernel's SDE when the general-LTI device path applies (parallel=True, state dimension 2..32, P0
-        stationary -- the GPU discretisation forms Q = P0 - F_k P0 F_k^T), else None.  The path computes in fp64;
-        a float32 model hands over its times and observations widened (N scalars each) and gets results rounded
-        to float32 -- less traffic and better arithmetic than fp32 (N, d, d) arrays."""
-        if not self.parallel:
-            return None
+            return None, None
         from . import _backend
         sde = self.kernel.get_sde()
         F, P0 = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64)
-        if not (_backend.LTI_DIM_MIN <= F.shape[0] <= _backend.LTI_DIM_MAX):
-            return None
         L = np.asarray(sde.L, np.float64)
         LQL = L @ np.atleast_2d(np.asarray(sde.Q, np.float64)) @ L.T
         if np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) > 1e-8 * max(1.0, float(np.max(np.abs(LQL)))):
-            return None
-        return sde
+            return None, None
+        form = _backend.nilpotent_form(sde.F)
+        if form is not None:
+            return (sde, form), None
+        if _backend.LTI_DIM_MIN <= F.shape[0] <= _backend.LTI_DIM_MAX:
+            return None, sde
+        return None, None
+
+    def _fused_form(self):
+        return self._device_forms()[0]
+
+    def _lti_form(self):
+        return self._device_forms()[1]
 
     def _make_model(self, ts):
         R = np.reshape(np.asarray(self.noise_variance, dtype=config.default_float()), (1, 1))
@@ -114,7 +110,7 @@ class StateSpaceGP:
         Xnew = np.asarray(Xnew, dtype=dtype)
         squeezed_ts = ts.reshape(-1)
         squeezed_Xnew = Xnew.reshape(-1)
-        fused = self._fused_form()
+        fused, lti = self._device_forms()
         if (fused is not None and squeezed_Xnew.size > 0 and np.all(np.diff(squeezed_ts) >= 0)
                 and np.all(np.diff(squeezed_Xnew) >= 0)):
             # the whole of predict_f on the device: merge, missing-marking, filter + smoother, projection
@@ -124,7 +120,6 @@ class StateSpaceGP:
             mean, var, _ = _backend.gp_predict(form, sde.P0, sde.H, self.noise_variance, squeezed_ts, ys.reshape(-1),
                                                squeezed_Xnew)
             return mean[:, None], var[:, None]
-        lti = self._lti_form() if fused is None else None
         if (lti is not None and squeezed_Xnew.size > 0 and np.all(np.diff(squeezed_ts) >= 0)
                 and np.all(np.diff(squeezed_Xnew) >= 0)):
             # kernels without the closed-form discretisation (RBF, Periodic, sums, products): merge, discretisation,
@@ -156,12 +151,11 @@ class StateSpaceGP:
 
     def maximum_log_likelihood_objective(self):
         ts, Y = self.data
-        fused = self._fused_form()
+        fused, lti = self._device_forms()
         if fused is not None:
             from . import _backend
             sde, form = fused
             return _backend.gp(form, sde.P0, sde.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))["ll"]
-        lti = self._lti_form()
         if lti is not None:
             from . import _backend
             ll = _backend.lti_ll(lti.F, lti.P0, lti.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))
@@ -234,10 +228,11 @@ class StateSpaceGP:
             raise NotImplementedError("gradients run on the parallel (HIP) path: construct with parallel=True")
         from . import _backend
         ts, Y = self.data
-        if self._fused_form() is None:
+        fused, lti = self._device_forms()
+        if fused is None:
             # no dual-number path: batched differences on the general-LTI kernels (d <= 16), one evaluation at a
             # time above that (e.g. the CO2 kernel at its reference order, d = 18)
-            return self._lti_ll_and_grad(batched=self._lti_form() is not None, wrt=wrt)
+            return self._lti_ll_and_grad(batched=lti is not None, wrt=wrt)
         ll, g = _backend.gp_ll_grad(self._grad_blocks(), ts.reshape(-1), Y.reshape(-1))
         return ll, g
 

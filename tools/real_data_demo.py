@@ -1,6 +1,6 @@
 """Runs the real-data drivers (pssgp/experiments/real_data.py) at the reference's sizes on SYNTHETIC files written in the
 reference's formats (its data files are not part of this repository): sunspot MAP fit + 96 000-point predict_f, a short
-CO2 HMC at quasi-periodic order 2 (d = 14).  Usage: python tools/real_data_demo.py"""
+CO2 HMC at quasi-periodic order 2 (d = 14) and a shorter one at the reference's order 3 (d = 18).  Usage: python tools/real_data_demo.py"""
 import json
 import os
 import pathlib
@@ -31,3 +31,5 @@ with tempfile.TemporaryDirectory() as d:
         for t, v in zip(tm, co2(tm)):
             f.write(f"{int(t)} 1 {t:.4f} {v:.2f} {v:.2f} 30 0.1 0.1\n")
     print(json.dumps(RD.co2_hmc(d, n_training=3192, qp_order=2, n_samples=40, n_burnin=20, step_size=0.002)))
+    # the reference's own order (co2/mcmc.py:42-65): d = 18, one device evaluation per finite-difference point
+    print(json.dumps(RD.co2_hmc(d, n_training=3192, qp_order=3, n_samples=8, n_burnin=4, step_size=0.002)))
