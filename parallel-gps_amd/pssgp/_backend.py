@@ -449,6 +449,56 @@ def lti_predict(F, Pinf, H, R, ts, ys, tq, t0=0.0, device=0):
     return mean, var, ll.value
 
 
+class LtiLlStream:
+    """Log-likelihoods of several general LTI models over one series, one ASYNCHRONOUS device evaluation each
+    (pgps_lti_ll_dev_f64): the series is uploaded once, the results are read once at the end, and the host prepares
+    model i + 1 (its get_sde()) while the device runs model i.  For the state dimensions above the batch kernels'
+    (17..32, e.g. the reference's CO2 kernel, d = 18)."""
+
+    def __init__(self, ts, ys, capacity, t0=0.0, device=0):
+        self.ctx = get_context(device)
+        ts_a = _prep(ts, np.float64, (-1,))
+        ys_a = _prep(ys, np.float64, (-1,))
+        if ys_a.shape[0] != ts_a.shape[0]:
+            raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
+        self.n, self.t0, self.capacity, self.count = ts_a.shape[0], float(t0), int(capacity), 0
+        self.d_ts = self.d_ys = self.d_ll = None
+        try:
+            self.d_ts = self.ctx.malloc(ts_a.nbytes)
+            self.d_ys = self.ctx.malloc(ys_a.nbytes)
+            self.d_ll = self.ctx.malloc(8 * max(self.capacity, 1))
+            self.ctx.h2d(self.d_ts, ts_a)
+            self.ctx.h2d(self.d_ys, ys_a)
+        except Exception:
+            self.close()
+            raise
+
+    def push(self, F, Pinf, H, R):
+        if self.count >= self.capacity:
+            raise ValueError("LtiLlStream is full")
+        F, Pinf, H, d = _lti_model(F, Pinf, H)
+        self.ctx.call("pgps_lti_ll_dev_f64", c_long(self.n), c_int(d), _ptr(F), _ptr(Pinf), _ptr(H), c_double(float(R)),
+                      c_void_p(self.d_ts), c_void_p(self.d_ys), c_double(self.t0), c_void_p(self.d_ll + 8 * self.count))
+        self.count += 1
+
+    def finish(self):
+        """The log-likelihoods pushed so far (waits for the device); releases the device buffers."""
+        out = np.empty(self.count, np.float64)
+        try:
+            if self.count:
+                self.ctx.d2h(out, self.d_ll)
+        finally:
+            self.close()
+        return out
+
+    def close(self):
+        for name in ("d_ts", "d_ys", "d_ll"):
+            p = getattr(self, name, None)
+            if p:
+                self.ctx.free(p)
+            setattr(self, name, None)
+
+
 def lti_ll_batch(models, ts, ys, t0=0.0, device=0):
     """Log-likelihoods of B general LTI models over one series in one set of launches (pgps_lti_ll_batch_f64).
 

@@ -287,29 +287,42 @@ class StateSpaceGP:
             raise ValueError(f"thetas has {thetas.shape[1]} columns, the model {len(params)} trainable parameters")
         saved = [getattr(o, n) for o, n in params]
         models, general = [], []
+        ts, Y = self.data
+        stream = None                   # state dimensions 17..32: asynchronous single evaluations, see below
         try:
             for row in thetas:
                 for (o, n), v in zip(params, row):
                     setattr(o, n, float(v))
                 sde = self.kernel.get_sde()
                 form = _backend.nilpotent_form(sde.F)
-                P0, H = np.asarray(sde.P0, np.float64), np.asarray(sde.H, np.float64).reshape(-1)
+                F, P0, H = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64), np.asarray(sde.H, np.float64).reshape(-1)
                 if form is not None:
                     models.append((form, P0, H, self.noise_variance))
+                d = F.shape[0]
+                if _backend.LTI_BATCH_DIM_MAX < d <= _backend.LTI_DIM_MAX:
+                    # one device evaluation per setting on the wave-cooperative kernels, enqueued as soon as its model
+                    # exists: the device runs setting i while the host builds the SDE of setting i + 1
+                    if stream is None:
+                        stream = _backend.LtiLlStream(ts.reshape(-1), Y.reshape(-1), thetas.shape[0])
+                    stream.push(F, P0, H, self.noise_variance)
+                    continue
                 # kernels without the closed-form discretisation (RBF, Periodic, sums, products): general-LTI batch
-                general.append((np.asarray(sde.F, np.float64), P0, H, self.noise_variance))
+                general.append((F, P0, H, self.noise_variance))
+            if stream is not None:
+                if stream.count != thetas.shape[0]:
+                    raise ValueError("all settings of a batch must give the same state dimension")
+                out, stream = stream.finish(), None
+                return out
         finally:
             for (o, n), v in zip(params, saved):
                 setattr(o, n, v)
-        ts, Y = self.data
+            if stream is not None:
+                stream.close()
         if len(models) == len(general):
             return _backend.gp_ll_batch(models, ts.reshape(-1), Y.reshape(-1))
         d = general[0][0].shape[0]
         if _backend.LTI_DIM_MIN <= d <= _backend.LTI_BATCH_DIM_MAX:
             return _backend.lti_ll_batch(general, ts.reshape(-1), Y.reshape(-1))
-        if d <= _backend.LTI_DIM_MAX:
-            # 17..32: one device evaluation per setting (wave-cooperative kernels; nothing but ts, ys and the model moves)
-            return np.array([_backend.lti_ll(F, P0, H, R, ts.reshape(-1), Y.reshape(-1)) for F, P0, H, R in general])
         raise NotImplementedError(f"batched evaluation covers the Matern family and state dimensions "
                                   f"{_backend.LTI_DIM_MIN}..{_backend.LTI_DIM_MAX}; this kernel has d = {d}")
 
