@@ -3,6 +3,7 @@
 // No PyTorch, no TensorFlow: HIP runtime only.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include <cstdio>
 #include <cstring>
@@ -68,6 +69,7 @@ extern "C" int pgps_create(int device, pgps_ctx** out) {
         return PGPS_E_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char* e = std::getenv("PGPS_WC_SERIAL3")) ctx->wc_serial3 = (e[0] == '1');      // diagnostic, see pgps_wc.hip
     if (hipMalloc((void**)&ctx->status_word, 256) != hipSuccess || hipMemset(ctx->status_word, 0, 256) != hipSuccess) {
         (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;

@@ -10,12 +10,14 @@
 // a row strip of the right one (broadcast along lr).  Padding rows / columns are kept exactly zero.
 // The scan has three levels:
 //
-//   level 1  one wave per chunk of Lw steps          (N / Lw waves)     wc_reduce1 / wc_apply1 / wc_smooth1
-//   level 2  one wave per group of 64 chunk totals   (N / 64 Lw waves)  wc_reduce2 / wc_sreduce2
-//   level 3  one wave folds the group totals                            wc_carry3 / wc_scarry3
+//   level 1  one wave per chunk of Lw steps (16..64)   (N / Lw waves)     wc_reduce1 / wc_apply1 / wc_smooth1
+//   level 2  one wave per group of 8..64 chunk totals                     wc_reduce2 / wc_sreduce2
+//   level 3  Kogge-Stone over the group totals, one wave per element and level: wc_ks_filter + wc_fin_filter,
+//            wc_ks_smoother + wc_fin_smoother (the single wave that used to walk the groups, wc_carry3 /
+//            wc_scarry3, is kept behind PGPS_WC_SERIAL3=1 as a cross-check)
 //
-// and runs as  wc_reduce1 -> wc_reduce2 -> wc_carry3 -> wc_apply1 (writes fms, fPs, ll partials and
-// the smoothing aggregates) -> wc_sreduce2 -> wc_scarry3 -> wc_smooth1 (writes sms, sPs).
+// and runs as  wc_reduce1 -> wc_reduce2 -> level 3 -> wc_apply1 (writes fms, fPs, ll partials and
+// the smoothing aggregates) -> wc_sreduce2 -> level 3 -> wc_smooth1 (writes sms, sPs).
 // Same algebra as pgps_math.h (filt_extend / filt_combine / filt_apply / kf_step / smth_*).  MFMA is not
 // used: the contractions are at most 32 wide and interleaved with solves and rank-one updates.
 //
@@ -31,7 +33,7 @@
 namespace pgps {
 namespace wc {
 
-constexpr int kGroup = 64;      // level-1 totals per level-2 wave
+constexpr int kGroupMax = 64;   // level-1 totals per level-2 wave: WcArgs::kgroup, 8..64 (launch_scan_wc)
 
 template <int DP>
 struct Geo {
@@ -329,6 +331,7 @@ struct WcArgs {
     int d, Lw;
     long nchunk;            // level-1 chunks
     int ngroup;             // level-2 groups
+    int kgroup;             // chunks per group
     const T *P0, *H;
     T R;
     const T *Fs, *Qs, *ys;
@@ -344,6 +347,7 @@ struct WcArgs {
     T* sagg2;               // (ngroup, nsmth)
     T* scarry2;             // (ngroup, d + d^2) smoothed (m, P) of the first step after each group
     double* llpart;         // (nchunk,)
+    T *ksA, *ksB;           // (ngroup, nfilt) each: Kogge-Stone ping-pong over the group totals (both scans)
 };
 
 // One step's (F, Q) as register tiles: fetched a step ahead, parked in LDS when needed.
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(64) void wc_reduce2(const WcArgs<T> a) {
     T* acc = pool.take(NFL); T* cur = pool.take(NFL); T* out = pool.take(NFL);
     T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRC); T* X = pool.take(MSZ); T* vt = pool.take(DP);
     const int g = blockIdx.x;
-    const long c0 = (long)g * kGroup, c1 = min(a.nchunk, c0 + kGroup);
+    const long c0 = (long)g * a.kgroup, c1 = min(a.nchunk, c0 + a.kgroup);
     filt_set_identity<T, DP>(d, acc);
     sync();
     for (long c = c0; c < c1; ++c) {
@@ -711,6 +715,93 @@ __global__ __launch_bounds__(64) void wc_carry3(const WcArgs<T> a) {
     }
 }
 
+// Level 3 as a Kogge-Stone scan over the group totals (the serial wc_carry3 above costs one `apply` per group on ONE
+// wave: 7 ms at 2^20 steps, d = 18): out[i] = in[i - stride] (x) in[i], one wave per element and level.
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_ks_filter(int d, long n, long stride, const T* in, T* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MSZ = Geo<DP>::MSZ, NFL = Geo<DP>::NFL;
+    const int nf = nfilt(d), dk = (d + 3) & ~3;
+    const long i = blockIdx.x;
+    if (i >= n) return;
+    if (i < stride) {
+        for (int e = lane_id(); e < nf; e += 64) out[i * nf + e] = in[i * nf + e];
+        return;
+    }
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* r1 = pool.take(NFL); T* r2 = pool.take(NFL); T* o = pool.take(NFL);
+    T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRC); T* X = pool.take(MSZ); T* vt = pool.take(DP);
+    filt_g2l<T, DP>(d, in + (i - stride) * nf, r1);
+    filt_g2l<T, DP>(d, in + i * nf, r2);
+    sync();
+    combine<T, DP>(d, dk, r1, r2, o, M, rhs, X, vt);
+    sync();
+    filt_l2g<T, DP>(d, o, out + i * nf);
+}
+
+// (m, P) entering group g = the inclusive prefix of the groups before it applied to (0, P0); one wave per group
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_fin_filter(const WcArgs<T> a, const T* incl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MSZ = Geo<DP>::MSZ;
+    const int d = a.d, dd = d * d, nf = nfilt(d), dk = (d + 3) & ~3;
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* m = pool.take(DP); T* P = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NFL);
+    T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRA); T* X = pool.take(MSZ);
+    const int g = blockIdx.x;
+    if (g >= a.ngroup) return;
+    if (lane_id() < DP) m[lane_id()] = T(0);
+    mat_g2l<T, DP>(d, a.P0, P);
+    sync();
+    symmetrise<T, DP>(P);
+    sync();
+    if (g > 0) {
+        filt_g2l<T, DP>(d, incl + (long)(g - 1) * nf, cur);
+        sync();
+        apply<T, DP>(d, dk, m, P, cur, M, rhs, X);
+        sync();
+    }
+    T* out = a.carry2 + (long)g * (d + dd);
+    vec_l2g<T, DP>(d, m, out);
+    mat_l2g<T, DP>(d, P, out + d);
+}
+
+// suffix scan of the smoothing totals: out[i] = in[i] (x) in[i + stride] (the later element is applied first)
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_ks_smoother(int d, long n, long stride, const T* in, T* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NSL = Geo<DP>::NSL;
+    const int ns = nsmth(d), dk = (d + 3) & ~3;
+    const long i = blockIdx.x;
+    if (i >= n) return;
+    if (i + stride >= n) {
+        for (int e = lane_id(); e < ns; e += 64) out[i * ns + e] = in[i * ns + e];
+        return;
+    }
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* ra = pool.take(NSL); T* rb = pool.take(NSL); T* o = pool.take(NSL); T* X = pool.take(Geo<DP>::MSZ);
+    smth_g2l<T, DP>(d, in + i * ns, ra);
+    smth_g2l<T, DP>(d, in + (i + stride) * ns, rb);
+    sync();
+    scombine<T, DP>(dk, ra, rb, o, X);
+    sync();
+    smth_l2g<T, DP>(d, o, out + i * ns);
+}
+
+// (sm, sP) of the first step after group g = (g, L) of the suffix total that starts at group g + 1 (its E multiplies the
+// zero state beyond the end of the series); zero after the last group.  Records are [E | L | g], carries [sm | sP].
+template <typename T>
+__global__ __launch_bounds__(64) void wc_fin_smoother(const WcArgs<T> a, const T* sfx) {
+    const int d = a.d, dd = d * d, ns = nsmth(d);
+    const int g = blockIdx.x;
+    if (g >= a.ngroup) return;
+    T* out = a.scarry2 + (long)g * (d + dd);
+    const bool last = (g == a.ngroup - 1);
+    const T* rec = sfx + (long)(g + 1) * ns;
+    for (int e = lane_id(); e < d + dd; e += 64)
+        out[e] = last ? T(0) : (e < d ? rec[2 * dd + e] : rec[dd + (e - d)]);
+}
+
 // smoother gain E = (Pp^-1 F P)^T from Pp and FP (both LDS matrices); M, rhs scratch
 template <typename T, int DP>
 __device__ __forceinline__ void gain(int d, const T* Pp, const T* FP, T* E, T* M, T* rhs) {
@@ -749,7 +840,7 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
     T* rec = Ee;                                        // the chunk's in-group prefix (NFL <= 3 NSL): prologue only
     static_assert(Geo<DP>::NFL <= 3 * ((Geo<DP>::NSL + 1) & ~1), "prefix record must fit the smoothing scratch");
     const long c = blockIdx.x;
-    const int g = (int)(c / kGroup);
+    const int g = (int)(c / a.kgroup);
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
     vec_g2l<T, DP>(d, a.H, h);
     {   // state entering the chunk: group carry pushed through the in-group prefix
@@ -865,7 +956,7 @@ __global__ __launch_bounds__(64) void wc_sreduce2(const WcArgs<T> a) {
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* acc = pool.take(NSL); T* cur = pool.take(NSL); T* out = pool.take(NSL); T* X = pool.take(Geo<DP>::MSZ);
     const int g = blockIdx.x;
-    const long c0 = (long)g * kGroup, c1 = min(a.nchunk, c0 + kGroup);
+    const long c0 = (long)g * a.kgroup, c1 = min(a.nchunk, c0 + a.kgroup);
     smth_set_identity<T, DP>(d, acc);
     sync();
     for (long c = c1 - 1; c >= c0; --c) {
@@ -924,7 +1015,7 @@ __global__ __launch_bounds__(64) void wc_smooth1(const WcArgs<T> a) {
     T* mp = pool.take(DP); T* v = pool.take(DP); T* rec = pool.take(Geo<DP>::NSL);
     T* rhsA = pool.take(DP * Geo<DP>::NRA);
     const long c = blockIdx.x;
-    const int g = (int)(c / kGroup);
+    const int g = (int)(c / a.kgroup);
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
     {
         const T* cg = a.scarry2 + (long)g * (d + dd);
@@ -1104,6 +1195,9 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode) {
     WC_ATTR((wc_reduce1<T, DP>), l_reduce1);
     WC_ATTR((wc_reduce2<T, DP>), l_reduce2);
     WC_ATTR((wc_carry3<T, DP>), l_carry3);
+    WC_ATTR((wc_ks_filter<T, DP>), l_reduce2);
+    WC_ATTR((wc_fin_filter<T, DP>), l_carry3);
+    WC_ATTR((wc_ks_smoother<T, DP>), l_sred2);
     WC_ATTR((wc_apply1<T, DP, true>), l_apply1);
     WC_ATTR((wc_apply1<T, DP, false>), l_apply1);
     WC_ATTR((wc_sreduce2<T, DP>), l_sred2);
@@ -1113,11 +1207,41 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode) {
     const dim3 blk(64), g1((unsigned)a.nchunk), g2((unsigned)a.ngroup);
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T, DP>, g1, blk, (unsigned)bytes(l_reduce1), a);
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce2<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a);
-    timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_carry3<T, DP>, dim3(1), blk, (unsigned)bytes(l_carry3), a);
+    // level 3: Kogge-Stone over the group totals, ping-pong agg2 -> ksA -> ksB -> ...; serial wc_carry3 / wc_scarry3
+    // (one wave walking the groups) only when forced (PGPS_WC_SERIAL3, the cross-check of the tests)
+    const bool serial3 = ctx->wc_serial3 != 0;
+    if (serial3) {
+        timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_carry3<T, DP>, dim3(1), blk, (unsigned)bytes(l_carry3), a);
+    } else {
+        const T* cur = a.agg2;
+        T* nxt = a.ksA;
+        for (long stride = 1; stride < a.ngroup; stride <<= 1) {
+            timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_ks_filter<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a.d,
+                         (long)a.ngroup, stride, cur, nxt);
+            cur = nxt;
+            nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
+        }
+        timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_fin_filter<T, DP>, g2, blk, (unsigned)bytes(l_carry3), a, cur);
+    }
     if (mode == MODE_PKFS) {
         timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, DP, true>, g1, blk, (unsigned)bytes(l_apply1), a);
         timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_sreduce2<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a);
-        timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_scarry3<T, DP>, dim3(1), blk, (unsigned)bytes(l_scarry3), a);
+        if (serial3) {
+            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_scarry3<T, DP>, dim3(1), blk, (unsigned)bytes(l_scarry3), a);
+        } else {
+            const T* cur = a.sagg2;
+            T* nxt = a.ksA;
+            for (long stride = 1; stride < a.ngroup; stride <<= 1) {
+                timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_ks_smoother<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a.d,
+                             (long)a.ngroup, stride, cur, nxt);
+                cur = nxt;
+                nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
+            }
+            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_fin_smoother<T>, g2, blk, 0u, a, cur);
+            if (a.ll)
+                timed_launch(ctx, PGPS_K_LL_FINALIZE, wc::wc_ll_finalize, dim3(1), blk, 0u, (const double*)a.llpart,
+                             (long)a.nchunk, a.ll);
+        }
         timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_smooth1<T, DP>, g1, blk, (unsigned)bytes(l_smooth1), a);
     } else {
         timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, DP, false>, g1, blk, (unsigned)bytes(l_apply1), a);
@@ -1138,9 +1262,15 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     WcArgs<T> a{};
     a.N = sa.N; a.d = d;
-    a.Lw = ctx->chunk > 0 ? ctx->chunk : 64;
+    // one wave per chunk: about a thousand chunks before the chunks grow to 64 steps; groups of 8..64 chunks so that the
+    // Kogge-Stone levels over the group totals stay at one round of waves (<= 512 groups up to 2^21 steps)
+    long lw = ctx->chunk > 0 ? ctx->chunk : (sa.N + 1023) / 1024;
+    if (ctx->chunk <= 0) lw = lw < 16 ? 16 : (lw > 64 ? 64 : lw);
+    a.Lw = (int)lw;
     a.nchunk = (sa.N + a.Lw - 1) / a.Lw;
-    a.ngroup = (int)((a.nchunk + kGroup - 1) / kGroup);
+    long kg = (a.nchunk + 511) / 512;
+    a.kgroup = (int)(kg < 8 ? 8 : (kg > kGroupMax ? kGroupMax : kg));
+    a.ngroup = (int)((a.nchunk + a.kgroup - 1) / a.kgroup);
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs; a.ll = sa.ll;
     const size_t dd = (size_t)d * d, nf = nfilt(d), ns = nsmth(d), nc = (size_t)a.nchunk, ng = (size_t)a.ngroup;
@@ -1154,12 +1284,15 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     const size_t o_sagg2 = off;  off = wc_align(off + ng * ns * sizeof(T));
     const size_t o_sc2 = off;    off = wc_align(off + ng * (d + dd) * sizeof(T));
     const size_t o_ll = off;     off = wc_align(off + nc * sizeof(double));
+    const size_t o_ksA = off;    off = wc_align(off + ng * nf * sizeof(T));
+    const size_t o_ksB = off;    off = wc_align(off + ng * nf * sizeof(T));
     int rc = ensure(ctx, ctx->ws, off);
     if (rc) return rc;
     char* base = (char*)ctx->ws.p;
     a.agg1 = (T*)(base + o_agg1); a.lpre1 = (T*)(base + o_lpre1); a.agg2 = (T*)(base + o_agg2);
     a.carry2 = (T*)(base + o_carry2); a.sagg1 = (T*)(base + o_sagg1); a.lsuf1 = (T*)(base + o_lsuf1);
     a.sagg2 = (T*)(base + o_sagg2); a.scarry2 = (T*)(base + o_sc2); a.llpart = (double*)(base + o_ll);
+    a.ksA = (T*)(base + o_ksA); a.ksB = (T*)(base + o_ksB);
     if (d <= 8) return launch_scan_wc_dp<T, 8>(ctx, a, mode);
     if (d <= 12) return launch_scan_wc_dp<T, 12>(ctx, a, mode);
     if (d <= 16) return launch_scan_wc_dp<T, 16>(ctx, a, mode);

@@ -65,7 +65,8 @@ def test_forced_wavecoop_small_d(wave_family, kernel_zoo, idx, dtype):
 @pytest.mark.parametrize("n,lw", [(1, 32), (2, 32), (31, 32), (32, 32), (33, 32), (2049, 32), (2200, 7), (4097, 1),
                                   (70000, 16)])
 def test_wavecoop_ragged_lengths_and_levels(wave_family, n, lw):
-    """Chunk / group / multi-group boundaries of the three-level scan (64 chunks per group)."""
+    """Chunk / group / multi-group boundaries of the three-level scan (8..64 chunks per group, Kogge-Stone over the
+    group totals: 9 groups at n = 2049, 456 at n = 4097, 487 at n = 70000)."""
     from pssgp.kernels import Matern52
     wave_family.set_chunk(lw)
     t = make_times(n, seed=n % 97)
@@ -133,3 +134,30 @@ def test_reference_equivalence_suite_exact_kernels():
             mean_ss, var_ss = model.predict_f(query)
             np.testing.assert_allclose(mean_ss[:, 0], mean_gp, atol=val_tol, rtol=val_tol)
             np.testing.assert_allclose(var_ss[:, 0], var_gp, atol=val_tol, rtol=val_tol)
+
+
+def test_level3_kogge_stone_equals_serial_walk(monkeypatch):
+    """Level 3 of the scan -- Kogge-Stone over the group totals -- against the single-wave serial walk it replaced
+    (PGPS_WC_SERIAL3=1, read when a context is created), at d = 18 (the CO2 kernel) with 188 groups."""
+    from pssgp import _backend as B
+    from pssgp.kernels import Matern32, Periodic, SquaredExponential
+    k = Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern32(0.5, 5.) + Matern32(1., 2.)
+    t = make_times(6000, seed=12)
+    ssm = O.get_ssm(k.get_sde(), t, 0.1)
+    y = sample_series(ssm, seed=12, nan_frac=0.15)
+    default = B.get_context()
+    monkeypatch.setenv("PGPS_WC_SERIAL3", "1")
+    serial = B.Context(0)
+    monkeypatch.delenv("PGPS_WC_SERIAL3")
+    res = []
+    try:
+        for ctx in (default, serial):
+            monkeypatch.setitem(B._contexts, 0, ctx)
+            ctx.set_chunk(4)                                  # 1500 chunks, 8 per group
+            res.append(_gpu_all(ssm, y, np.float64))
+    finally:
+        monkeypatch.setitem(B._contexts, 0, default)
+        default.set_chunk(0)
+        serial.close()
+    _check(res[0], res[1], 1e-10)
+    _check(res[0], _oracle_all(ssm, y), 1e-7)
