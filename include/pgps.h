@@ -307,6 +307,10 @@ int pgps_seq_ks_f64(long N, int d, const double* Fs, const double* ms, const dou
 int pgps_seq_ks_f32(long N, int d, const float* Fs, const float* ms, const float* Ps, const float* mps,
                     const float* Pps, float* sms, float* sPs);
 
+/* ---- host helper: the balancing sweep of balance_ss (pssgp/kernels/math_utils.py:10-29, numba in the reference) ----
+ * scale[d] = accumulated diagonal scaling after n_iter sweeps over F (d,d).  Host pointers, no context. */
+int pgps_host_balance_f64(int d, const double* F, int n_iter, double* scale);
+
 #ifdef __cplusplus
 }
 #endif

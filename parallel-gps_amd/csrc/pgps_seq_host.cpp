@@ -184,3 +184,30 @@ extern "C" int pgps_seq_ks_f32(long N, int d, const float* Fs, const float* ms, 
                                const float* Pps, float* sms, float* sPs) {
     return seq_ks<float>(N, d, Fs, ms, Ps, mps, Pps, sms, sPs);
 }
+
+// The sweep of balance_ss (pssgp/kernels/math_utils.py:10-29, a numba loop in the reference): n_iter passes over the
+// states, each visit equalising the off-diagonal column and row 2-norms of the progressively rescaled matrix; returns
+// the accumulated diagonal scaling.  It is the inner loop of every get_sde() of a composite kernel, i.e. of every
+// hyper-parameter setting an optimiser or sampler visits.  0/0 (an isolated state) gives NaN, as in the reference.
+extern "C" int pgps_host_balance_f64(int d, const double* F, int n_iter, double* scale) {
+    if (d < 1 || !F || !scale || n_iter < 0) return PGPS_E_INVALID;
+    std::vector<double> W((size_t)d * d);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) W[(size_t)i * d + j] = (i == j) ? 0.0 : F[(size_t)i * d + j];
+    for (int i = 0; i < d; ++i) scale[i] = 1.0;
+    for (int it = 0; it < n_iter; ++it)
+        for (int i = 0; i < d; ++i) {
+            double c = 0.0, r = 0.0;
+            for (int k = 0; k < d; ++k) {
+                c += W[(size_t)k * d + i] * W[(size_t)k * d + i];
+                r += W[(size_t)i * d + k] * W[(size_t)i * d + k];
+            }
+            const double f = std::pow(r / c, 0.25);
+            scale[i] *= f;
+            for (int k = 0; k < d; ++k) {
+                W[(size_t)k * d + i] *= f;
+                W[(size_t)i * d + k] /= f;
+            }
+        }
+    return PGPS_OK;
+}

@@ -13,11 +13,32 @@ except Exception:                       # pragma: no cover
     _lyap = None
 
 
+def _native_balancing_diagonal(F, n_iter):
+    """The same sweep in libpgps' host code (pgps_host_balance_f64; the reference compiles this loop with numba):
+    None when the library is not built."""
+    try:
+        import ctypes
+        from .. import _backend
+        lib = _backend.load_library()
+        fn = lib.pgps_host_balance_f64
+    except Exception:
+        return None
+    Fc = np.ascontiguousarray(F, dtype=np.float64)
+    scale = np.empty(Fc.shape[0], np.float64)
+    with np.errstate(all="ignore"):
+        code = fn(ctypes.c_int(Fc.shape[0]), Fc.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(n_iter)),
+                  scale.ctypes.data_as(ctypes.c_void_p))
+    return scale if code == 0 else None
+
+
 def _balancing_diagonal(F, n_iter):
     """Sweep `n_iter` times over the states; each visit equalises the off-diagonal
     column and row 2-norms of the progressively rescaled matrix.  Returns the
     accumulated diagonal scaling d (math_utils.py:10-29: the norms are taken on the
     working copy, which is rescaled in place)."""
+    native = _native_balancing_diagonal(F, n_iter)
+    if native is not None:
+        return native
     W = np.array(F, dtype=np.float64, copy=True)
     dim = W.shape[0]
     scale = np.ones(dim)

@@ -158,3 +158,28 @@ def test_nilpotent_form_detection_host():
     assert B.nilpotent_form(RBF(1., 1., order=3).get_sde().F) is None
     assert B.nilpotent_form(Periodic(SquaredExponential(1., 1.), 1., order=1).get_sde().F) is None
     assert B.nilpotent_form((Matern32() + Matern52()).get_sde().F) is None
+
+
+def test_native_balancing_sweep_equals_the_numpy_loop(monkeypatch):
+    """pgps_host_balance_f64 (libpgps host code, used by get_sde when the library is built) against the numpy
+    restatement of the reference's numba loop (pssgp/kernels/math_utils.py:10-29), including the 0/0 of an isolated
+    state."""
+    from pssgp.kernels import math_utils as M
+    rng = np.random.default_rng(3)
+    for d in (2, 5, 11, 18):
+        F = rng.standard_normal((d, d)) * np.exp(rng.uniform(-3, 3, (d, d)))
+        native = M._native_balancing_diagonal(F, 7)
+        assert native is not None, "libpgps.so not built"
+        monkeypatch.setattr(M, "_native_balancing_diagonal", lambda *a: None)
+        ref = M._balancing_diagonal(F, 7)
+        monkeypatch.undo()
+        assert np.max(np.abs(native / ref - 1.0)) < 1e-13
+    F = np.zeros((4, 4))
+    F[:2, :2] = [[-1., 2.], [0.5, -3.]]
+    with np.errstate(all="ignore"):
+        out = M._native_balancing_diagonal(F, 3)
+        monkeypatch.setattr(M, "_native_balancing_diagonal", lambda *a: None)
+        ref = M._balancing_diagonal(F, 3)
+    # 0/0 at the isolated states, and 0 * NaN spreads it through their (zero) rows and columns: NaN throughout, as the
+    # reference's loop gives (SURVEY.md 8d: Periodic + Matern52 as a direct sum)
+    assert np.all(np.isnan(out)) and np.all(np.isnan(ref))
