@@ -104,6 +104,26 @@ def sample_prior_observations(P0, Fs, Qs, H, R, rng):
     return b @ h + np.sqrt(R) * rng.standard_normal(n)
 
 
+def host_core_share():
+    """Threads for the all-cores CPU baseline: the scheduler affinity capped by the cgroup CPU quota (a GPU box shows
+    every core of the host but grants a share of them; more threads than the share only get throttled) and by 32."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = fh.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, p = int(fq.read()), int(fp.read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
+
+
 def main():
     args = parse()
     if os.environ.get("PGPS_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack after N seconds
@@ -453,6 +473,21 @@ def main():
         out["cpu_baseline"] = {"value": n_local / cpu_t, "unit": "timesteps/s", "cores": 1, "kind": "port",
                                "sample": f"the full workload ({n_local} steps), sequential kf+ks "
                                          f"(oracle/kalman_seq.c), median of {reps} runs"}
+        # the same pass on all host cores (chunked scan, oracle/kalman_par.c, OpenMP) -- for context
+        if dtype_np == np.float64 and d <= 16:
+            os.environ.pop("OMP_NUM_THREADS", None)             # pinned to 1 above for numpy's sake only
+            cores = host_core_share()
+            ptimes = []
+            for _ in range(reps):
+                c0 = time.perf_counter()
+                pres = c_oracle.par_kfs(ssm, ys_h, cores)
+                ptimes.append(time.perf_counter() - c0)
+            par_t = float(np.median(ptimes))
+            out["cpu_baseline_all_cores"] = {
+                "value": n_local / par_t, "unit": "timesteps/s", "cores": cores, "kind": "port",
+                "sample": f"the full workload ({n_local} steps), chunked scan with OpenMP over {cores} threads "
+                          f"(oracle/kalman_par.c), median of {reps} runs",
+                "ll_rel_vs_sequential": abs(pres[4] - res[4]) / abs(res[4])}
         # the checker also checks: GPU result vs the sequential oracle on the benchmarked arrays
         cf, cP, cs, csP, cll = res
         out["parity_vs_cpu_oracle"] = {"ll_rel": abs(ll_val - cll) / abs(cll)}

@@ -123,6 +123,30 @@ def test_c_oracle_matches_numpy_oracle(dtype):
         assert abs(cll - ll) < tol * abs(ll)
 
 
+@pytest.mark.parametrize("nthreads", [1, 3, 8])
+def test_all_cores_c_oracle_matches_sequential_c_oracle(nthreads):
+    """oracle/kalman_par.c (chunked scan with OpenMP: the all-cores CPU baseline of bench.py, a C restatement of the
+    filtering / smoothing elements and operators of pssgp/kalman/parallel.py at chunk granularity) against the
+    sequential C oracle and the numpy oracle, with missing observations, ragged chunk sizes and fewer steps than
+    chunks."""
+    from pssgp.kernels import Matern32, Matern52, RBF
+    rng = np.random.default_rng(9)
+    for k, n in ((Matern32(1., 1.), 5003), (Matern32(1., 1.) + Matern52(1., .5), 1201),
+                 (RBF(1., 1., order=6, balancing_iter=10), 700), (Matern52(1., 1.), 5), (Matern32(1., 1.), 1)):
+        t = np.cumsum(0.05 * rng.uniform(0.5, 1.5, n))
+        ssm = O.get_ssm(k.get_sde(), t, 0.1)
+        y = rng.standard_normal(n)
+        y[rng.random(n) < 0.2] = np.nan
+        cf, cP, cs, csP, cll = C.kfs(ssm, y)
+        pf, pP, ps, psP, pll = C.par_kfs(ssm, y, nthreads)
+        assert relerr(pf, cf) < 1e-11 and relerr(pP, cP) < 1e-11
+        assert relerr(ps, cs) < 1e-11 and relerr(psP, csP) < 1e-11
+        assert abs(pll - cll) <= 1e-11 * max(1.0, abs(cll))
+        if n <= 1201:
+            sms, sPs = O.kfs(ssm, y)
+            assert relerr(ps, sms) < 1e-10 and relerr(psP, sPs) < 1e-10
+
+
 def test_merge_sorted_matches_stable_argsort():
     rng = np.random.default_rng(0)
     a = np.sort(rng.integers(0, 50, 40).astype(float))
