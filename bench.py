@@ -104,6 +104,20 @@ def sample_prior_observations(P0, Fs, Qs, H, R, rng):
     return b @ h + np.sqrt(R) * rng.standard_normal(n)
 
 
+def dominant_symbol(slot, d, suf, family, world):
+    """The device function behind a timing slot (slots are named after the lane-chunk kernels): mirrors
+    dispatch_scan in csrc/pgps_core.hip."""
+    smooth = slot == "k_smoother_apply"
+    rc = suf == "f64" and 2 <= d <= 16 and (family == 3 or (family == 0 and (d >= 5 if world == 1 else d > 6)))
+    if rc:
+        return f"pgps::rc::rc_smooth1<{d}, false>" if smooth else f"pgps::rc::rc_apply1<{d}, false>"
+    if family == 2 or (family == 0 and d > 6):
+        if suf == "f32" and family == 0 and d <= 16 and world == 1:
+            return f"pgps::rc::rc_smooth1<{d}, false> (fp32 arrays widened)" if smooth else f"pgps::rc::rc_apply1<{d}, false>"
+        return "pgps::wc::wc_smooth1" if smooth else "pgps::wc::wc_apply1"
+    return f"pgps::{slot}<{'double' if suf == 'f64' else 'float'}, {d}, ...>"
+
+
 def host_core_share():
     """Threads for the all-cores CPU baseline: the scheduler affinity capped by the cgroup CPU quota (a GPU box shows
     every core of the host but grants a share of them; more threads than the share only get throttled) and by 32."""
@@ -327,7 +341,8 @@ def main():
                                f"({n_total} total), {suf}, irregular times, prior-sampled observations",
                    "steps_per_gpu": n_local, "state_dim": d,
                    "parallelism": "1 GPU" if world == 1 else f"{world} contiguous time segments, 2 RCCL all-gathers"},
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": dominant_symbol(dominant, d, suf, args.family, world),
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_avg_s * 1e3,
