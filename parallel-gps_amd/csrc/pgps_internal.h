@@ -28,7 +28,7 @@ struct pgps_ctx {
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
     int wc_serial3 = 0;                 // wave-cooperative family: serial level 3 instead of Kogge-Stone (env PGPS_WC_SERIAL3)
-    DevBuf lti[10];                     // general-LTI entry points: model, merged series, Fs, Qs, E, g (d > 16: moments)
+    DevBuf lti[12];                     // general-LTI entry points: model, merged series, Fs, Qs, E, g (d > 16: moments)
     DevBuf stamps;                      // diagnostic build only
     int* status_word = nullptr;         // device word kernels raise flags in (pgps_status)
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i

@@ -23,6 +23,10 @@ def _kernels():
         "co2_d18": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern32(0.5, 5.) +
         Matern32(1., 2.),                                                                                     # d = 18
         "periodic10": lambda: Periodic(SquaredExponential(1., 0.8), period=1.5, order=10),                    # d = 22
+        # block-diagonal models are discretised block by block (co2_d18: 16 + 2, periodic10: 11 blocks of 2, this
+        # product: 4 blocks of 6); a dense d = 20 companion matrix (RBF order 20) takes wc_discretise
+        "qp3*m52": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern52(1., 2.),       # d = 24
+        "rbf20": lambda: RBF(variance=1., lengthscales=1.5, order=20, balancing_iter=10),                     # d = 20
     }
 
 
@@ -33,7 +37,7 @@ def _series(n, seed):
     return t, y
 
 
-@pytest.mark.parametrize("name", ["m32+m52", "rbf6", "c5_qp_m52", "rbf15", "co2_d18", "periodic10"])
+@pytest.mark.parametrize("name", ["m32+m52", "rbf6", "c5_qp_m52", "rbf15", "co2_d18", "periodic10", "qp3*m52", "rbf20"])
 def test_lti_ll_and_predict_vs_oracle(name):
     from pssgp import _backend as B
     sde = _kernels()[name]().get_sde()
@@ -51,7 +55,7 @@ def test_lti_ll_and_predict_vs_oracle(name):
     # matrix-fraction Q (kernels/base.py:39-46) and the device's Pinf - F Pinf F^T differ by ~3e-7 in the posterior
     # mean (the oracle evaluated with either Q differs from itself by that much; cond Pinf = 1.6e5, Lyapunov
     # residual 5e-13) -- everywhere else the agreement is ~1e-12
-    tol = 2e-6 if name == "rbf15" else 1e-7
+    tol = 2e-6 if name in ("rbf15", "rbf20") else 1e-7
     assert np.max(np.abs(mean - mean_o)) < tol * scale
     assert np.max(np.abs(var - var_o)) < tol * max(1.0, float(np.max(var_o)))
     assert abs(ll2 - ll_o) < 1e-8 * abs(ll_o)
