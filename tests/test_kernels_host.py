@@ -183,3 +183,14 @@ def test_native_balancing_sweep_equals_the_numpy_loop(monkeypatch):
     # 0/0 at the isolated states, and 0 * NaN spreads it through their (zero) rows and columns: NaN throughout, as the
     # reference's loop gives (Periodic + Matern52 as a direct sum)
     assert np.all(np.isnan(out)) and np.all(np.isnan(ref))
+
+
+def test_toymodels_import_path():
+    """The reference's tests import their signals as `from pssgp.toymodels import sinu, obs_noise`
+    (tests/test_gp_vs_kfs.py); the same path works here."""
+    from pssgp.toymodels import comp_sinu, obs_noise, rect, sinu
+    t = np.linspace(0.0, 1.0, 11)
+    for f in (sinu, comp_sinu, rect):
+        assert f(t).shape == t.shape and np.all(np.isfinite(f(t)))
+    y = obs_noise(sinu(t), 0.1, 7)
+    assert y.shape == t.shape and np.all(y == obs_noise(sinu(t), 0.1, 7))
