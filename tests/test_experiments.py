@@ -169,3 +169,36 @@ def test_sunspot_map_and_co2_hmc_on_synthetic_files(tmp_path):
     assert res["state_dim"] == 10 and len(res["posterior_mean"]) == 8
     assert res["posterior_mean"][0] == 1.0 and res["posterior_std"][0] == 0.0        # the period is not trained
     assert abs(res["posterior_mean"][7] - 0.05) < 1e-12 and all(np.isfinite(res["posterior_mean"]))
+
+
+def test_reference_named_enums_and_factories():
+    """pssgp/experiments/common.py:21-71 under the same names: enumerations, covariance factory (QP = Periodic over a
+    squared-exponential base kernel), model factory (the dense GPflow GPR is not part of this backend)."""
+    from pssgp.experiments.common import CovarianceEnum, MCMC, ModelEnum, get_model, get_simple_covariance_function
+    from pssgp.kernels import Matern52, Periodic, RBF
+    from pssgp.misc_utils import rmse
+    assert [m.value for m in MCMC] == ["HMC", "MALA", "NUTS"] and [m.value for m in ModelEnum] == ["GP", "SSGP", "PSSGP"]
+    assert isinstance(get_simple_covariance_function(CovarianceEnum.Matern52, variance=2., lengthscales=.5), Matern52)
+    assert isinstance(get_simple_covariance_function("RBF", variance=1., lengthscales=1., order=4), RBF)
+    qp = get_simple_covariance_function("QP", variance=1.5, lengthscales=0.7, period=2., order=2)
+    assert isinstance(qp, Periodic) and qp.base_kernel.variance == 1.5 and qp.get_sde().F.shape == (6, 6)
+    t = np.linspace(0., 1., 8)[:, None]
+    for name, par in (("SSGP", False), ("PSSGP", True)):
+        m = get_model(name, (t, np.sin(t)), 0.1, qp)
+        assert m.parallel is par and m.noise_variance == 0.1
+    with pytest.raises(NotImplementedError):
+        get_model(ModelEnum.GP, (t, t), 0.1, qp)
+    assert abs(rmse([1., 2.], [[1.], [4.]]) - np.sqrt(2.0)) < 1e-15
+
+
+@pytest.mark.gpu
+def test_factory_models_agree():
+    from pssgp.experiments.common import get_model, get_simple_covariance_function
+    from pssgp.toymodels import obs_noise, sinu
+    t = np.sort(np.random.default_rng(4).uniform(0, 1, 300))
+    y = obs_noise(sinu(t), 0.1, 4)
+    lls = [float(get_model(name, (t[:, None], y[:, None]), 0.1,
+                           get_simple_covariance_function("Matern32", variance=1., lengthscales=0.5)
+                           ).maximum_log_likelihood_objective()) for name in ("SSGP", "PSSGP")]
+    assert abs(lls[0] - lls[1]) < 1e-9 * abs(lls[0])
+    assert abs(lls[0] - O.dense_gp(("matern32", 1., 0.5), t, y, 0.1)) < 1e-8 * abs(lls[0])
