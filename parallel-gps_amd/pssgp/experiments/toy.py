@@ -183,6 +183,113 @@ def hmc(gp, n_samples=1000, n_burnin=100, step_size=0.05, n_leapfrogs=10, seed=3
     return np.array(out), accepted / max(1, n_samples)
 
 
+# ---- the reference's other two samplers (experiments/common.py:95-117 picks HMC, MALA or NUTS from tfp.mcmc) ---------
+def mala_chain(logp_and_grad, u0, n_samples, n_burnin, step_size, rng):
+    """Metropolis-adjusted Langevin: proposal u + step_size grad + sqrt(2 step_size) xi (tfp.mcmc's convention for
+    `step_size`), Metropolis-Hastings correction with the asymmetric proposal densities.  Returns (samples, acceptance)."""
+    u = np.asarray(u0, np.float64).copy()
+    lp, g = logp_and_grad(u)
+    out, accepted = [], 0
+    for it in range(n_samples + n_burnin):
+        prop = u + step_size * g + math.sqrt(2.0 * step_size) * rng.standard_normal(u.shape)
+        try:
+            lpn, gn = logp_and_grad(prop)
+            ok = np.isfinite(lpn) and np.all(np.isfinite(gn))
+        except Exception:
+            ok = False
+        if ok:
+            fwd = -np.sum((prop - u - step_size * g) ** 2) / (4.0 * step_size)
+            bwd = -np.sum((u - prop - step_size * gn) ** 2) / (4.0 * step_size)
+            if math.log(rng.uniform()) < lpn + bwd - lp - fwd:
+                u, lp, g = prop, lpn, gn
+                accepted += it >= n_burnin
+        if it >= n_burnin:
+            out.append(u.copy())
+    return np.array(out), accepted / max(1, n_samples)
+
+
+def nuts_chain(logp_and_grad, u0, n_samples, n_burnin, step_size, rng, max_depth=8):
+    """No-U-Turn sampler (Hoffman & Gelman 2014, algorithm 3: slice variable, doubling, uniform sampling from the
+    admissible set), identity mass matrix, fixed step.  Returns (samples, mean tree depth)."""
+    def leap(u, r, g, eps):
+        r = r + 0.5 * eps * g
+        u = u + eps * r
+        lp, g = logp_and_grad(u)
+        return u, r + 0.5 * eps * g, g, lp
+
+    def build(u, r, g, log_slice, v, j, eps):
+        if j == 0:
+            try:
+                u1, r1, g1, lp1 = leap(u, r, g, v * eps)
+                joint = lp1 - 0.5 * r1 @ r1
+                if not (np.isfinite(joint) and np.all(np.isfinite(g1))):
+                    joint = -np.inf
+            except Exception:
+                u1, r1, g1, lp1, joint = u, r, g, -np.inf, -np.inf
+            n1 = int(log_slice <= joint)
+            s1 = log_slice < joint + 1000.0
+            return u1, r1, g1, u1, r1, g1, u1, g1, lp1, n1, s1
+        um, rm, gm, up, rp, gp_, u1, g1, lp1, n1, s1 = build(u, r, g, log_slice, v, j - 1, eps)
+        if s1:
+            if v == -1:
+                um, rm, gm, _, _, _, u2, g2, lp2, n2, s2 = build(um, rm, gm, log_slice, v, j - 1, eps)
+            else:
+                _, _, _, up, rp, gp_, u2, g2, lp2, n2, s2 = build(up, rp, gp_, log_slice, v, j - 1, eps)
+            if n2 > 0 and rng.uniform() < n2 / max(n1 + n2, 1):
+                u1, g1, lp1 = u2, g2, lp2
+            du = up - um
+            s1 = s2 and (du @ rm >= 0) and (du @ rp >= 0)
+            n1 += n2
+        return um, rm, gm, up, rp, gp_, u1, g1, lp1, n1, s1
+
+    u = np.asarray(u0, np.float64).copy()
+    lp, g = logp_and_grad(u)
+    out, depths = [], []
+    for it in range(n_samples + n_burnin):
+        r0 = rng.standard_normal(u.shape)
+        log_slice = lp - 0.5 * r0 @ r0 + math.log(rng.uniform())
+        um, up, rm, rp, gm, gp_ = u, u, r0, r0, g, g
+        j, n, s = 0, 1, True
+        while s and j < max_depth:
+            v = -1 if rng.uniform() < 0.5 else 1
+            if v == -1:
+                um, rm, gm, _, _, _, u1, g1, lp1, n1, s1 = build(um, rm, gm, log_slice, v, j, step_size)
+            else:
+                _, _, _, up, rp, gp_, u1, g1, lp1, n1, s1 = build(up, rp, gp_, log_slice, v, j, step_size)
+            if s1 and n1 > 0 and rng.uniform() < min(1.0, n1 / n):
+                u, g, lp = u1, g1, lp1
+            n += n1
+            du = up - um
+            s = s1 and (du @ rm >= 0) and (du @ rp >= 0)
+            j += 1
+        if it >= n_burnin:
+            out.append(u.copy())
+            depths.append(j)
+    return np.array(out), float(np.mean(depths)) if depths else 0.0
+
+
+def run_chain(gp, mcmc="HMC", n_samples=1000, n_burnin=100, step_size=0.05, n_leapfrogs=10, seed=31415):
+    """The sampler choice of the reference's scripts (experiments/common.py:95-117) over this module's posterior:
+    returns constrained samples (n_samples, P) and a diagnostic (acceptance rate; mean tree depth for NUTS)."""
+    mcmc = getattr(mcmc, "value", mcmc).upper()
+    if mcmc == "HMC":
+        return hmc(gp, n_samples, n_burnin, step_size, n_leapfrogs, seed)
+    rng = np.random.RandomState(seed)
+    params = gp.trainable_parameters()
+    u0 = _softplus_inv(np.array([getattr(o, n) for o, n in params], np.float64))
+    f = lambda u: log_posterior_and_grad(gp, u)
+    if mcmc == "MALA":
+        us, diag = mala_chain(f, u0, n_samples, n_burnin, step_size, rng)
+    elif mcmc == "NUTS":
+        us, diag = nuts_chain(f, u0, n_samples, n_burnin, step_size, rng)
+    else:
+        raise ValueError(f"sampler {mcmc!r}: HMC, MALA or NUTS")
+    theta = _softplus(us)
+    for (o, n), v in zip(params, theta[-1] if len(theta) else _softplus(u0)):
+        setattr(o, n, float(v))
+    return theta, diag
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     sub = ap.add_subparsers(dest="cmd", required=True)
