@@ -1612,8 +1612,12 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
         // four chains per wave: 4096 chains put one wave on every SIMD, and every doubling adds a Kogge-Stone
         // launch to both scans.  Measured at d = 11: 2^17 steps 0.67 ms with 4096 chains against 0.79 ms with 8192;
         // 2^20 steps 3.57 ms with 8192 (two waves per SIMD where the registers allow) against 3.73 ms with 4096.
+        // From d = 10 the filter + smoother with every moment written is better off with 4096 chains up to 2^20 steps
+        // (d = 11: 3.24 -> 3.11 ms, d = 15: 5.45 -> 5.19 ms; d = 6 loses 12 %, the log-likelihood-only and projected
+        // calls lose 2-10 %, so they keep 8192).
+        const long cap = (d >= 10 && store_f && !qslot && mode == MODE_PKFS) ? 256 : 128;
         long lw = (sa.N + 4095) / 4096;
-        if (lw > 128) { lw = (sa.N + 8191) / 8192; if (lw < 128) lw = 128; }
+        if (lw > cap) { lw = (sa.N + 8191) / 8192; if (lw < cap) lw = cap; }
         if (batch > 1) {                        // the models multiply the chains: keep about 8192 in flight
             lw = ((long)sa.N * batch + 8191) / 8192;
             if (lw > 128) lw = 128;
