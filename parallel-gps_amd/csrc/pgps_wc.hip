@@ -1189,7 +1189,11 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode) {
     size_t need = 0;
     for (size_t v : {l_reduce1, l_reduce2, l_carry3, l_apply1, l_sred2, l_scarry3, l_smooth1}) need = need > v ? need : v;
     if (bytes(need) > 160 * 1024) return PGPS_E_UNSUPPORTED_DIM;
+    // the dynamic-LDS ceilings are set once per context and instantiation (a dozen runtime calls per scan otherwise:
+    // they show at the few-thousand-step series of the experiment drivers)
+    bool& attr_done = ctx->wc_attr_done[sizeof(T) == 8 ? 1 : 0][DP / 4];
 #define WC_ATTR(K, L)                                                                                              \
+    if (!attr_done)                                                                                                \
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)bytes(L)))
     WC_ATTR((wc_reduce1<T, DP>), l_reduce1);
@@ -1204,6 +1208,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode) {
     WC_ATTR((wc_scarry3<T, DP>), l_scarry3);
     WC_ATTR((wc_smooth1<T, DP>), l_smooth1);
 #undef WC_ATTR
+    attr_done = true;
     const dim3 blk(64), g1((unsigned)a.nchunk), g2((unsigned)a.ngroup);
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T, DP>, g1, blk, (unsigned)bytes(l_reduce1), a);
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce2<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a);
