@@ -361,3 +361,60 @@ def test_nilpotent_form_detection():
     assert B.nilpotent_form(RBF(1., 1., order=3).get_sde().F) is None
     assert B.nilpotent_form(Periodic(SquaredExponential(1., 1.), 1., order=1).get_sde().F) is None
     assert B.nilpotent_form((Matern32() + Matern12()).get_sde().F) is None
+
+
+def test_two_host_threads_with_their_own_contexts():
+    """one context per host thread.  Two threads, each with its own context on the same GPU, run
+    different workloads (lane-chunk d = 2, row-cooperative d = 11) concurrently and repeatedly; every result equals
+    the single-threaded one bit for bit."""
+    import ctypes
+    import threading
+    from pssgp import _backend as B
+    from pssgp.kernels import Matern32, Matern52, Periodic, SquaredExponential
+    kernels = [Matern32(1., 1.), Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.)]
+    jobs = []
+    for i, k in enumerate(kernels):
+        t = make_times(30011 if i == 0 else 6007, seed=40 + i)
+        ssm = O.get_ssm(k.get_sde(), t, 0.1)
+        y = sample_series(ssm, seed=40 + i, nan_frac=0.1)
+        jobs.append((ssm, y))
+
+    def run(ctx, ssm, y):
+        P0, Fs, Qs, H, R = (np.ascontiguousarray(a, np.float64) for a in ssm)
+        N, d = Fs.shape[0], Fs.shape[1]
+        sms, sPs = np.empty((N, d)), np.empty((N, d, d))
+        fms, fPs = np.empty((N, d)), np.empty((N, d, d))
+        ll = ctypes.c_double(0.0)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        ctx.call("pgps_pkfs_f64", ctypes.c_long(N), ctypes.c_int(d), p(P0), p(Fs), p(Qs), p(H.reshape(-1)),
+                 ctypes.c_double(float(R.reshape(()))), p(np.ascontiguousarray(y)), p(fms), p(fPs), p(sms), p(sPs),
+                 ctypes.cast(ctypes.byref(ll), ctypes.c_void_p))
+        return sms, sPs, ll.value
+
+    ctxs = [B.Context(0), B.Context(0)]
+    try:
+        want = [run(ctxs[i], *jobs[i]) for i in range(2)]
+        errors = []
+
+        def worker(i):
+            try:
+                for _ in range(15):
+                    got = run(ctxs[i], *jobs[i])
+                    if not (np.array_equal(got[0], want[i][0]) and np.array_equal(got[1], want[i][1]) and got[2] == want[i][2]):
+                        errors.append(f"thread {i}: result changed under concurrency")
+                        return
+            except Exception as e:                         # noqa: BLE001
+                errors.append(f"thread {i}: {e!r}")
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=120)
+        assert not any(th.is_alive() for th in threads), "a worker did not finish"
+        assert not errors, errors
+    finally:
+        for c in ctxs:
+            c.close()
+    os_, osP = O.kfs(jobs[1][0], jobs[1][1])
+    assert relerr(want[1][0], os_) < 1e-9 and relerr(want[1][1], osP) < 1e-9
