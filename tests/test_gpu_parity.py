@@ -418,3 +418,47 @@ def test_two_host_threads_with_their_own_contexts():
             c.close()
     os_, osP = O.kfs(jobs[1][0], jobs[1][1])
     assert relerr(want[1][0], os_) < 1e-9 and relerr(want[1][1], osP) < 1e-9
+
+
+def test_error_codes_across_the_abi():
+    """Errors are return codes, never exceptions or faults (include/pgps.h; the reference raises
+    InvalidArgumentError from TensorFlow): bad sizes, unsupported state dimensions, null and misaligned pointers, a
+    model whose log-likelihood is not finite."""
+    import ctypes
+    from pssgp import _backend as B
+    lib, ctx = B.load_library(), B.get_context()
+    h = ctx.handle
+    P = ctypes.c_void_p
+    N, d = 64, 2
+    t = make_times(N, seed=1)
+    from pssgp.kernels import Matern32
+    ssm = O.get_ssm(Matern32(1., 1.).get_sde(), t, 0.1)
+    P0, Fs, Qs, Hm, R = (np.ascontiguousarray(a, np.float64) for a in ssm)
+    y = sample_series(ssm, seed=1)
+    sms, sPs = np.empty((N, d)), np.empty((N, d, d))
+    ll = ctypes.c_double(0.0)
+    p = lambda a: a.ctypes.data_as(P)
+    args = lambda n, dim: (h, ctypes.c_long(n), ctypes.c_int(dim), p(P0), p(Fs), p(Qs), p(Hm.reshape(-1)),
+                           ctypes.c_double(0.1), p(y), None, None, p(sms), p(sPs), ctypes.cast(ctypes.byref(ll), P))
+    assert lib.pgps_pkfs_f64(*args(N, d)) == 0
+    assert lib.pgps_pkfs_f64(*args(0, d)) == -1                        # PGPS_E_INVALID
+    assert lib.pgps_pkfs_f64(*args(N, 33)) == -2                       # PGPS_E_UNSUPPORTED_DIM
+    assert lib.pgps_pkfs_f64(*args(N, 0)) in (-1, -2)
+    bad = list(args(N, d))
+    bad[4] = None                                                       # Fs = NULL
+    assert lib.pgps_pkfs_f64(*bad) != 0
+    # device entry point with a misaligned pointer
+    dptr = ctx.malloc(Fs.nbytes + 64)
+    try:
+        rc = lib.pgps_pkf_dev_f64(h, ctypes.c_long(N), ctypes.c_int(d), P(dptr), P(dptr + 8), P(dptr), P(dptr),
+                                  ctypes.c_double(0.1), P(dptr), P(dptr), P(dptr), None)
+        assert rc == -1
+    finally:
+        ctx.free(dptr)
+    # non-finite result: negative noise variance large enough to make an innovation variance negative
+    with pytest.raises(B.PgpsError) as err:
+        B.lti_ll(np.array([[-1., 0.], [0., -2.]]), np.diag([1., 1.]), np.array([1., 1.]), -5.0, t, y)
+    assert err.value.code == -5                                         # PGPS_E_NUMERIC
+    # the context is still usable afterwards
+    assert lib.pgps_pkfs_f64(*args(N, d)) == 0
+    assert isinstance(lib.pgps_strerror(-1), bytes) and len(lib.pgps_strerror(-1)) > 0
