@@ -285,15 +285,18 @@ def test_statespacegp_equals_dense_gp(kernel_zoo, idx):
         assert np.max(np.abs(mean[:, 0] - mean_o)) < 1e-8 and np.max(np.abs(var[:, 0] - var_o)) < 1e-8
 
 
-@pytest.mark.parametrize("dtype,kname,n", [(np.float64, "m32", 1 << 20), (np.float32, "rbf6", 1 << 18)])
+@pytest.mark.parametrize("dtype,kname,n", [(np.float64, "m32", 1 << 20), (np.float32, "rbf6", 1 << 18),
+                                           (np.float32, "rbf6", 1 << 20), (np.float64, "c5", 1 << 20),
+                                           (np.float64, "m32", 1 << 21)])
 def test_full_size_against_c_oracle(dtype, kname, n):
-    """BASELINE sizes: N = 2^20 Matern-3/2 fp64 (config c2) against the C sequential oracle on
-    the same arrays, plus size-independent properties: the smoothed state of the last step
-    equals its filtered state, smoothed variances never exceed filtered ones, and the
-    log-likelihood is additive over a split of the series into two calls at a missing gap."""
-    from pssgp.kernels import Matern32, RBF
+    """BASELINE sizes -- N = 2^20 Matern-3/2 fp64 (config c2), RBF order 6 fp32 (c3), the quasi-periodic d = 11 kernel
+    fp64 (c5), 2^21 Matern-3/2 (one GPU's share of c4) -- against the C sequential oracle on the same arrays, plus
+    size-independent properties: the smoothed state of the last step equals its filtered state and smoothed variances
+    never exceed filtered ones."""
+    from pssgp.kernels import Matern32, Matern52, Periodic, RBF, SquaredExponential
     B = _gpu()
-    k = Matern32(1., 1.) if kname == "m32" else RBF(1., 1., order=6, balancing_iter=10)
+    k = {"m32": lambda: Matern32(1., 1.), "rbf6": lambda: RBF(1., 1., order=6, balancing_iter=10),
+         "c5": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.)}[kname]()
     sde = k.get_sde()
     t = make_times(n, seed=0)
     Fs, Qs = B.discretise(sde.F, sde.P0, t, 0.0)                    # fp64 discretisation on the GPU
