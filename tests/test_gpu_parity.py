@@ -287,10 +287,10 @@ def test_statespacegp_equals_dense_gp(kernel_zoo, idx):
 
 @pytest.mark.parametrize("dtype,kname,n", [(np.float64, "m32", 1 << 20), (np.float32, "rbf6", 1 << 18),
                                            (np.float32, "rbf6", 1 << 20), (np.float64, "c5", 1 << 20),
-                                           (np.float64, "m32", 1 << 21)])
+                                           (np.float64, "m32", 1 << 21), (np.float64, "m32", 1 << 24)])
 def test_full_size_against_c_oracle(dtype, kname, n):
     """BASELINE sizes -- N = 2^20 Matern-3/2 fp64 (config c2), RBF order 6 fp32 (c3), the quasi-periodic d = 11 kernel
-    fp64 (c5), 2^21 Matern-3/2 (one GPU's share of c4) -- against the C sequential oracle on the same arrays, plus
+    fp64 (c5), 2^21 and 2^24 Matern-3/2 (one GPU's share of c4, and all of it) -- against the C sequential oracle on the same arrays, plus
     size-independent properties: the smoothed state of the last step equals its filtered state and smoothed variances
     never exceed filtered ones."""
     from pssgp.kernels import Matern32, Matern52, Periodic, RBF, SquaredExponential
