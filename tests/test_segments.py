@@ -328,3 +328,60 @@ def test_segmentscan_multiprocess_on_one_gpu(tmp_path, world):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+
+
+@pytest.mark.gpu
+def test_config_c4_scale_eight_segments_on_one_gpu():
+    """BASELINE config c4 (Matern-3/2, fp64, 2^24 steps as 8 contiguous segments of 2^21) with the eight ranks played
+    one after the other on a single GPU, the two all-gathers done by numpy: every rank's slice of the filtered and
+    smoothed moments and the log-likelihood against the sequential C oracle on the whole series."""
+    from oracle import c_oracle as C
+    from pssgp import _backend as B
+    from pssgp.distributed import record_lengths, split_segments
+    from pssgp.kernels import Matern32
+    from tests.conftest import make_times, sample_series_fast
+    world, n_total, d = 8, 1 << 24, 2
+    sde = Matern32(1., 1.).get_sde()
+    t = make_times(n_total, seed=0)
+    Fs, Qs = B.discretise(sde.F, sde.P0, t, 0.0)
+    ssm = (np.asarray(sde.P0), Fs, Qs, np.asarray(sde.H).reshape(1, -1), np.array([[0.1]]))
+    y = sample_series_fast(ssm, seed=0, nan_frac=0.1)
+    cf, cP, cs, csP, cll = C.kfs(ssm, y)
+    rf, rs, _ = record_lengths(d)
+    bounds = split_segments(n_total, world)
+    L, I, Rv = ctypes.c_long, ctypes.c_int, ctypes.c_double(0.1)
+    ranks = []
+    try:
+        for r, (lo, hi) in enumerate(bounds):
+            n = hi - lo
+            ctx = B.Context(0)              # a rank = a context: the scan workspace lives in it between the phases
+            ranks.append(dict(ctx=ctx, n=n, lo=lo, hi=hi, P0=_Dev(ctx, ssm[0]), H=_Dev(ctx, ssm[3].reshape(-1)),
+                              Fs=_Dev(ctx, Fs[lo:hi]), Qs=_Dev(ctx, Qs[lo:hi]), ys=_Dev(ctx, y[lo:hi]),
+                              fms=_Dev(ctx, shape=(n, d)), fPs=_Dev(ctx, shape=(n, d, d)), sms=_Dev(ctx, shape=(n, d)),
+                              sPs=_Dev(ctx, shape=(n, d, d)), rec_f=_Dev(ctx, shape=(rf,)), rec_s=_Dev(ctx, shape=(rs,)),
+                              gf=_Dev(ctx, shape=(world, rf)), gs=_Dev(ctx, shape=(world, rs)), ll=_Dev(ctx, shape=(2,))))
+        for r, k in enumerate(ranks):
+            k["ctx"].call("pgps_seg_filter_reduce_dev_f64", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p, k["Qs"].p, k["H"].p, Rv,
+                     k["ys"].p, k["rec_f"].p)
+        gf = np.stack([k["rec_f"].get() for k in ranks])
+        for r, k in enumerate(ranks):
+            k["gf"].put(gf)
+            k["ctx"].call("pgps_seg_filter_apply_dev_f64", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p, k["Qs"].p, k["H"].p, Rv,
+                     k["ys"].p, k["gf"].p, k["fms"].p, k["fPs"].p, k["rec_s"].p)
+        gs = np.stack([k["rec_s"].get() for k in ranks])
+        for r, k in enumerate(ranks):
+            k["gs"].put(gs)
+            k["ctx"].call("pgps_seg_smoother_apply_dev_f64", L(k["n"]), I(d), I(r), I(world), k["Fs"].p, k["Qs"].p, k["fms"].p,
+                     k["fPs"].p, k["gs"].p, k["sms"].p, k["sPs"].p, k["ll"].p)
+        for k in ranks:
+            lo, hi = k["lo"], k["hi"]
+            assert relerr(k["fms"].get(), cf[lo:hi]) < 1e-8 and relerr(k["fPs"].get(), cP[lo:hi]) < 1e-8
+            assert relerr(k["sms"].get(), cs[lo:hi]) < 1e-8 and relerr(k["sPs"].get(), csP[lo:hi]) < 1e-8
+            assert abs(k["ll"].get()[0] - cll) < 1e-10 * abs(cll)
+    finally:
+        for k in ranks:
+            k["ctx"].synchronize()
+            for v in k.values():
+                if isinstance(v, _Dev):
+                    v.free()
+            k["ctx"].close()
