@@ -1129,8 +1129,8 @@ static int lti_dev(pgps_ctx* ctx, long N, long K, int d, const double* F, const 
     TRY(stage_in<double>(ctx, ctx->st[11], nullptr, 2, &dll));
     if (d > rc::kDimMax) return lti_dev_wc(ctx, m, d, model, F, Pinf, R, ts_m, ys_m, t0, qslot, mean, var, ll ? ll : dll);
     TRY(stage_in<double>(ctx, ctx->lti[4], nullptr, m * dd, &Fs));
-    // log-likelihood only: the process noise stays implicit (Q_k = Pinf - F_k Pinf F_k^T inside the predict)
-    if (K > 0) TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, m * dd, &Qs));
+    // the process noise stays implicit in both calls (Q_k = Pinf - F_k Pinf F_k^T inside the predict step): Qs is
+    // never formed
     TRY(launch_disc_rc(ctx, (long)m, d, model, model + dd, ts_m, t0, Fs, Qs));
     ScanArgs<double> a{};
     a.N = (long)m; a.seg_first = 1; a.seg_last = 1;

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) void rc_reduce1(const RcArgs a0) {
 // level 1: apply -- Kalman pass, log-likelihood, smoothing elements and the chunk's smoothing total
 // (kf_step / smth_element / smth_combine of pgps_math.h; parallel.py:135-151, 155-184)
 // ====================================================================================================
-template <int D, bool SMOOTH, bool FAST>
+template <int D, bool SMOOTH, bool FAST, bool IMPQS = false>
 __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
@@ -385,7 +385,9 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
     LogLik ll;
     double Fc[D], Fr[D], Q[D], y;
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
-    const bool impq = !SMOOTH && (a.implicit_q & 1);    // see rc_reduce1; the smoothing elements need F P itself
+    // see rc_reduce1.  Filter only: a runtime flag; with the smoothing elements (which need F P itself: one more
+    // product) a separate instantiation, so that the array path's kernel stays exactly as it was
+    const bool impq = SMOOTH ? IMPQS : (a.implicit_q & 1);
     double Pinf[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
@@ -418,17 +420,27 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
         const long ku = kw + s, k = k0 + s;
         // predict
         double FP[D], Pp[D];
-        if (impq) {
+        if (impq && !SMOOTH) {
             double Pm[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) Pm[i] = P[i] - Pinf[i];
             zero<D>(FP); mm<D>(FP, Fc, Pm);
             copy<D>(Pp, Pinf);
+            mm<D>(Pp, FP, Fr);
+        } else if (impq) {
+            // with the smoothing elements F P is needed as it is: Pp = Pinf + (F P - F Pinf) F^T
+            double FI[D], Dm[D];
+            zero<D>(FP); mm<D>(FP, Fc, P);
+            zero<D>(FI); mm<D>(FI, Fc, Pinf);
+#pragma unroll
+            for (int i = 0; i < D; ++i) Dm[i] = FP[i] - FI[i];
+            copy<D>(Pp, Pinf);
+            mm<D>(Pp, Dm, Fr);
         } else {
             zero<D>(FP); mm<D>(FP, Fc, P);
             copy<D>(Pp, Q);
+            mm<D>(Pp, FP, Fr);
         }
-        mm<D>(Pp, FP, Fr);
         const double mp = mvr<D>(Fr, m, 0.0);
         const double yk = y;
         // Next step's inputs.  The filter-only kernel has the registers to fetch them a whole step ahead; with
@@ -519,14 +531,15 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
     }
 }
 
-template <int D, bool SMOOTH>
+template <int D, bool SMOOTH, bool IMPQS = false>
 __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a0) {
+    static_assert(SMOOTH || !IMPQS, "the implicit-noise instantiation is the smoothing one");
     __shared__ double tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     double* patch = patch_init(tl, row);
     const RcArgs a = model_view(a0);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<D, SMOOTH, true>(a, patch, lane, row);
-    else apply1_body<D, SMOOTH, false>(a, patch, lane, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<D, SMOOTH, true, IMPQS>(a, patch, lane, row);
+    else apply1_body<D, SMOOTH, false, IMPQS>(a, patch, lane, row);
 }
 
 // ====================================================================================================
@@ -1096,7 +1109,10 @@ int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
     const dim3 blk(64), g1((unsigned)((a.nchunk + 3) / 4), (unsigned)(a.batch > 1 ? a.batch : 1));
     switch (phase) {
         case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_reduce1<D>, g1, blk, 0u, a); break;
-        case 1: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, true>, g1, blk, 0u, a); break;
+        case 1:
+            if (a.implicit_q & 1) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, true, true>, g1, blk, 0u, a);
+            else timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, true>, g1, blk, 0u, a);
+            break;
         case 2: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, false>, g1, blk, 0u, a); break;
         case 3: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D, false>, g1, blk, 0u, a); break;
         case 5: timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_selem1<D>, g1, blk, 0u, a); break;

@@ -1636,7 +1636,8 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
     a.store_f = store_f; a.qslot = qslot; a.pmean = pmean; a.pvar = pvar;
     a.seg_first = 1; a.seg_last = 1;
     a.implicit_q = (sa.Qs == nullptr) ? 1 : 0;
-    if (a.implicit_q && (mode != MODE_PKF || store_f)) return PGPS_E_INVALID;
+    // (Qs may be absent where nothing per step is written: the log-likelihood call and the projected smoother)
+    if (a.implicit_q && (store_f || (mode != MODE_PKF && !(mode == MODE_PKFS && qslot)))) return PGPS_E_INVALID;
     // projected-posterior calls come from the general-LTI entry points, whose Qs is Pinf - F Pinf F^T by
     // construction: the reduce pass need not read it
     if (qslot && !a.implicit_q) a.implicit_q = 2;
