@@ -1622,7 +1622,7 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
         // calls lose 2-10 %, so they keep 8192).
         const long cap = (d >= 10 && store_f && !qslot && mode == MODE_PKFS) ? 256 : 128;
         long lw = (sa.N + 4095) / 4096;
-        if (lw > cap) { lw = (sa.N + 8191) / 8192; if (lw < cap) lw = cap; }
+        if (lw > cap) { lw = (sa.N + 8191) / 8192; if (lw < 128) lw = 128; }     // 8192 chains, two full rounds of blocks
         if (batch > 1) {                        // the models multiply the chains: keep about 8192 in flight
             lw = ((long)sa.N * batch + 8191) / 8192;
             if (lw > 128) lw = 128;
