@@ -67,6 +67,8 @@ int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
  * wave-cooperative otherwise, d <= 32),
  * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64, 2 <= d <= 16). */
 int pgps_set_family(pgps_ctx* ctx, int family);
+/* (Diagnostic, environment: PGPS_WC_SERIAL3=1 when a context is created makes the wave-cooperative family walk its
+ * group totals with one wave instead of the Kogge-Stone scan -- the cross-check of tests/test_gpu_wavecoop.py.) */
 /* LDS staging of the lane-chunk kernels: -1 = automatic, 0 = off (direct global accesses),
  * 2 or 4 = steps per lane per staged sub-tile (2: fp64 only).  Tuning / A-B knob. */
 int pgps_set_stage(pgps_ctx* ctx, int steps_per_subtile);
