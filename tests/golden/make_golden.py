@@ -75,7 +75,7 @@ def small_d():
 def large_d():
     """Sequential-oracle outputs (N = 1024, 20 % missing) for config c5's kernel
     `Periodic(SE(1, 1), period 1, order 1) * Matern32 + Matern52` (d = 11) and RBF order 15 (d = 15): the state
-    dimensions of the row-cooperative kernels.  Stored as projections (H m, H P H^T) plus the filtered / smoothed
+    dimensions of the row-cooperative kernels; and the CO2 kernel of the reference at d = 18 (wave-cooperative).  Stored as projections (H m, H P H^T) plus the filtered / smoothed
     moments of a few steps in full."""
     from pssgp.kernels import Matern32, Matern52, Periodic, RBF, SquaredExponential
     rng = np.random.default_rng(2)
@@ -85,7 +85,9 @@ def large_d():
     y[rng.random(n) < 0.2] = np.nan
     out = {"t": t, "y": y, "full_steps": np.array([0, 1, 511, 1022, 1023])}
     kernels = {"c5": Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.),
-               "rbf15": RBF(1., 0.5, order=15, balancing_iter=10)}
+               "rbf15": RBF(1., 0.5, order=15, balancing_iter=10),
+               # the reference's CO2 kernel at its own order (experiments/co2/mcmc.py:42-65), d = 18: wave-cooperative path
+               "co2_d18": Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern32(0.5, 5.) + Matern32(1., 2.)}
     for name, k in kernels.items():
         ssm = O.get_ssm(k.get_sde(), t, 0.1)
         fms, fPs, ll = O.kf(ssm, y, True)

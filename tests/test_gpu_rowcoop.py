@@ -215,18 +215,19 @@ def test_fp32_series_at_large_d_run_through_fp64(name):
     assert np.max(np.abs(gQs - ssm[2])) < 1e-3 * max(1.0, float(np.max(np.abs(ssm[0]))))
 
 
-@pytest.mark.parametrize("name", ["c5", "rbf15"])
+@pytest.mark.parametrize("name", ["c5", "rbf15", "co2_d18"])
 def test_golden_large_d(name):
-    """The committed sequential-oracle vectors for d = 11 (config c5's kernel) and d = 15 (tests/golden/
-    large_d_n1024.npz, written by tests/golden/make_golden.py): through pkf / pkfs on the arrays and through the
-    general-LTI device path."""
+    """The committed sequential-oracle vectors for d = 11 (config c5's kernel), d = 15 and d = 18 (the reference's CO2
+    kernel: wave-cooperative kernels) (tests/golden/large_d_n1024.npz, written by tests/golden/make_golden.py):
+    through pkf / pkfs on the arrays and through the general-LTI device path."""
     import os
     from pssgp import _backend as B
     from pssgp.kalman.parallel import pkf, pkfs
     from pssgp.kernels import Matern32, Matern52, Periodic, RBF, SquaredExponential
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "large_d_n1024.npz"))
     k = {"c5": Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.),
-         "rbf15": RBF(1., 0.5, order=15, balancing_iter=10)}[name]
+         "rbf15": RBF(1., 0.5, order=15, balancing_iter=10),
+         "co2_d18": Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern32(0.5, 5.) + Matern32(1., 2.)}[name]
     ssm = k.get_ssm(g["t"][:, None], 0.1)
     fms, fPs, ll = pkf(ssm, g["y"][:, None], return_loglikelihood=True)
     sms, sPs = pkfs(ssm, g["y"][:, None])

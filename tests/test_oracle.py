@@ -186,3 +186,9 @@ def test_golden_fixtures_reproduce():
     assert abs(pll - float(g["c5/ll"])) < 1e-9 * abs(float(g["c5/ll"]))
     h = ssm[3].reshape(-1)
     assert np.max(np.abs(pf @ h - g["c5/fmean"])) < 1e-9
+    # d = 18: the reference's CO2 kernel at its own order
+    k18 = Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern32(0.5, 5.) + Matern32(1., 2.)
+    ssm = O.get_ssm(k18.get_sde(), g["t"], 0.1)
+    assert ssm[1].shape[1] == 18
+    ll18 = O.kf(ssm, g["y"], True)[2]
+    assert abs(ll18 - float(g["co2_d18/ll"])) < 1e-9 * abs(float(g["co2_d18/ll"]))
