@@ -202,6 +202,26 @@ def hmc(gp, priors=None, fixed=(), n_samples=1000, n_burnin=100, step_size=0.01,
 
 
 # ---- drivers ---------------------------------------------------------------------------------------------
+def run_chain(gp, mcmc="HMC", priors=None, fixed=(), n_samples=1000, n_burnin=100, step_size=0.01, n_leapfrogs=10,
+              seed=31415):
+    """The sampler choice of the reference's mcmc scripts (experiments/common.py:95-117: HMC, MALA or NUTS) over this
+    module's posterior; returns constrained samples of ALL parameters (n_samples, P) and a diagnostic (acceptance
+    rate; mean tree depth for NUTS)."""
+    from .toy import mala_chain, nuts_chain
+    mcmc = getattr(mcmc, "value", mcmc).upper()
+    if mcmc == "HMC":
+        return hmc(gp, priors, fixed, n_samples, n_burnin, step_size, n_leapfrogs, seed)
+    post = Posterior(gp, priors, fixed)
+    rng = np.random.RandomState(seed)
+    if mcmc == "MALA":
+        us, diag = mala_chain(post, post.u0(), n_samples, n_burnin, step_size, rng)
+    elif mcmc == "NUTS":
+        us, diag = nuts_chain(post, post.u0(), n_samples, n_burnin, step_size, rng)
+    else:
+        raise ValueError(f"sampler {mcmc!r}: HMC, MALA or NUTS")
+    return np.array([post.set(u) for u in us]), diag
+
+
 def sunspot_map(data_dir, n_training=3200, noise_variance=10., n_interp_factor=30, maxiter=100):
     """sunspot/map.py: MAP fit of the Matern-3/2 model on the last n_training months, then predict_f on
     n_training * 30 interpolation times."""
@@ -219,12 +239,12 @@ def sunspot_map(data_dir, n_training=3200, noise_variance=10., n_interp_factor=3
 
 
 def co2_hmc(data_dir, n_training=3192, qp_order=3, noise_variance=0.05, n_samples=1000, n_burnin=100, step_size=0.01,
-            n_leapfrogs=10):
+            n_leapfrogs=10, mcmc="HMC"):
     t, y = load_co2(data_dir, n_training)
     gp = StateSpaceGP((t, y), co2_covariance(qp_order), noise_variance, parallel=True)
     priors, fixed = co2_setup(gp)
     tic = time.perf_counter()
-    samples, acc = hmc(gp, priors, fixed, n_samples, n_burnin, step_size, n_leapfrogs)
+    samples, acc = run_chain(gp, mcmc, priors, fixed, n_samples, n_burnin, step_size, n_leapfrogs)
     names = [f"{type(o).__name__}.{n}" for o, n in gp.trainable_parameters()]
     return dict(n_training=int(t.shape[0]), qp_order=qp_order, state_dim=int(gp.kernel.get_sde().F.shape[0]),
                 seconds=round(time.perf_counter() - tic, 3), acceptance=acc, parameters=names,
@@ -246,12 +266,13 @@ def main(argv=None):
     c.add_argument("--n-samples", type=int, default=1000)
     c.add_argument("--n-burnin", type=int, default=100)
     c.add_argument("--step-size", type=float, default=0.01)
+    c.add_argument("--mcmc", default="HMC", choices=["HMC", "MALA", "NUTS"])
     args = ap.parse_args(argv)
     if args.cmd == "sunspot-map":
         print(json.dumps(sunspot_map(args.data_dir, args.n_training, args.noise_variance)))
     else:
         print(json.dumps(co2_hmc(args.data_dir, args.n_training, args.qp_order, args.noise_variance, args.n_samples,
-                                 args.n_burnin, args.step_size)))
+                                 args.n_burnin, args.step_size, mcmc=args.mcmc)))
 
 
 if __name__ == "__main__":

@@ -166,6 +166,8 @@ def test_sunspot_map_and_co2_hmc_on_synthetic_files(tmp_path):
     assert 0.0 < out["lengthscales"] < 100.0 and out["noise_variance"] > 0.0 and np.isfinite(out["max_std"])
     # CO2 kernel at order 1 (d = 10) on the general-LTI path: a few HMC iterations move, fixed parameters stay
     res = RD.co2_hmc(str(tmp_path), n_training=300, qp_order=1, n_samples=6, n_burnin=4, step_size=0.002)
+    nuts = RD.co2_hmc(str(tmp_path), n_training=300, qp_order=1, n_samples=4, n_burnin=2, step_size=0.002, mcmc="NUTS")
+    assert np.all(np.isfinite(nuts["posterior_mean"])) and 0 < nuts["acceptance"] <= 8     # (mean tree depth for NUTS)
     assert res["state_dim"] == 10 and len(res["posterior_mean"]) == 8
     assert res["posterior_mean"][0] == 1.0 and res["posterior_std"][0] == 0.0        # the period is not trained
     assert abs(res["posterior_mean"][7] - 0.05) < 1e-12 and all(np.isfinite(res["posterior_mean"]))
