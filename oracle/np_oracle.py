@@ -18,6 +18,9 @@ vectors for this path.  What its tests *do* pin is
   (ii)  predict_f mean/var == dense GPR posterior (tests/test_gp_vs_kfs.py:80-99),
   (iii) known-answer SDE constants (tests/test_rbf.py:27-39,
         tests/test_periodic.py:32-50).
+  (iv)  the parameters its own three models learn in notebooks/PSSGP101.ipynb cell 13
+        on notebooks/data/regression_1D.csv (7.96569 / 0.212416 / 0.00575949) -- the
+        reference-held numeric pin, reproduced in tests/test_reference_pin.py.
 `tests/test_oracle.py` re-runs (i)-(iii) against this file: the dense GP below is
 independent of every state-space routine, so agreement of `kf/ks` and `pkf/pks`
 with it to 1e-9 is the pin.  Third-party arithmetic restated from its published
