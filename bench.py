@@ -8,20 +8,32 @@ A "step" is one pass of the hot path over one series already resident in HBM:
 `pgps_pkfs_dev_f64` = k_filter_reduce + k_filter_apply + k_smoother_apply, producing the
 filtered and smoothed moments of every time step and the log-likelihood.
 
-Workload at N = 1: BASELINE.json configs[1] -- Matern-3/2 (state dim 2), 2^20 steps, fp64,
+Workload at N = 1: BASELINE.json configs[1] (c2) -- Matern-3/2 (state dim 2), 2^20 steps, fp64,
 irregular times, observations drawn from the model's own prior.
-At N > 1 the series is N * 2^20 steps long and rank r owns the contiguous segment
-[r * 2^20, (r+1) * 2^20) ("weak" scaling); the segments are stitched by two tiny all-gathers
-of segment totals over RCCL (pssgp/distributed.py).
+At N > 1: BASELINE.json configs[3] (c4) -- the same model over ONE series of 2^24 steps split into N
+contiguous segments, rank r owning [r * 2^24 / N, (r+1) * 2^24 / N) ("strong" scaling; `--scaling weak`
+keeps 2^20 steps per GPU instead).  The segments are stitched by two all-gathers of segment totals
+over RCCL, issued by libpgps itself on the context's stream (pgps_pkfs_seg_dev_f64; `--exchange torch`
+runs the older torch.distributed-hosted variant).
 
-PyTorch is plumbing here: device buffers, the stream handed to libpgps, torch.distributed.
+`python bench.py --gpus N` works unaided: without a launcher's WORLD_SIZE in the environment the parent
+-- before it imports torch or touches the GPU -- starts `python -m torch.distributed.run` with N fresh
+child processes and relays rank 0's JSON line.
+
+PyTorch is plumbing here: device buffers, the stream handed to libpgps, and (gloo, CPU) the rendezvous,
+the barrier and the max-over-ranks of the timing.
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL across processes: dmabuf IPC only on this driver
 
 # one host thread is all this benchmark needs: multi-threaded BLAS in the (untimed) data generation
 # burns the container's CPU quota and the throttling then lands inside the timed region
@@ -43,7 +55,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--log2n", type=int, default=20, help="log2 of the steps per GPU (default 20 = config c2)")
+    ap.add_argument("--log2n", type=int, default=0,
+                    help="log2 of the series length: of the WHOLE series with --scaling strong (default 24 = config c4), "
+                         "of the steps per GPU with --scaling weak and at one GPU (default 20 = config c2)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="auto = strong (one 2^24-step series split over the GPUs) when --gpus > 1")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "lib", "torch"],
+                    help="lib: RCCL communicator owned by the libpgps context, one call per pass (default); torch: the "
+                         "three library phases with torch.distributed collectives in between (--dist-backend)")
     ap.add_argument("--kernel", default="matern32",
                     choices=["matern32", "matern52", "rbf6", "matern12", "c5", "rbf15", "periodic10"])
     ap.add_argument("--family", type=int, default=0, help="0 auto, 1 lane-chunk, 2 wave-cooperative kernels")
@@ -55,16 +74,46 @@ def parse():
                          "resident ts/ys (discretisation inside the scan); fused-ll: log-likelihood only")
     ap.add_argument("--single-pass", type=int, default=-1,
                     help="single-pass (look-back) filter kernel: -1 auto, 0 off (three launches), 1 on")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="--exchange torch only: torch.distributed backend of the collectives (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-gpu0", action="store_true",
-                    help="dry run of the multi-rank path on a 1-GPU box: every rank uses GPU 0 (needs --dist-backend gloo)")
+                    help="dry run of the multi-rank path on a 1-GPU box: every rank uses GPU 0 (RCCL refuses two ranks on "
+                         "one device, so this implies --exchange torch --dist-backend gloo)")
     ap.add_argument("--force-segments", action="store_true",
                     help="run the multi-GPU segment protocol even at one GPU (measures its overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-every", type=int, default=8,
                     help="hipEvent-time every n-th launch of the dominant kernel inside the timed region")
     ap.add_argument("--nan-frac", type=float, default=0.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.scaling == "auto":
+        args.scaling = "strong" if args.gpus > 1 else "weak"
+    if args.log2n <= 0:
+        args.log2n = 24 if args.scaling == "strong" and args.gpus > 1 else 20
+    if args.all_on_gpu0:
+        args.exchange, args.dist_backend = "torch", "gloo"
+    if args.exchange == "auto":
+        args.exchange = "lib"
+    return args
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh ranks (nothing in THIS process has touched
+    torch or the GPU yet), relay rank 0's JSON line and the launcher's exit code."""
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    return proc.returncode if proc.returncode != 0 or lines else 1
 
 
 def make_kernel(name):
@@ -105,17 +154,32 @@ def sample_prior_observations(P0, Fs, Qs, H, R, rng):
 
 
 def dominant_symbol(slot, d, suf, family, world):
-    """The device function behind a timing slot (slots are named after the lane-chunk kernels): mirrors
+    """The device function(s) behind a timing slot (slots are named after the lane-chunk kernels): mirrors
     dispatch_scan in csrc/pgps_core.hip."""
-    smooth = slot == "k_smoother_apply"
+    rc_names = {"k_filter_reduce": "pgps::rc::rc_reduce1<{d}> + rc_ks_filter<{d}> levels", "k_filter_apply": "pgps::rc::rc_apply1<{d}, ...>",
+                "k_smoother_reduce": "pgps::rc::rc_ks_smoother<{d}> levels", "k_smoother_apply": "pgps::rc::rc_smooth1<{d}, false>"}
+    wc_names = {"k_filter_reduce": "pgps::wc::wc_reduce1/2 + wc_ks_filter levels", "k_filter_apply": "pgps::wc::wc_apply1",
+                "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels", "k_smoother_apply": "pgps::wc::wc_smooth1"}
     rc = suf == "f64" and 2 <= d <= 16 and (family == 3 or (family == 0 and (d >= 5 if world == 1 else d > 6)))
     if rc:
-        return f"pgps::rc::rc_smooth1<{d}, false>" if smooth else f"pgps::rc::rc_apply1<{d}, false>"
+        return rc_names[slot].format(d=d)
     if family == 2 or (family == 0 and d > 6):
-        if suf == "f32" and family == 0 and d <= 16 and world == 1:
-            return f"pgps::rc::rc_smooth1<{d}, false> (fp32 arrays widened)" if smooth else f"pgps::rc::rc_apply1<{d}, false>"
-        return "pgps::wc::wc_smooth1" if smooth else "pgps::wc::wc_apply1"
+        if suf == "f32" and family == 0 and d <= 16:
+            return rc_names[slot].format(d=d) + " (fp32 arrays widened to fp64)"
+        return wc_names[slot]
     return f"pgps::{slot}<{'double' if suf == 'f64' else 'float'}, {d}, ...>"
+
+
+def workload_name(args, d, suf, n_total, n_local, world):
+    tag = {("matern32", "f64", 20, 1): "c2: ", ("rbf6", "f32", 20, 1): "c3: ", ("c5", "f64", 20, 1): "c5: "}.get(
+        (args.kernel, suf, args.log2n, world), "")
+    if world > 1 and args.scaling == "strong" and (args.kernel, suf, args.log2n) == ("matern32", "f64", 24):
+        tag = "c4: "
+    if world > 1 and args.scaling == "strong":
+        return (f"{tag}{args.kernel} state-dim {d}, ONE series of N=2^{args.log2n} steps split into {world} contiguous "
+                f"segments of {n_local} (strong scaling), {suf}, irregular times, prior-sampled observations")
+    return (f"{tag}{args.kernel} state-dim {d}, N=2^{args.log2n} steps per GPU ({n_total} total), {suf}, irregular "
+            f"times, prior-sampled observations")
 
 
 def host_core_share():
@@ -138,8 +202,35 @@ def host_core_share():
     return max(1, min(n, 32))
 
 
+# compulsory bytes per time step of each launch slot at the reference's pkf / pks contract (w =
+# sizeof scalar): the filter's (3d^2+d+1)w belong to the Kalman pass (reads Fs, Qs, ys, writes fms, fPs), the smoother's
+# (4d^2+2d)w to the backward pass; the reduce pass re-reads Fs, Qs, ys -- (2d^2+1)w it has to touch, none of them part
+# of B_alg = (7d^2+3d+1)w (which is what `whole_path_frac` is measured against)
+SLOT_BYTES = {"k_filter_reduce": lambda d, w: (2 * d * d + 1) * w,
+              "k_filter_apply": lambda d, w: (3 * d * d + d + 1) * w,
+              "k_smoother_reduce": lambda d, w: (3 * d * d + d) * w,
+              "k_smoother_apply": lambda d, w: (4 * d * d + 2 * d) * w}
+SLOT_INDEX = {"k_filter_reduce": 0, "k_filter_apply": 1, "k_smoother_reduce": 2, "k_smoother_apply": 3}
+
+
+def committed_traffic(key, slot):
+    """HBM-side bytes per launch of `slot` for workload `key` from the newest committed PMC summary that has it
+    (profiles/r*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 * FETCH + WRITE)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                tj = json.load(fh)
+            if key in tj and slot in tj[key]:
+                return tj[key][slot]["traffic_bytes"], f"profiles/{os.path.basename(path)} (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     if os.environ.get("PGPS_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["PGPS_BENCH_WATCHDOG"]), exit=True)
@@ -151,28 +242,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" %
-                             (args.gpus, args.gpus))
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     if args.all_on_gpu0:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    use_lib_exchange = args.exchange == "lib"
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.dist_backend == "nccl":
+        if not use_lib_exchange and args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            # control plane only (rendezvous, barrier, max of the timings): CPU, never in the data path
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     dtype_np = np.float64 if args.dtype == "f64" else np.float32
     dtype_t = torch.float64 if args.dtype == "f64" else torch.float32
     suf = args.dtype
     w = 8 if suf == "f64" else 4
-    n_local = 1 << args.log2n
-    n_total = n_local * world
+    if args.scaling == "strong":
+        n_total = 1 << args.log2n
+        if n_total % world:
+            raise SystemExit(f"2^{args.log2n} steps do not split evenly over {world} GPUs")
+        n_local = n_total // world
+    else:
+        n_local = 1 << args.log2n
+        n_total = n_local * world
 
     # ---- model + synthetic series (seeded; identical on every rank, each keeps its segment) ----
     kern = make_kernel(args.kernel)
@@ -242,6 +338,22 @@ def main():
         def step():
             ctx.call(f"pgps_pkfs_dev_{suf}", ctypes.c_long(n_local), ctypes.c_int(d), P(P0_d), P(Fs_d), P(Qs_d),
                      P(H_d), real(noise), P(ys_d), P(fms), P(fPs), P(sms), P(sPs), P(ll_d))
+    elif use_lib_exchange:
+        # the product's multi-GPU path: the context owns the RCCL communicator, one library call per pass
+        from pssgp import distributed as pdist
+
+        def bcast(uid):
+            if world == 1:
+                return uid
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        seg = pdist.ShardedScan(ctx, pdist.share_unique_id(rank, broadcast=bcast), rank, world, d, dtype_np)
+        ptrs = [t.data_ptr() for t in (P0_d, Fs_d, Qs_d, H_d)] + [noise] + [t.data_ptr() for t in (ys_d, fms, fPs, sms, sPs, ll_d)]
+
+        def step():
+            seg.pkfs(n_local, *ptrs)
     else:
         from pssgp import distributed as pdist
         seg = pdist.SegmentScan(ctx, rank, world, d, dtype_np, torch_device=dev)
@@ -263,12 +375,22 @@ def main():
     for _ in range(min(args.warmup, 10)):
         step()
     torch.cuda.synchronize(dev)
-    dominant = "k_smoother_apply" if args.path != "fused-ll" else "k_filter_apply"
+    # which launch slot dominates a pass: measured (events around every launch of a short untimed run), not assumed
+    n_probe = max(3, min(args.warmup, 10))
+    ctx.profile_read(reset=True)
+    ctx.profile_sample(1)
+    ctx.profile_enable(0x0f)
+    for _ in range(n_probe):
+        step()
+    probe = ctx.profile_read(reset=True)
+    ctx.profile_enable(0)
+    per_pass = {k: v[0] / n_probe for k, v in probe.items() if v[1] and k in SLOT_BYTES}
+    dominant = max(per_pass, key=per_pass.get) if per_pass else "k_smoother_apply"
     empty_pair_ms = ctx.profile_calibrate()
     ctx.profile_read(reset=True)
     ctx.profile_sample(args.event_every)
-    dom_slot = 3 if dominant == "k_smoother_apply" else 1
-    ctx.profile_enable((1 << dom_slot) if args.event_every > 0 else 0)   # time the dominant kernel's launches
+    dom_slot = SLOT_INDEX[dominant]
+    ctx.profile_enable((1 << dom_slot) if args.event_every > 0 else 0)   # time the dominant slot's launches
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize(dev)
@@ -288,14 +410,16 @@ def main():
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(0)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        tmax = torch.tensor([elapsed, gpu_ms], dtype=torch.float64,
+                            device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, gpu_ms = float(tmax[0].item()), float(tmax[1].item())
 
     # per-kernel breakdown (separate, untimed loop with events around every launch)
     ctx.profile_sample(1)
     ctx.profile_enable(0x3f)
-    for _ in range(min(args.steps, 50)):
+    n_break = min(args.steps, 50)
+    for _ in range(n_break):
         step()
     breakdown = ctx.profile_read(reset=True)
     ctx.profile_enable(0)
@@ -304,24 +428,22 @@ def main():
 
     # ---- roofline of the dominant kernel -----------------------------------------------------
     dom_ms, dom_n = prof[dominant]
+    if not dom_n:                                          # --event-every 0: fall back to the breakdown loop's timing
+        dom_ms, dom_n = breakdown[dominant]
     # the events are stamped by hipExtLaunchKernelGGL with the dispatch's own start / end timestamps
-    # (the clock rocprofv3's kernel trace reads), so no event-packet overhead is included
+    # (the clock rocprofv3's kernel trace reads), so no event-packet overhead is included.  A slot of the row- /
+    # wave-cooperative families can hold several launches per pass (the Kogge-Stone levels sit in the reduce slots);
+    # the two slots that can dominate there, k_filter_apply and k_smoother_apply, are one launch per pass
     dom_raw_ms = dom_ms / max(dom_n, 1)
     dom_avg_s = max(dom_raw_ms, 1e-9) * 1e-3
-    dom_bytes = (4 * d * d + 2 * d) * w * n_local          # smoother: reads Fs,Qs,fms,fPs; writes sms,sPs
+    dom_bytes = SLOT_BYTES[dominant](d, w) * n_local
     achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     alg_bytes_step = (7 * d * d + 3 * d + 1) * w
     # HBM-side bytes per launch of the dominant kernel from the committed PMC profile of this workload
     traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            tj = json.load(fh)
-        key = f"{args.kernel}_{suf}_log2n{args.log2n}"
-        if world == 1 and key in tj and not args.chunk and args.stage < 0 and args.family == 0:
-            traffic = tj[key][dominant]["traffic_bytes"]
-            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE)"
-    except Exception:
-        pass
+    if world == 1 and not args.chunk and args.stage < 0 and args.family == 0 and args.path == "lgssm":
+        traffic, traffic_src = committed_traffic(f"{args.kernel}_{suf}_log2n{args.log2n}", dominant)
+    whole_gbps = alg_bytes_step * n_total * args.steps / (gpu_ms * 1e-3) / 1e9 / world     # per GPU
 
     out = {
         "metric": "timesteps/sec (filter+smooth+log-lik)",
@@ -332,23 +454,31 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": suf,
         "data": "synthetic",
         "path": args.path,
-        "config": {"workload": f"{args.kernel} state-dim {d}, N=2^{args.log2n} steps per GPU "
-                               f"({n_total} total), {suf}, irregular times, prior-sampled observations",
-                   "steps_per_gpu": n_local, "state_dim": d,
-                   "parallelism": "1 GPU" if world == 1 else f"{world} contiguous time segments, 2 RCCL all-gathers"},
+        "config": {"workload": workload_name(args, d, suf, n_total, n_local, world),
+                   "steps_per_gpu": n_local, "steps_total": n_total, "state_dim": d,
+                   "parallelism": "1 GPU" if world == 1 else
+                   f"{world} contiguous time segments, 2 all-gathers of segment totals per pass ("
+                   + ("RCCL ncclAllGather issued by libpgps on the context's stream" if use_lib_exchange
+                      else f"torch.distributed {args.dist_backend}") + ")"},
         "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": dominant_symbol(dominant, d, suf, args.family, world),
                      "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_avg_s * 1e3,
-                     "launches_timed": dom_n, "empty_event_pair_ms": empty_pair_ms},
+                     "launches_timed": dom_n, "empty_event_pair_ms": empty_pair_ms,
+                     "dominant_by": {k: round(v, 6) for k, v in per_pass.items()},
+                     # the whole pass against its algorithmic bytes B_alg = (7d^2+3d+1)w per step, per GPU,
+                     # from the GPU-event time of the timed region
+                     "whole_path_GBps": whole_gbps, "whole_path_frac": whole_gbps / HBM_PEAK_GBPS,
+                     "algorithmic_bytes_per_step": alg_bytes_step},
         "whole_path_effective_GBps": alg_bytes_step * n_total * args.steps / elapsed / 1e9,
         "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in breakdown.items() if v[1]},
+        "kernel_ms_per_pass": {k: v[0] / n_break for k, v in breakdown.items() if v[1]},
         "host_enqueue_ms_per_step": (t_enq - t0) / args.steps * 1e3,
         "gpu_event_ms_per_step": gpu_ms / args.steps,
         "log_likelihood": ll_val,
@@ -512,6 +642,8 @@ def main():
                 "smoothed_cov_rel": float(np.max(np.abs(sPs.cpu().numpy() - csP)) / np.max(np.abs(csP)))})
     if rank == 0:
         print(json.dumps(out))
+    if use_lib_exchange and (world > 1 or args.force_segments) and args.path == "lgssm":
+        seg.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -17,8 +17,10 @@
  *   - return value 0 = PGPS_OK, negative = error (pgps_strerror); nothing throws across the
  *     ABI; outputs are undefined after an error.
  *   - one call in flight per context; contexts are independent (one per GPU / per thread).
- *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels, up to PGPS_MAX_DIM the
- *     wave-cooperative ones (pkf, pkfs; stand-alone pks, discretise and the segment calls: d <= 6).
+ *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels (one lane owns whole d x d operands), fp64
+ *     series with 5 <= d <= 16 the row-cooperative ones (fp32 at 5 <= d <= 8 has its own row-cooperative kernels, fp32
+ *     at 9..16 is widened to fp64 for them), up to PGPS_MAX_DIM the wave-cooperative ones; pgps_set_family overrides.
+ *     Every call takes every d <= PGPS_MAX_DIM except the segment calls (pgps_seg_*, pgps_pkfs_seg_*): d <= 16.
  *   - NaN in `ys` marks a missing observation (parallel.py:42,86-95).
  */
 #ifndef PGPS_H_
@@ -38,6 +40,7 @@ extern "C" {
 #define PGPS_E_NOMEM (-4)           /* device or host allocation failed */
 #define PGPS_E_NUMERIC (-5)         /* non-finite result (reference: TF raises on CPU, NaNs on GPU) */
 #define PGPS_E_NO_DEVICE (-6)       /* no HIP device visible */
+#define PGPS_E_COMM (-7)            /* an RCCL call failed (pgps_last_hip_error carries RCCL's message) */
 
 #define PGPS_MAX_DIM_LANE 6   /* lane-chunk kernels: one lane holds whole d x d operands */
 #define PGPS_MAX_DIM 32       /* wave-cooperative kernels: operands in LDS, 64 lanes share each operation */
@@ -295,6 +298,35 @@ int pgps_seg_smoother_apply_dev_f64(pgps_ctx*, long N, int d, int rank, int nran
 int pgps_seg_smoother_apply_dev_f32(pgps_ctx*, long N, int d, int rank, int nranks, const float* Fs,
                                     const float* Qs, const float* fms, const float* fPs, const float* gathered_s,
                                     float* sms, float* sPs, double* ll);
+
+/* The three calls of a pass keep state in the context's scratch between them (chain totals, their scans, for
+ * d > 6 the stored smoothing elements): no other call on the same context, and no pgps_set_chunk, may come between
+ * phase 1 and phase 3 of a pass.  The library checks it -- a phase whose predecessor was not the previous call on the
+ * context with the same (N, d, rank, nranks) returns PGPS_E_INVALID instead of reading stale scratch. */
+
+/* ---- the same pass with the exchange inside the library: RCCL over xGMI ----------------------------
+ * The context owns the communicator (one process per GPU, one context per process).
+ *   rank 0:      pgps_comm_get_unique_id(id)   -> hand the PGPS_COMM_ID_BYTES bytes to every rank (any transport)
+ *   every rank:  pgps_comm_init(ctx, id, rank, nranks)        (collective: returns when all ranks have joined)
+ *   every rank:  pgps_pkfs_seg_dev_*(ctx, N_local, d, ...)    per pass, as often as wanted
+ *   every rank:  pgps_comm_destroy(ctx)                       (pgps_destroy does it too)
+ * pgps_pkfs_seg_dev_* = pkfs (pssgp/kalman/parallel.py:199-201) + log-likelihood for the segment [rank's steps] of a
+ * series sharded over the communicator's ranks in rank order: reduce -> ncclAllGather (segment totals + first-step
+ * halo, (3d^2+3d+d(d+1)) scalars per rank) -> filter -> ncclAllGather (smoothing totals + log-likelihood partial) ->
+ * smoother, ALL enqueued on the context's stream: no host synchronisation, no framework.  Arguments as
+ * pgps_pkfs_dev_* with this rank's arrays; P0 is the prior of the WHOLE series (used by rank 0), ll receives the
+ * log-likelihood of the whole series on every rank.  d <= 16 (fp32: 7 <= d <= 16 computes in fp64).  nranks = 1 works
+ * (RCCL copies locally).  pgps_comm_allgather_dev is the bare collective on the context's stream (bytes per rank). */
+#define PGPS_COMM_ID_BYTES 128
+int pgps_comm_get_unique_id(void* id);
+int pgps_comm_init(pgps_ctx* ctx, const void* id, int rank, int nranks);
+int pgps_comm_destroy(pgps_ctx* ctx);
+int pgps_comm_info(pgps_ctx* ctx, int* rank, int* nranks);      /* nranks = 0: no communicator */
+int pgps_comm_allgather_dev(pgps_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
+int pgps_pkfs_seg_dev_f64(pgps_ctx*, long N, int d, const double* P0, const double* Fs, const double* Qs, const double* H,
+                          double R, const double* ys, double* fms, double* fPs, double* sms, double* sPs, double* ll);
+int pgps_pkfs_seg_dev_f32(pgps_ctx*, long N, int d, const float* P0, const float* Fs, const float* Qs, const float* H,
+                          float R, const float* ys, float* fms, float* fPs, float* sms, float* sPs, double* ll);
 
 /* ---- sequential mode: pssgp/kalman/sequential.py:11-73 (kf, ks) ------------------------
  * StateSpaceGP(parallel=False).  Host arithmetic on HOST pointers, as in the reference (its

@@ -15,6 +15,7 @@ using namespace pgps;
 
 namespace pgps {
 int ensure(pgps_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (&b == &ctx->ws) ++ctx->ws_epoch;            // somebody is about to lay the scratch out (again)
     if (bytes <= b.cap) return PGPS_OK;
     if (b.p) HIPCHK(ctx, hipFree(b.p));
     b.p = nullptr;
@@ -42,6 +43,7 @@ extern "C" const char* pgps_strerror(int code) {
         case PGPS_E_NOMEM: return "out of memory";
         case PGPS_E_NUMERIC: return "non-finite result";
         case PGPS_E_NO_DEVICE: return "no HIP device";
+        case PGPS_E_COMM: return "RCCL communicator error (pgps_last_hip_error)";
         default: return "unknown error";
     }
 }
@@ -83,6 +85,8 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
     if (!ctx) return PGPS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)pgps_comm_destroy(ctx);
+    if (ctx->comm_buf.p) (void)hipFree(ctx->comm_buf.p);
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
     if (ctx->stamps.p) (void)hipFree(ctx->stamps.p);
     if (ctx->status_word) (void)hipFree(ctx->status_word);
@@ -666,6 +670,18 @@ static int seg_common(pgps_ctx* ctx, long N, int d, int rank, int nranks, ScanAr
     return PGPS_OK;
 }
 
+// Phase `phase` (2, 3) may only follow phase - 1 of the same pass with nothing else on the context in between: the
+// scratch it reads (chain totals, their scans, stored smoothing elements) is whatever the last call left in `ws`.
+static bool seg_follows(const pgps_ctx* ctx, int phase, long N, int d, int rank, int nranks) {
+    const auto& t = ctx->seg_tag;
+    return t.phase == phase - 1 && t.N == N && t.d == d && t.rank == rank && t.nranks == nranks && t.chunk == ctx->chunk &&
+           t.epoch == ctx->ws_epoch;
+}
+static void seg_mark(pgps_ctx* ctx, int phase, long N, int d, int rank, int nranks) {
+    ctx->seg_tag.phase = phase; ctx->seg_tag.N = N; ctx->seg_tag.d = d; ctx->seg_tag.rank = rank;
+    ctx->seg_tag.nranks = nranks; ctx->seg_tag.chunk = ctx->chunk; ctx->seg_tag.epoch = ctx->ws_epoch;
+}
+
 template <typename T>
 static int seg_reduce(pgps_ctx* ctx, long N, int d, int rank, int nranks, const T* P0, const T* Fs, const T* Qs,
                       const T* H, T R, const T* ys, T* rec_f) {
@@ -673,7 +689,10 @@ static int seg_reduce(pgps_ctx* ctx, long N, int d, int rank, int nranks, const 
     TRY(seg_common<T>(ctx, N, d, rank, nranks, a));
     if (!P0 || !Fs || !Qs || !H || !ys || !rec_f || !aligned16(Fs) || !aligned16(Qs)) return PGPS_E_INVALID;
     a.P0 = P0; a.H = H; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys; a.rec_f = rec_f;
-    return dispatch_scan<T>(ctx, d, a, MODE_SEG_REDUCE);
+    ctx->seg_tag.phase = 0;
+    TRY(dispatch_scan<T>(ctx, d, a, MODE_SEG_REDUCE));
+    seg_mark(ctx, 1, N, d, rank, nranks);
+    return PGPS_OK;
 }
 
 template <typename T>
@@ -686,7 +705,11 @@ static int seg_filter(pgps_ctx* ctx, long N, int d, int rank, int nranks, const 
         return PGPS_E_INVALID;
     a.P0 = P0; a.H = H; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys;
     a.gathered_f = gathered_f; a.fms = fms; a.fPs = fPs; a.rec_s = rec_s;
-    return dispatch_scan<T>(ctx, d, a, MODE_SEG_FILTER);
+    if (!seg_follows(ctx, 2, N, d, rank, nranks)) return PGPS_E_INVALID;
+    ctx->seg_tag.phase = 0;
+    TRY(dispatch_scan<T>(ctx, d, a, MODE_SEG_FILTER));
+    seg_mark(ctx, 2, N, d, rank, nranks);
+    return PGPS_OK;
 }
 
 template <typename T>
@@ -700,6 +723,8 @@ static int seg_smoother(pgps_ctx* ctx, long N, int d, int rank, int nranks, cons
         return PGPS_E_INVALID;
     a.Fs = Fs; a.Qs = Qs; a.fms = const_cast<T*>(fms); a.fPs = const_cast<T*>(fPs);
     a.gathered_s = gathered_s; a.sms = sms; a.sPs = sPs; a.ll = ll;
+    if (!seg_follows(ctx, 3, N, d, rank, nranks)) return PGPS_E_INVALID;
+    ctx->seg_tag.phase = 0;
     return dispatch_scan<T>(ctx, d, a, MODE_SEG_SMOOTHER);
 }
 
@@ -722,6 +747,72 @@ static int seg_smoother(pgps_ctx* ctx, long N, int d, int rank, int nranks, cons
 
 PGPS_DEFINE_SEG(f64, double)
 PGPS_DEFINE_SEG(f32, float)
+
+// One call per pass: reduce -> all-gather -> filter -> all-gather -> smoother, all enqueued on the context's stream
+// through the context's own RCCL communicator -- no host round trip, no framework in between.
+template <typename T>
+static int pkfs_seg_run(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R, const T* ys,
+                        T* fms, T* fPs, T* sms, T* sPs, double* ll) {
+    const int rank = ctx->comm_rank, nranks = ctx->comm_nranks;
+    const size_t rf = ((size_t)seg_rec_f_len(d) * sizeof(T) + 15) / 16 * 16, rs = ((size_t)seg_rec_s_len(d) * sizeof(T) + 15) / 16 * 16;
+    TRY(ensure(ctx, ctx->comm_buf, (rf + rs) * (size_t)(nranks + 1)));
+    char* base = (char*)ctx->comm_buf.p;
+    T* rec_f = (T*)base;
+    T* rec_s = (T*)(base + rf);
+    T* gat_f = (T*)(base + rf + rs);
+    T* gat_s = (T*)(base + rf + rs + rf * (size_t)nranks);
+    // records travel at their natural length (the ranks' slots in gathered_* are seg_rec_*_len(d) apart)
+    TRY(seg_reduce<T>(ctx, N, d, rank, nranks, P0, Fs, Qs, H, R, ys, rec_f));
+    TRY(comm_allgather(ctx, rec_f, gat_f, (size_t)seg_rec_f_len(d) * sizeof(T)));
+    TRY(seg_filter<T>(ctx, N, d, rank, nranks, P0, Fs, Qs, H, R, ys, gat_f, fms, fPs, rec_s));
+    TRY(comm_allgather(ctx, rec_s, gat_s, (size_t)seg_rec_s_len(d) * sizeof(T)));
+    return seg_smoother<T>(ctx, N, d, rank, nranks, Fs, Qs, fms, fPs, gat_s, sms, sPs, ll);
+}
+
+template <typename T>
+static int pkfs_seg_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R, const T* ys,
+                        T* fms, T* fPs, T* sms, T* sPs, double* ll) {
+    if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
+    if (!ctx->comm) return PGPS_E_INVALID;                      // pgps_comm_init first (also for one rank)
+    if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
+    if constexpr (sizeof(T) == 4) {
+        if (ctx->family == 0 && d > PGPS_MAX_DIM_LANE && d <= rc::kDimMax) {
+            // fp32 segments at 7 <= d <= 16: widened to fp64 scratch for the row-cooperative kernels (as the whole-series
+            // calls do, scan_f32_via_f64), fp64 records on the wire, results narrowed
+            const size_t n = (size_t)N, dd = (size_t)d * d;
+            TRY(ensure(ctx, ctx->lti[6], (dd + d + 2 * n * dd + n + 2 * (n * d + n * dd)) * sizeof(double)));
+            double* b = (double*)ctx->lti[6].p;
+            double *P064 = b, *H64 = P064 + dd, *Fs64 = H64 + d, *Qs64 = Fs64 + n * dd, *ys64 = Qs64 + n * dd, *fm = ys64 + n,
+                   *fP = fm + n * d, *sm = fP + n * dd, *sP = sm + n * d;
+            auto grid = [](size_t m) { return dim3((unsigned)std::min<size_t>(4096, (m + 255) / 256)); };
+            auto widen = [&](const float* in, double* out, size_t m) {
+                hipLaunchKernelGGL(pgps::k_widen, grid(m), dim3(256), 0, ctx->stream, (long)m, in, out);
+            };
+            auto narrow = [&](const double* in, float* out, size_t m) {
+                hipLaunchKernelGGL(pgps::k_narrow, grid(m), dim3(256), 0, ctx->stream, (long)m, in, out);
+            };
+            widen((const float*)P0, P064, dd); widen((const float*)H, H64, d); widen((const float*)Fs, Fs64, n * dd);
+            widen((const float*)Qs, Qs64, n * dd); widen((const float*)ys, ys64, n);
+            TRY(pkfs_seg_run<double>(ctx, N, d, P064, Fs64, Qs64, H64, (double)R, ys64, fm, fP, sm, sP, ll));
+            narrow(fm, (float*)fms, n * d); narrow(fP, (float*)fPs, n * dd);
+            narrow(sm, (float*)sms, n * d); narrow(sP, (float*)sPs, n * dd);
+            HIPCHK(ctx, hipGetLastError());
+            return PGPS_OK;
+        }
+    }
+    return pkfs_seg_run<T>(ctx, N, d, P0, Fs, Qs, H, R, ys, fms, fPs, sms, sPs, ll);
+}
+
+extern "C" int pgps_pkfs_seg_dev_f64(pgps_ctx* c, long N, int d, const double* P0, const double* Fs, const double* Qs,
+                                     const double* H, double R, const double* ys, double* fms, double* fPs, double* sms,
+                                     double* sPs, double* ll) {
+    return pkfs_seg_dev<double>(c, N, d, P0, Fs, Qs, H, R, ys, fms, fPs, sms, sPs, ll);
+}
+extern "C" int pgps_pkfs_seg_dev_f32(pgps_ctx* c, long N, int d, const float* P0, const float* Fs, const float* Qs,
+                                     const float* H, float R, const float* ys, float* fms, float* fPs, float* sms, float* sPs,
+                                     double* ll) {
+    return pkfs_seg_dev<float>(c, N, d, P0, Fs, Qs, H, R, ys, fms, fPs, sms, sPs, ll);
+}
 
 // ---------------------------------------------------------------------------------------------
 // fused-discretisation ("gp") entry points

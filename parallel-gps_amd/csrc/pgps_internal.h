@@ -32,6 +32,13 @@ struct pgps_ctx {
     DevBuf lti[12];                     // general-LTI entry points: model, merged series, Fs, Qs, E, g (d > 16: moments)
     DevBuf stamps;                      // diagnostic build only
     int* status_word = nullptr;         // device word kernels raise flags in (pgps_status)
+    void* comm = nullptr;               // ncclComm_t (RCCL) of a series sharded over GPUs: pgps_comm_init (pgps_comm.hip)
+    int comm_rank = 0, comm_nranks = 0;
+    DevBuf comm_buf;                    // [rec_f | rec_s | gathered_f | gathered_s] of pgps_pkfs_seg_dev_*
+    // the three-phase segment protocol keeps state in `ws` between its calls: what the last phase left, and the
+    // workspace epoch (bumped by every call that carves `ws`) it left it at
+    struct SegTag { int phase = 0; long N = 0; int d = 0, rank = 0, nranks = 0, chunk = 0; unsigned long epoch = 0; } seg_tag;
+    unsigned long ws_epoch = 0;
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
     int prof_every = 1;                 // time every n-th launch of an enabled slot
     long prof_seen[PGPS_K_COUNT] = {0};
@@ -61,6 +68,8 @@ constexpr int kWave = 64;
 constexpr int kWaves = kBlock / kWave;
 
 int ensure(pgps_ctx* ctx, DevBuf& b, size_t bytes);
+// all-gather of `bytes` per rank on the context's stream through the context's RCCL communicator (pgps_comm.hip)
+int comm_allgather(pgps_ctx* ctx, const void* send, void* recv, size_t bytes);
 int prof_flush(pgps_ctx* ctx);
 void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks);
 

@@ -13,6 +13,7 @@ _LIB_PATH = os.environ.get("PGPS_LIB", os.path.join(_HERE, "libpgps.so"))
 
 PGPS_OK = 0
 PGPS_K_NAMES = None
+COMM_ID_BYTES = 128             # PGPS_COMM_ID_BYTES
 
 c_void_p, c_int, c_long, c_double, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long,
                                               ctypes.c_double, ctypes.c_float)
@@ -58,6 +59,11 @@ def _declare(lib):
     lib.pgps_profile_calibrate.argtypes = [P, ctypes.POINTER(c_double)]
     lib.pgps_profile_read.argtypes = [P, ctypes.POINTER(c_double), ctypes.POINTER(c_long), c_int]
     lib.pgps_seg_record_len.argtypes = [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    lib.pgps_comm_get_unique_id.argtypes = [P]
+    lib.pgps_comm_init.argtypes = [P, P, c_int, c_int]
+    lib.pgps_comm_destroy.argtypes = [P]
+    lib.pgps_comm_info.argtypes = [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    lib.pgps_comm_allgather_dev.argtypes = [P, P, P, ctypes.c_size_t]
     for suf, real in (("f64", c_double), ("f32", c_float)):
         for dev in ("", "_dev"):
             getattr(lib, f"pgps_discretise{dev}_{suf}").argtypes = [P, c_long, c_int, P, P, P, real, P, P]
@@ -73,6 +79,7 @@ def _declare(lib):
                                                                      P, P, P, P, P]
         getattr(lib, f"pgps_seg_smoother_apply_dev_{suf}").argtypes = [P, c_long, c_int, c_int, c_int, P, P, P, P, P,
                                                                        P, P, P]
+        getattr(lib, f"pgps_pkfs_seg_dev_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, real, P, P, P, P, P, P]
     return lib
 
 
@@ -92,14 +99,20 @@ def check(ctx, code, what):
     if code != PGPS_OK:
         lib = load_library()
         msg = lib.pgps_strerror(code).decode()
-        detail = lib.pgps_last_hip_error(ctx.handle).decode() if ctx is not None and code == -3 else ""
+        detail = lib.pgps_last_hip_error(ctx.handle).decode() if ctx is not None and code in (-3, -7) else ""
         raise PgpsError(code, f"{what}: {msg}", detail)
 
 
 class Context:
-    """One libpgps context = one GPU + one stream + scratch.  Not thread-safe per instance."""
+    """One libpgps context = one GPU + one stream + scratch (+ the RCCL communicator of a sharded series).
+
+    libpgps allows one call in flight per context (include/pgps.h); `lock` (re-entrant) serialises the calls made
+    through this object, so Python threads that share a context -- e.g. parallel MCMC chains on the default
+    context of `get_context` -- take turns instead of racing on its scratch.  Multi-call sequences that keep state
+    in the context (LtiLlStream, the three-phase segment protocol) hold the lock for their whole duration."""
 
     def __init__(self, device=0):
+        self.lock = threading.RLock()
         self.lib = load_library()
         n = c_int(0)
         self.lib.pgps_device_count(ctypes.byref(n))
@@ -113,8 +126,9 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
-            self.lib.pgps_destroy(self.handle)
-            self.handle = c_void_p()
+            with self.lock:
+                self.lib.pgps_destroy(self.handle)
+                self.handle = c_void_p()
 
     def __del__(self):
         try:
@@ -183,25 +197,57 @@ class Context:
     # -- raw device memory -----------------------------------------------------------------
     def malloc(self, nbytes):
         p = c_void_p()
-        check(self, self.lib.pgps_malloc(self.handle, int(nbytes), ctypes.byref(p)), "pgps_malloc")
+        with self.lock:
+            check(self, self.lib.pgps_malloc(self.handle, int(nbytes), ctypes.byref(p)), "pgps_malloc")
         return p.value
 
     def free(self, ptr):
-        check(self, self.lib.pgps_free(self.handle, c_void_p(ptr)), "pgps_free")
+        with self.lock:
+            check(self, self.lib.pgps_free(self.handle, c_void_p(ptr)), "pgps_free")
 
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
-        check(self, self.lib.pgps_memcpy_h2d(self.handle, c_void_p(dptr), arr.ctypes.data_as(c_void_p), arr.nbytes),
-              "pgps_memcpy_h2d")
+        with self.lock:
+            check(self, self.lib.pgps_memcpy_h2d(self.handle, c_void_p(dptr), arr.ctypes.data_as(c_void_p), arr.nbytes),
+                  "pgps_memcpy_h2d")
 
     def d2h(self, arr, dptr):
         assert arr.flags["C_CONTIGUOUS"]
-        check(self, self.lib.pgps_memcpy_d2h(self.handle, arr.ctypes.data_as(c_void_p), c_void_p(dptr), arr.nbytes),
-              "pgps_memcpy_d2h")
+        with self.lock:
+            check(self, self.lib.pgps_memcpy_d2h(self.handle, arr.ctypes.data_as(c_void_p), c_void_p(dptr), arr.nbytes),
+                  "pgps_memcpy_d2h")
+
+    # -- the communicator of a series sharded over GPUs (RCCL, owned by the context) -------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from one rank, to be handed to every rank's comm_init (any transport: a file, MPI, a
+        torch.distributed / TCP store ...)."""
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        code = load_library().pgps_comm_get_unique_id(buf)
+        if code != PGPS_OK:
+            raise PgpsError(code, "pgps_comm_get_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique id must be {COMM_ID_BYTES} bytes")
+        with self.lock:
+            check(self, self.lib.pgps_comm_init(self.handle, ctypes.c_char_p(bytes(unique_id)), int(rank), int(nranks)),
+                  "pgps_comm_init")
+
+    def comm_destroy(self):
+        with self.lock:
+            check(self, self.lib.pgps_comm_destroy(self.handle), "pgps_comm_destroy")
+
+    def comm_info(self):
+        r, n = c_int(0), c_int(0)
+        check(self, self.lib.pgps_comm_info(self.handle, ctypes.byref(r), ctypes.byref(n)), "pgps_comm_info")
+        return r.value, n.value
 
     # -- generic call by name ----------------------------------------------------------------
     def call(self, name, *args):
-        check(self, getattr(self.lib, name)(self.handle, *args), name)
+        with self.lock:
+            check(self, getattr(self.lib, name)(self.handle, *args), name)
 
 
 _contexts = {}
@@ -463,6 +509,8 @@ class LtiLlStream:
             raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
         self.n, self.t0, self.capacity, self.count = ts_a.shape[0], float(t0), int(capacity), 0
         self.d_ts = self.d_ys = self.d_ll = None
+        self.ctx.lock.acquire()             # the context is this stream's until close(): its scratch carries the
+        self._locked = True                 # asynchronous evaluations (one call in flight per context, pgps.h)
         try:
             self.d_ts = self.ctx.malloc(ts_a.nbytes)
             self.d_ys = self.ctx.malloc(ys_a.nbytes)
@@ -497,6 +545,9 @@ class LtiLlStream:
             if p:
                 self.ctx.free(p)
             setattr(self, name, None)
+        if getattr(self, "_locked", False):
+            self._locked = False
+            self.ctx.lock.release()
 
 
 def lti_ll_batch(models, ts, ys, t0=0.0, device=0):

@@ -423,6 +423,58 @@ def test_two_host_threads_with_their_own_contexts():
     assert relerr(want[1][0], os_) < 1e-9 and relerr(want[1][1], osP) < 1e-9
 
 
+def test_two_host_threads_on_the_shared_default_context():
+    """Two Python threads evaluating models through the module-level wrappers share ONE context per device
+    (`_backend.get_context`) -- parallel MCMC chains in the reference's drivers do exactly that under TensorFlow.  ctypes
+    releases the GIL, libpgps allows one call in flight per context: the context's lock makes the threads take turns.
+    Different workloads (fused Matern path, general-LTI path, array path) hammer the shared scratch; every result must
+    equal the single-threaded one bit for bit."""
+    import threading
+    from pssgp.kernels import Matern32, Matern52, RBF
+    from pssgp.model import StateSpaceGP
+    from pssgp.kalman.parallel import pkfs
+    rng = np.random.default_rng(8)
+    models = []
+    for i, k in enumerate([Matern32(1.3, 0.7), RBF(1., 0.8, order=6, balancing_iter=10), Matern52(0.9, 1.1)]):
+        t = make_times(20011 + 977 * i, seed=60 + i)
+        y = np.sin(t) + 0.3 * rng.standard_normal(t.size)
+        models.append(StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=0.2, parallel=True))
+    ta = make_times(9001, seed=70)
+    ssm = O.get_ssm(Matern32(1., 1.).get_sde(), ta, 0.1)
+    ya = sample_series(ssm, seed=70, nan_frac=0.1)
+
+    def job(i):
+        if i < 3:
+            m = models[i]
+            tq = np.linspace(0.1, float(m.data[0][-1, 0]), 501)[:, None]
+            mean, var = m.predict_f(tq)
+            return float(m.maximum_log_likelihood_objective()), mean.copy(), var.copy()
+        sms, sPs = pkfs(ssm, ya)
+        return 0.0, np.asarray(sms).copy(), np.asarray(sPs).copy()
+
+    want = [job(i) for i in range(4)]
+    errors = []
+
+    def worker(w):
+        try:
+            for rep in range(12):
+                for i in ((0, 1, 2, 3) if w == 0 else (3, 2, 1, 0)):
+                    got = job(i)
+                    if not (got[0] == want[i][0] and np.array_equal(got[1], want[i][1]) and np.array_equal(got[2], want[i][2])):
+                        errors.append(f"thread {w}, job {i}, repetition {rep}: result changed under concurrency")
+                        return
+        except Exception as e:                             # noqa: BLE001
+            errors.append(f"thread {w}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in threads), "a worker did not finish"
+    assert not errors, errors
+
+
 def test_error_codes_across_the_abi():
     """Errors are return codes, never exceptions or faults (include/pgps.h; the reference raises
     InvalidArgumentError from TensorFlow): bad sizes, unsupported state dimensions, null and misaligned pointers, a

@@ -385,3 +385,105 @@ def test_config_c4_scale_eight_segments_on_one_gpu():
                 if isinstance(v, _Dev):
                     v.free()
             k["ctx"].close()
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the exchange inside libpgps (the context owns the RCCL communicator)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,kname", [(np.float64, None), (np.float64, "m32+m52"), (np.float32, "m32+m52"),
+                                         (np.float64, "rbf8"), (np.float32, "rbf8"), (np.float64, "c5")])
+def test_rccl_communicator_in_library_world_1(dtype, kname, tmp_path):
+    """pgps_comm_init + pgps_pkfs_seg_dev_* with a REAL RCCL communicator of one rank (all this box has): the five
+    launches and the two ncclAllGathers of a pass go out on the context's stream with no host step in between, no
+    torch anywhere.  Against the oracle; twice, to see that the scratch and records are reusable."""
+    from pssgp import _backend as B
+    from pssgp.distributed import ShardedScan, share_unique_id
+    ssm, y = _problem(n=6000, seed=11, kernel=_seg_kernel(kname) if kname else None)
+    d = ssm[1].shape[1]
+    of, oP, oll = O.kf(ssm, y, True)
+    os_, osP = O.kfs(ssm, y)
+    ctx = B.Context(0)
+    assert ctx.comm_info() == (0, 0)
+    uid = share_unique_id(0, path=str(tmp_path / "uid"))
+    assert share_unique_id(1, path=str(tmp_path / "uid")) == uid        # what another rank would read
+    seg = ShardedScan(ctx, uid, 0, 1, d, dtype)
+    assert ctx.comm_info() == (0, 1)
+    n = y.size
+    P0, Fs, Qs, H = (_Dev(ctx, a, dtype=dtype) for a in (ssm[0], ssm[1], ssm[2], ssm[3].reshape(-1)))
+    ys = _Dev(ctx, y, dtype=dtype)
+    fms, fPs, sms, sPs = (_Dev(ctx, shape=s, dtype=dtype) for s in ((n, d), (n, d, d), (n, d), (n, d, d)))
+    ll = _Dev(ctx, shape=(2,), dtype=np.float64)
+    for _ in range(2):
+        seg.pkfs(n, P0.ptr, Fs.ptr, Qs.ptr, H.ptr, float(ssm[4].reshape(())), ys.ptr, fms.ptr, fPs.ptr, sms.ptr, sPs.ptr,
+                 ll.ptr)
+    ctx.synchronize()
+    tol = (1e-9 if d <= 5 else 1e-7) if dtype == np.float64 else 2e-3
+    assert relerr(fms.get(), of) < tol and relerr(fPs.get(), oP) < tol
+    assert relerr(sms.get(), os_) < tol and relerr(sPs.get(), osP) < tol
+    assert abs(ll.get()[0] - oll) < (1e-10 if dtype == np.float64 else 1e-4) * abs(oll)
+    # a second communicator on the same context is refused; after destroy the pass is refused
+    with pytest.raises(B.PgpsError):
+        ctx.comm_init(uid, 0, 1)
+    seg.close()
+    with pytest.raises(B.PgpsError):
+        seg.pkfs(n, P0.ptr, Fs.ptr, Qs.ptr, H.ptr, 0.1, ys.ptr, fms.ptr, fPs.ptr, sms.ptr, sPs.ptr, ll.ptr)
+    for v in (P0, Fs, Qs, H, ys, fms, fPs, sms, sPs, ll):
+        v.free()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kname", [None, "rbf8"])
+def test_segment_phases_out_of_order_are_refused(kname):
+    """The three phases keep state in the context's scratch (for d > 6 the smoothing elements themselves): a phase
+    that does not directly follow its predecessor on the context gets PGPS_E_INVALID, not stale scratch."""
+    from pssgp import _backend as B
+    from pssgp.distributed import record_lengths
+    ssm, y = _problem(n=3000, seed=5, kernel=_seg_kernel(kname) if kname else None)
+    d = ssm[1].shape[1]
+    n = y.size
+    rf, rs, _ = record_lengths(d)
+    ctx = B.Context(0)
+    P0, Fs, Qs, H = (_Dev(ctx, a) for a in (ssm[0], ssm[1], ssm[2], ssm[3].reshape(-1)))
+    ys = _Dev(ctx, y)
+    fms, fPs, sms, sPs = (_Dev(ctx, shape=s) for s in ((n, d), (n, d, d), (n, d), (n, d, d)))
+    rec_f, rec_s, ll = _Dev(ctx, shape=(rf,)), _Dev(ctx, shape=(rs,)), _Dev(ctx, shape=(2,))
+    L, I, Rv = ctypes.c_long, ctypes.c_int, ctypes.c_double(0.1)
+
+    def reduce_():
+        ctx.call("pgps_seg_filter_reduce_dev_f64", L(n), I(d), I(0), I(1), P0.p, Fs.p, Qs.p, H.p, Rv, ys.p, rec_f.p)
+
+    def filter_(nn=n):
+        ctx.call("pgps_seg_filter_apply_dev_f64", L(nn), I(d), I(0), I(1), P0.p, Fs.p, Qs.p, H.p, Rv, ys.p, rec_f.p, fms.p,
+                 fPs.p, rec_s.p)
+
+    def smoother_():
+        ctx.call("pgps_seg_smoother_apply_dev_f64", L(n), I(d), I(0), I(1), Fs.p, Qs.p, fms.p, fPs.p, rec_s.p, sms.p, sPs.p,
+                 ll.p)
+
+    def refused(fn, *a):
+        with pytest.raises(B.PgpsError) as e:
+            fn(*a)
+        assert e.value.code == -1
+
+    refused(filter_)                    # no phase 1 at all
+    refused(smoother_)
+    reduce_()
+    refused(smoother_)                  # phase 2 skipped
+    reduce_()
+    refused(filter_, n - 1)             # another N
+    reduce_()
+    ctx.call("pgps_pkf_dev_f64", L(n), I(d), P0.p, Fs.p, Qs.p, H.p, Rv, ys.p, fms.p, fPs.p, ll.p)   # scratch re-laid out
+    refused(filter_)
+    reduce_(); filter_()
+    ctx.set_chunk(8)
+    refused(smoother_)                  # geometry changed between the phases
+    ctx.set_chunk(0)
+    reduce_(); filter_(); smoother_()   # and the regular order still works
+    ctx.synchronize()
+    os_, osP = O.kfs(ssm, y)
+    assert relerr(sms.get(), os_) < 1e-7 and relerr(sPs.get(), osP) < 1e-7
+    for v in (P0, Fs, Qs, H, ys, fms, fPs, sms, sPs, rec_f, rec_s, ll):
+        v.free()
+    ctx.close()
