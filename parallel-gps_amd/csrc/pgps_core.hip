@@ -330,9 +330,7 @@ extern "C" int pgps_get_chunk(pgps_ctx* ctx, long N, int* Lc, int* nb) {
     return PGPS_OK;
 }
 
-// fp32 series at 7 <= d <= 16 (whole-series calls): widened to fp64 scratch, run on the row-cooperative kernels,
-// narrowed back.  Three to four times faster than the fp32 wave-cooperative kernels at d = 15 despite the two
-// conversion passes, and the arithmetic is then exact to fp32 rounding of inputs and outputs.
+// fp32 <-> fp64 conversion passes (the discretisation kernels of 7 <= d <= 16 compute in fp64 whatever the series' type)
 namespace pgps {
 static __global__ void k_widen(long n, const float* in, double* out) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (double)in[i];
@@ -342,44 +340,13 @@ static __global__ void k_narrow(long n, const double* in, float* out) {
 }
 }  // namespace pgps
 
-static int scan_f32_via_f64(pgps_ctx* ctx, int d, const ScanArgs<float>& a, Mode mode) {
-    const size_t N = (size_t)a.N, dd = (size_t)d * d;
-    const bool pks = mode == MODE_PKS, smooth = mode != MODE_PKF;
-    // one scratch block: [P0 | H | Fs | Qs | ys | fms | fPs | sms | sPs]
-    const size_t n_small = dd + d, n_in = 2 * N * dd + N, n_f = N * d + N * dd, n_s = smooth ? N * d + N * dd : 0;
-    int rc_ = ensure(ctx, ctx->lti[6], (n_small + n_in + n_f + n_s) * sizeof(double));
-    if (rc_) return rc_;
-    double* base = (double*)ctx->lti[6].p;
-    double *P0 = base, *H = P0 + dd, *Fs = H + d, *Qs = Fs + N * dd, *ys = Qs + N * dd, *fms = ys + N, *fPs = fms + N * d,
-           *sms = fPs + N * dd, *sPs = sms + N * d;
-    auto widen = [&](const float* in, double* out, size_t n) {
-        if (in && n) hipLaunchKernelGGL(pgps::k_widen, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
-                                        (long)n, in, out);
-    };
-    auto narrow = [&](const double* in, float* out, size_t n) {
-        if (out && n) hipLaunchKernelGGL(pgps::k_narrow, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
-                                         (long)n, in, out);
-    };
-    widen(a.P0, P0, dd); widen(a.H, H, d);
-    widen(a.Fs, Fs, N * dd); widen(a.Qs, Qs, N * dd); widen(a.ys, ys, N);
-    if (pks) { widen(a.fms, fms, N * d); widen(a.fPs, fPs, N * dd); }
-    ScanArgs<double> b{};
-    b.N = a.N; b.seg_first = 1; b.seg_last = 1;
-    b.P0 = a.P0 ? P0 : nullptr; b.H = a.H ? H : nullptr; b.R = (double)a.R; b.Fs = Fs; b.Qs = Qs; b.ys = a.ys ? ys : nullptr;
-    b.fms = fms; b.fPs = fPs; b.sms = smooth ? sms : nullptr; b.sPs = smooth ? sPs : nullptr; b.ll = a.ll;
-    rc_ = launch_scan_rc(ctx, b, d, mode);
-    if (rc_) return rc_;
-    if (!pks) { narrow(fms, a.fms, N * d); narrow(fPs, a.fPs, N * dd); }
-    if (smooth) { narrow(sms, a.sms, N * d); narrow(sPs, a.sPs, N * dd); }
-    HIPCHK(ctx, hipGetLastError());
-    return PGPS_OK;
-}
-
 template <typename T>
 static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
     if constexpr (sizeof(T) == 4) {
-        const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
-        if (whole && ctx->family == 0 && d > PGPS_MAX_DIM_LANE && d <= rc::kDimMax) return scan_f32_via_f64(ctx, d, a, mode);
+        // row-cooperative family in fp32: its own instantiations (16-lane rows, v_fmac_f32_dpp), every mode; automatic
+        // from d = 5, where one lane no longer holds whole operands without spilling
+        const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
+        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d >= 5))) return launch_scan_rc<float>(ctx, a, d, mode);
     }
     if constexpr (sizeof(T) == 8) {
         // row-cooperative family: fp64, d <= 16, whole-series filter / filter+smoother
@@ -775,31 +742,6 @@ static int pkfs_seg_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, 
     if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
     if (!ctx->comm) return PGPS_E_INVALID;                      // pgps_comm_init first (also for one rank)
     if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
-    if constexpr (sizeof(T) == 4) {
-        if (ctx->family == 0 && d > PGPS_MAX_DIM_LANE && d <= rc::kDimMax) {
-            // fp32 segments at 7 <= d <= 16: widened to fp64 scratch for the row-cooperative kernels (as the whole-series
-            // calls do, scan_f32_via_f64), fp64 records on the wire, results narrowed
-            const size_t n = (size_t)N, dd = (size_t)d * d;
-            TRY(ensure(ctx, ctx->lti[6], (dd + d + 2 * n * dd + n + 2 * (n * d + n * dd)) * sizeof(double)));
-            double* b = (double*)ctx->lti[6].p;
-            double *P064 = b, *H64 = P064 + dd, *Fs64 = H64 + d, *Qs64 = Fs64 + n * dd, *ys64 = Qs64 + n * dd, *fm = ys64 + n,
-                   *fP = fm + n * d, *sm = fP + n * dd, *sP = sm + n * d;
-            auto grid = [](size_t m) { return dim3((unsigned)std::min<size_t>(4096, (m + 255) / 256)); };
-            auto widen = [&](const float* in, double* out, size_t m) {
-                hipLaunchKernelGGL(pgps::k_widen, grid(m), dim3(256), 0, ctx->stream, (long)m, in, out);
-            };
-            auto narrow = [&](const double* in, float* out, size_t m) {
-                hipLaunchKernelGGL(pgps::k_narrow, grid(m), dim3(256), 0, ctx->stream, (long)m, in, out);
-            };
-            widen((const float*)P0, P064, dd); widen((const float*)H, H64, d); widen((const float*)Fs, Fs64, n * dd);
-            widen((const float*)Qs, Qs64, n * dd); widen((const float*)ys, ys64, n);
-            TRY(pkfs_seg_run<double>(ctx, N, d, P064, Fs64, Qs64, H64, (double)R, ys64, fm, fP, sm, sP, ll));
-            narrow(fm, (float*)fms, n * d); narrow(fP, (float*)fPs, n * dd);
-            narrow(sm, (float*)sms, n * d); narrow(sP, (float*)sPs, n * dd);
-            HIPCHK(ctx, hipGetLastError());
-            return PGPS_OK;
-        }
-    }
     return pkfs_seg_run<T>(ctx, N, d, P0, Fs, Qs, H, R, ys, fms, fPs, sms, sPs, ll);
 }
 

@@ -198,8 +198,9 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
 // wave-cooperative family (pgps_wc.hip): runtime state dimension, 1 <= d <= 32
 template <typename T>
 int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);
-// row-cooperative family (pgps_rc.hip.h): fp64, 2 <= d <= 16, pkf / pkfs
-int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> a, int d, Mode mode);
+// row-cooperative family (pgps_rc.hip.h): fp64 and fp32, 2 <= d <= 16
+template <typename Real>
+int launch_scan_rc(pgps_ctx* ctx, ScanArgs<Real> a, int d, Mode mode);
 // the same with nothing written per step: MODE_PKF = log-likelihood only; MODE_PKFS = H sm, H sP H^T at the steps
 // qslot marks (a.sPs / a.sms are then scratch of N d^2 / N d doubles for the smoothing elements)
 // (MODE_PKF with a.Qs == nullptr: implicit process noise Q_k = P0 - F_k P0 F_k^T, P0 must be stationary)
@@ -213,43 +214,45 @@ int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* ta
                        const double* Qs, const double* ys, double* ll);
 namespace rc {
 constexpr int kDimMin = 2, kDimMax = 16;
-struct RcArgs {
+template <typename Real>
+struct RcArgsT {
     long N;
     int Lw;                     // steps per chain
     long nchunk;                // chains
     long wfast;                 // waves [1, wfast) lie inside the series, halo step included: predicate-free body
-    const double *P0, *H;
-    double R;
-    const double *Fs, *Qs, *ys;
-    double *fms, *fPs, *sms, *sPs;
-    double* agg1;               // (nchunk, nfilt) chunk totals
-    const double* pre;          // (nchunk, nfilt) inclusive prefixes of agg1
-    double* sagg1;              // (nchunk, nsmth) smoothing totals
-    const double* suf;          // (nchunk, nsmth) inclusive suffixes of sagg1
-    double *Es, *gs;            // (N, d, d), (N, d) the smoothing elements' E and g: sPs / sms themselves (overwritten
+    const Real *P0, *H;
+    Real R;
+    const Real *Fs, *Qs, *ys;
+    Real *fms, *fPs, *sms, *sPs;
+    Real* agg1;               // (nchunk, nfilt) chunk totals
+    const Real* pre;          // (nchunk, nfilt) inclusive prefixes of agg1
+    Real* sagg1;              // (nchunk, nsmth) smoothing totals
+    const Real* suf;          // (nchunk, nsmth) inclusive suffixes of sagg1
+    Real *Es, *gs;            // (N, d, d), (N, d) the smoothing elements' E and g: sPs / sms themselves (overwritten
                                 // in place by the smoother) unless those are not there yet (segments, projections)
-    double* Lws;                // (N, d, d) the smoothing elements' L
+    Real* Lws;                // (N, d, d) the smoothing elements' L
     double* llpart;             // (nchunk,)
     int seg_first, seg_last;    // this launch covers the first / last step of the whole series (multi-GPU segments)
-    const double* carry;        // !seg_first: compact filter record of everything before the segment
-    const double *halo_F, *halo_Q;  // !seg_last: F, Q of the first step of the next segment
-    const double* carry_back;   // !seg_last: compact smoother record of everything after the segment
+    const Real* carry;        // !seg_first: compact filter record of everything before the segment
+    const Real *halo_F, *halo_Q;  // !seg_last: F, Q of the first step of the next segment
+    const Real* carry_back;   // !seg_last: compact smoother record of everything after the segment
     int batch;                  // models evaluated over the same series (blockIdx.y); 0 / 1 = one
     long bs_F, bs_agg, bs_model;    // per-model strides of Fs / Qs, of agg1 / pre, of the model table
-    const double* Rs;           // batch entry point: observation noise of model b at Rs[b * bs_model] (else null)
+    const Real* Rs;           // batch entry point: observation noise of model b at Rs[b * bs_model] (else null)
     int implicit_q;             // Qs is not there: Q_k = P0 - F_k P0 F_k^T is folded into the predict (P0 stationary)
     int store_f;                // write fms / fPs (0: log-likelihood-only and projected-posterior calls)
     const int* qslot;           // projected-posterior mode: (N,) slot of step k in pmean / pvar, or -1
-    double *pmean, *pvar;       // (K,) H sm and H sP H^T at the query steps
+    Real *pmean, *pvar;       // (K,) H sm and H sP H^T at the query steps
 };
-// defined in pgps_rc_inst.hip, one explicit instantiation per d
-template <int D>
-int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase);
-template <int D>
-int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out, int batch, long bstride,
-                 const double* fixed);
-template <int D>
-int launch_rc_seg_carry(pgps_ctx* ctx, int which, const double* gathered, int rank, int nranks, int reclen, double* out);
+using RcArgs = RcArgsT<double>;
+// defined in pgps_rc_inst.hip, one explicit instantiation per (scalar type, d)
+template <typename Real, int D>
+int launch_rc_level1(pgps_ctx* ctx, const RcArgsT<Real>& a, int phase);
+template <typename Real, int D>
+int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const Real* in, Real* out, int batch, long bstride,
+                 const Real* fixed);
+template <typename Real, int D>
+int launch_rc_seg_carry(pgps_ctx* ctx, int which, const Real* gathered, int rank, int nranks, int reclen, Real* out);
 template <int D>
 int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, const double* ts, double t0, double* Fs,
                    double* Qs, int batch, long bs_model);

@@ -421,13 +421,14 @@ __device__ __forceinline__ void stage_commit(char* lds, const V4* r) {
 }
 // nt = streaming (non-temporal) stores: worth 12 % on the smoother pass once a pass no longer fits
 // the 256 MiB Infinity Cache (N = 2^24), slightly harmful when it does (N = 2^20) -- chosen per call
-template <typename GEO, bool NT>
+// LSTRIDE: distance between the owners' segments in LDS (another geometry's when the records live inside its buffer)
+template <typename GEO, bool NT, int LSTRIDE = GEO::STRIDE>
 __device__ __forceinline__ void stage_drain(char* __restrict__ g, long lane_pitch, const char* lds) {
     const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
     for (int v = 0; v < GEO::NV; ++v) {
         const int q = v * kWave + lane;
-        const V4 x = *reinterpret_cast<const V4*>(lds + (q / GEO::NV) * GEO::STRIDE + (q % GEO::NV) * 16);
+        const V4 x = *reinterpret_cast<const V4*>(lds + (q / GEO::NV) * LSTRIDE + (q % GEO::NV) * 16);
         V4* dst = reinterpret_cast<V4*>(g + (long)(q / GEO::NV) * lane_pitch + (q % GEO::NV) * 16);
         if constexpr (NT) __builtin_nontemporal_store(x, dst);
         else *dst = x;
@@ -439,11 +440,16 @@ __device__ __forceinline__ void stage_get(const char* lds, int i, T* out) {
     const int lane = threadIdx.x & (kWave - 1);
     load_rec<T, N>(reinterpret_cast<const T*>(lds + lane * GEO::STRIDE) + i * N, out);
 }
-template <typename GEO, typename T, int N>
+template <typename GEO, typename T, int N, int LSTRIDE = GEO::STRIDE>
 __device__ __forceinline__ void stage_put(char* lds, int i, const T* in) {
     const int lane = threadIdx.x & (kWave - 1);
-    store_rec<T, N>(reinterpret_cast<T*>(lds + lane * GEO::STRIDE) + i * N, in);
+    store_rec<T, N>(reinterpret_cast<T*>(lds + lane * LSTRIDE) + i * N, in);
 }
+// The G observations of a lane's sub-tile come straight from global memory (G * sizeof(T) contiguous bytes per lane,
+// one or two 16-byte loads): they are 8 of the 72 bytes a step moves, and without a transposition buffer for them
+// (and with the filtered means leaving through Q's buffer, below) two workgroups fit the LDS of a CU.
+template <typename T, int G>
+__device__ __forceinline__ void y_issue(const T* __restrict__ p, T* out) { load_rec<T, G>(p, out); }
 
 // staging is used when a record is small: d <= 2, and d = 3 with 144-byte lane segments
 // (fp64 G = 2, fp32 G = 4); G = steps per lane per sub-tile
@@ -454,8 +460,10 @@ struct StageCfg {
     using GF = StageGeom<D * D * (int)sizeof(T), GG>;     // F, Q, P records
     using GM = StageGeom<D * (int)sizeof(T), GG>;         // m records
     using GY = StageGeom<(int)sizeof(T), GG>;             // y records
-    static constexpr int F1_BYTES = on ? 2 * GF::BYTES + GY::BYTES : 16;
-    static constexpr int F3_BYTES = on ? 2 * GF::BYTES + GY::BYTES + GM::BYTES : 16;
+    // filter kernels: F (in; filtered P out) and Q (in; filtered m out, written compactly into the lane's own
+    // segment once Q_i has been read: m_i ends before Q_{i+1} begins) -- 2 x 9 KiB per wave at d = 2 fp64
+    static constexpr int F1_BYTES = on ? 2 * GF::BYTES : 16;
+    static constexpr int F3_BYTES = on ? 2 * GF::BYTES : 16;
     static constexpr int S3_BYTES = on ? 3 * GF::BYTES + GM::BYTES : 16;
 };
 
@@ -535,40 +543,40 @@ __device__ __forceinline__ void lane_filter_reduce_staged(const ScanArgs<T>& a, 
                                                           FiltElem<T, D>& agg) {
     using CFG = StageCfg<T, D, G>;
     using GF = typename CFG::GF;
-    using GY = typename CFG::GY;
     constexpr int MAT = D * D;
     const int lane = threadIdx.x & (kWave - 1);
     char* lF = lds;
     char* lQ = lF + GF::BYTES;
-    char* lY = lQ + GF::BYTES;
-    const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchY = (long)a.Lc * sizeof(T);
+    const long pitchF = (long)a.Lc * MAT * sizeof(T);
     const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
     const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
-    const char* gY = reinterpret_cast<const char*>(a.ys + wbase);
+    const T* gY = a.ys + wbase + (long)lane * a.Lc;
     const int S = a.Lc / G;
-    V4 rF[GF::NV], rQ[GF::NV], rY[GY::NV];
+    V4 rF[GF::NV], rQ[GF::NV];
+    T yn[G];
     stage_issue<GF>(gF, pitchF, rF);
     stage_issue<GF>(gQ, pitchF, rQ);
-    stage_issue<GY>(gY, pitchY, rY);
+    y_issue<T, G>(gY, yn);
     for (int s = 0; s < S; ++s) {
         wave_lds_sync();
         stage_commit<GF>(lF, rF);
         stage_commit<GF>(lQ, rQ);
-        stage_commit<GY>(lY, rY);
+        T yv[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) yv[i] = yn[i];
         if (s + 1 < S) {
             stage_issue<GF>(gF + (long)(s + 1) * GF::SEG, pitchF, rF);
             stage_issue<GF>(gQ + (long)(s + 1) * GF::SEG, pitchF, rQ);
-            stage_issue<GY>(gY + (long)(s + 1) * GY::SEG, pitchY, rY);
+            y_issue<T, G>(gY + (s + 1) * G, yn);
         }
         wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const long k = wbase + (long)lane * a.Lc + s * G + i;
-            T F[MAT], Qf[MAT], yv[1];
+            T F[MAT], Qf[MAT];
             stage_get<GF, T, MAT>(lF, i, F);
             stage_get<GF, T, MAT>(lQ, i, Qf);
-            stage_get<GY, T, 1>(lY, i, yv);
-            filter_reduce_step<T, D>(a, k, F, Qf, yv[0], h, agg);
+            filter_reduce_step<T, D>(a, k, F, Qf, yv[i], h, agg);
         }
     }
 }
@@ -715,18 +723,18 @@ struct FilterApplyStaged {
     using CFG = StageCfg<T, D, G>;
     using GF = typename CFG::GF;
     using GM = typename CFG::GM;
-    using GY = typename CFG::GY;
     static constexpr int MAT = D * D;
-    V4 rF[GF::NV], rQ[GF::NV], rY[GY::NV];
+    V4 rF[GF::NV], rQ[GF::NV];
+    T yn[G];
     T Fh[MAT], Qh[MAT];
     bool have_next;
 
     __device__ __forceinline__ void prefetch(const ScanArgs<T>& a, long wbase) {
         const int lane = threadIdx.x & (kWave - 1);
-        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchY = (long)a.Lc * sizeof(T);
+        const long pitchF = (long)a.Lc * MAT * sizeof(T);
         stage_issue<GF>(reinterpret_cast<const char*>(a.Fs + wbase * MAT), pitchF, rF);
         stage_issue<GF>(reinterpret_cast<const char*>(a.Qs + wbase * MAT), pitchF, rQ);
-        stage_issue<GY>(reinterpret_cast<const char*>(a.ys + wbase), pitchY, rY);
+        y_issue<T, G>(a.ys + wbase + (long)lane * a.Lc, yn);
         // the halo step of lane l is the first step of lane l+1: after the first sub-tile is in LDS
         // it is fetched from there (run()); only the wave's last lane reads global memory
         have_next = false;
@@ -737,14 +745,11 @@ struct FilterApplyStaged {
                                         LogLik& ll, SmthElem<T, D>& sagg) {
         const int lane = threadIdx.x & (kWave - 1);
         char* lF = lds;                     // F in, P out
-        char* lQ = lF + GF::BYTES;
-        char* lY = lQ + GF::BYTES;
-        char* lM = lY + GY::BYTES;          // m out
-        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchY = (long)a.Lc * sizeof(T),
-                   pitchM = (long)a.Lc * D * sizeof(T);
+        char* lQ = lF + GF::BYTES;          // Q in, m out (compact, inside the lane's own segment)
+        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchM = (long)a.Lc * D * sizeof(T);
         const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
         const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
-        const char* gY = reinterpret_cast<const char*>(a.ys + wbase);
+        const T* gY = a.ys + wbase + (long)lane * a.Lc;
         char* gP = reinterpret_cast<char*>(a.fPs + wbase * MAT);
         char* gM = reinterpret_cast<char*>(a.fms + wbase * D);
         const int S = a.Lc / G;
@@ -753,11 +758,13 @@ struct FilterApplyStaged {
             wave_lds_sync();
             stage_commit<GF>(lF, rF);
             stage_commit<GF>(lQ, rQ);
-            stage_commit<GY>(lY, rY);
+            T yv[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) yv[i] = yn[i];
             if (sb + 1 < S) {
                 stage_issue<GF>(gF + (long)(sb + 1) * GF::SEG, pitchF, rF);
                 stage_issue<GF>(gQ + (long)(sb + 1) * GF::SEG, pitchF, rQ);
-                stage_issue<GY>(gY + (long)(sb + 1) * GY::SEG, pitchY, rY);
+                y_issue<T, G>(gY + (sb + 1) * G, yn);
             }
             wave_lds_sync();
             if (SMOOTH && sb == 0 && lane < kWave - 1) {
@@ -769,18 +776,17 @@ struct FilterApplyStaged {
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const long k = k0 + sb * G + i;
-                T F[MAT], Qf[MAT], yv[1];
+                T F[MAT], Qf[MAT];
                 stage_get<GF, T, MAT>(lF, i, F);
                 stage_get<GF, T, MAT>(lQ, i, Qf);
-                stage_get<GY, T, 1>(lY, i, yv);
-                filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, yv[0], h, s, ll, sagg);
+                filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, yv[i], h, s, ll, sagg);
                 T Pf[MAT];
                 full_from_sym<T, D>(s.P, Pf);
-                stage_put<GM, T, D>(lM, i, s.m);
+                stage_put<GM, T, D, GF::STRIDE>(lQ, i, s.m);    // Q_k is dead too: m_k goes where Q_0..Q_k were
                 stage_put<GF, T, MAT>(lF, i, Pf);       // F_k is dead after its predict
             }
             wave_lds_sync();
-            stage_drain<GM, NT>(gM + (long)sb * GM::SEG, pitchM, lM);
+            stage_drain<GM, NT, GF::STRIDE>(gM + (long)sb * GM::SEG, pitchM, lQ);
             stage_drain<GF, NT>(gP + (long)sb * GF::SEG, pitchF, lF);
         }
         if (SMOOTH) filter_tail_apply<T, D>(have_next, Fh, Qh, s, sagg);
@@ -933,7 +939,6 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
     using CFG = StageCfg<T, D, G>;
     using GF = typename CFG::GF;
     using GM = typename CFG::GM;
-    using GY = typename CFG::GY;
     static_assert(CFG::on && LC % G == 0, "single-pass filter: staged dims only, whole sub-tiles");
     __shared__ T lds[kWaves * NF];
     __shared__ double lds_ll[kWaves];
@@ -959,9 +964,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
     const bool staged = (wbase + (long)kWave * LC <= a.N);
     char* lF = stage[wave];
     char* lQ = lF + GF::BYTES;
-    char* lY = lQ + GF::BYTES;
-    char* lM = lY + GY::BYTES;
-    const long pitchF = (long)LC * MAT * sizeof(T), pitchY = (long)LC * sizeof(T), pitchM = (long)LC * D * sizeof(T);
+    const long pitchF = (long)LC * MAT * sizeof(T), pitchM = (long)LC * D * sizeof(T);
 
     // ---- phase A: stream the chunk into registers and reduce it --------------------------------
     T Freg[LC][MAT], Qreg[LC][SYM];       // Q kept as its symmetric part: 3 instead of 4 values at d = 2
@@ -973,33 +976,29 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
     if (staged) {
         const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
         const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
-        const char* gY = reinterpret_cast<const char*>(a.ys + wbase);
-        V4 rF[GF::NV], rQ[GF::NV], rY[GY::NV];
+        V4 rF[GF::NV], rQ[GF::NV];
         stage_issue<GF>(gF, pitchF, rF);
         stage_issue<GF>(gQ, pitchF, rQ);
-        stage_issue<GY>(gY, pitchY, rY);
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) y_issue<T, G>(a.ys + k0 + sb * G, yreg + sb * G);
         if (SMOOTH && lane == kWave - 1) have_next = filter_tail_load<T, D>(a, wbase + (long)kWave * LC, Fh, Qh);
 #pragma unroll
         for (int sb = 0; sb < S; ++sb) {
             wave_lds_sync();
             stage_commit<GF>(lF, rF);
             stage_commit<GF>(lQ, rQ);
-            stage_commit<GY>(lY, rY);
             if (sb + 1 < S) {
                 stage_issue<GF>(gF + (long)(sb + 1) * GF::SEG, pitchF, rF);
                 stage_issue<GF>(gQ + (long)(sb + 1) * GF::SEG, pitchF, rQ);
-                stage_issue<GY>(gY + (long)(sb + 1) * GY::SEG, pitchY, rY);
             }
             wave_lds_sync();
 #pragma unroll
             for (int i = 0; i < G; ++i) {
-                T yv[1], Qf[MAT];
+                T Qf[MAT];
                 stage_get<GF, T, MAT>(lF, i, Freg[sb * G + i]);
                 stage_get<GF, T, MAT>(lQ, i, Qf);
-                stage_get<GY, T, 1>(lY, i, yv);
-                yreg[sb * G + i] = yv[0];
                 sym_from_full<T, D>(Qf, Qreg[sb * G + i]);
-                filter_reduce_step<T, D>(a, k0 + sb * G + i, Freg[sb * G + i], Qf, yv[0], h, agg);
+                filter_reduce_step<T, D>(a, k0 + sb * G + i, Freg[sb * G + i], Qf, yreg[sb * G + i], h, agg);
             }
         }
     } else {
@@ -1102,11 +1101,11 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
                                                 sagg);
                 T Pf[MAT];
                 full_from_sym<T, D>(s.P, Pf);
-                stage_put<GM, T, D>(lM, i, s.m);
+                stage_put<GM, T, D, GF::STRIDE>(lQ, i, s.m);
                 stage_put<GF, T, MAT>(lF, i, Pf);
             }
             wave_lds_sync();
-            stage_drain<GM, NT>(gM + (long)sb * GM::SEG, pitchM, lM);
+            stage_drain<GM, NT, GF::STRIDE>(gM + (long)sb * GM::SEG, pitchM, lQ);
             stage_drain<GF, NT>(gP + (long)sb * GF::SEG, pitchF, lF);
         }
         if (SMOOTH) filter_tail_apply<T, D>(have_next, Fh, Qh, s, sagg);

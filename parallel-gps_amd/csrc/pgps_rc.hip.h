@@ -1,4 +1,5 @@
-// pgps_rc.hip.h -- the "row-cooperative" scan family: fp64, state dimensions 2..16, one instantiation per d.
+// pgps_rc.hip.h -- the "row-cooperative" scan family: fp64 and fp32, state dimensions 2..16, one instantiation per
+// (scalar type, d).
 // Compiled by pgps_rc_inst.hip (-DPGPS_RC_D=d); the host driver that strings the launches together is in pgps_wc.hip
 // (scan_rc / scan_rc_seg / launch_disc_rc).
 //
@@ -33,12 +34,17 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pgps_internal.h"
 #include "pgps_math.h"
 #include "pgps_rc_asm.h"
 
 namespace pgps {
 namespace rc {
+
+template <typename T> struct Ident { using type = T; };
+template <typename T> using Id = typename Ident<T>::type;      // a parameter that takes no part in deducing T
 
 constexpr int kLdT = 17;                    // leading dimension of a transpose patch (16 lanes + 1)
 constexpr int kPatch = 16 * kLdT;           // doubles per row patch
@@ -52,56 +58,56 @@ __host__ __device__ inline int nfilt(int d) { return 3 * d * d + 2 * d; }      /
 __host__ __device__ inline int nsmth(int d) { return 2 * d * d + d; }          // [E | L | g]
 
 // z += X Y  (z pre-loaded with the addend; z must not alias x or y)
-template <int D>
-__device__ __forceinline__ void mm(double* z, const double* x, const double* y) {
+template <int D, typename Real>
+__device__ __forceinline__ void mm(Real* z, const Real* x, const Real* y) {
 #pragma unroll
-    for (int i = 0; i + 4 <= D; i += 4) Asm<D>::rows4(z + i, x + i, y);
+    for (int i = 0; i + 4 <= D; i += 4) Asm<Real, D>::rows4(z + i, x + i, y);
     constexpr int R = D % 4, I0 = D - R;
-    if constexpr (R == 1) Asm<D>::rows1(z + I0, x + I0, y);
-    if constexpr (R == 2) Asm<D>::rows2(z + I0, x + I0, y);
-    if constexpr (R == 3) Asm<D>::rows3(z + I0, x + I0, y);
+    if constexpr (R == 1) Asm<Real, D>::rows1(z + I0, x + I0, y);
+    if constexpr (R == 2) Asm<Real, D>::rows2(z + I0, x + I0, y);
+    if constexpr (R == 3) Asm<Real, D>::rows3(z + I0, x + I0, y);
 }
-template <int D>
-__device__ __forceinline__ void zero(double* z) {
+template <int D, typename Real>
+__device__ __forceinline__ void zero(Real* z) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) z[i] = 0.0;
+    for (int i = 0; i < D; ++i) z[i] = Real(0.0);
 }
-template <int D>
-__device__ __forceinline__ void copy(double* z, const double* x) {
+template <int D, typename Real>
+__device__ __forceinline__ void copy(Real* z, const Real* x) {
 #pragma unroll
     for (int i = 0; i < D; ++i) z[i] = x[i];
 }
 // (X v)_lane + add, X in ROW layout (lane i holds row i), v distributed (lane k holds v_k); also the
 // row-wide sum  sum_k v_k x_k + add  when x is replicated (every lane gets the same value)
-template <int D>
-__device__ __forceinline__ double mvr(const double* xr, double v, double add) {
-    double a0 = add, a1 = 0.0;
-    Asm<D>::mv(a0, a1, v, xr);
+template <int D, typename Real>
+__device__ __forceinline__ Real mvr(const Real* xr, Id<Real> v, Id<Real> add) {
+    Real a0 = add, a1 = Real(0.0);
+    Asm<Real, D>::mv(a0, a1, v, xr);
     return a0 + a1;
 }
 // add + sum_k v_k over the row (every lane gets it)
-template <int D>
-__device__ __forceinline__ double rowsum(double v, double add) {
-    double a0 = add, a1 = 0.0;
-    Asm<D>::rsum(a0, a1, v, 1.0);
+template <int D, typename Real>
+__device__ __forceinline__ Real rowsum(Real v, Id<Real> add) {
+    Real a0 = add, a1 = Real(0.0);
+    Asm<Real, D>::rsum(a0, a1, v, Real(1.0));
     return a0 + a1;
 }
 // sum_i h_i X[i][lane]: (X^T h)_lane, = (X h)_lane for symmetric X
-template <int D>
-__device__ __forceinline__ double dot_h(const double* x, const double* h) {
-    double a0 = 0.0, a1 = 0.0;
+template <int D, typename Real>
+__device__ __forceinline__ Real dot_h(const Real* x, const Real* h) {
+    Real a0 = Real(0.0), a1 = Real(0.0);
 #pragma unroll
     for (int i = 0; i + 1 < D; i += 2) { a0 = __builtin_fma(h[i], x[i], a0); a1 = __builtin_fma(h[i + 1], x[i + 1], a1); }
     if constexpr (D & 1) a0 = __builtin_fma(h[D - 1], x[D - 1], a0);
     return a0 + a1;
 }
-template <int D>
-__device__ __forceinline__ void rank1(double* z, double p, double q) { Asm<D>::rank1(z, p, q); }
+template <int D, typename Real>
+__device__ __forceinline__ void rank1(Real* z, Id<Real> p, Id<Real> q) { Asm<Real, D>::rank1(z, p, q); }
 
 // xt = X^T through the row's LDS patch.  Patch rows >= D are zero (cleared once, never written), so lanes >= D
 // read zeros.
-template <int D>
-__device__ __forceinline__ void transpose(const double* x, double* xt, double* patch, int lane) {
+template <int D, typename Real>
+__device__ __forceinline__ void transpose(const Real* x, Real* xt, Real* patch, int lane) {
 #pragma unroll
     for (int i = 0; i < D; ++i) patch[i * kLdT + lane] = x[i];
     sync();
@@ -109,21 +115,27 @@ __device__ __forceinline__ void transpose(const double* x, double* xt, double* p
     for (int i = 0; i < D; ++i) xt[i] = patch[lane * kLdT + i];
     sync();
 }
-template <int D>
-__device__ __forceinline__ void symmetrise(double* x, double* patch, int lane) {
-    double xt[D];
+template <int D, typename Real>
+__device__ __forceinline__ void symmetrise(Real* x, Real* patch, int lane) {
+    Real xt[D];
     transpose<D>(x, xt, patch, lane);
 #pragma unroll
-    for (int i = 0; i < D; ++i) x[i] = 0.5 * (x[i] + xt[i]);
+    for (int i = 0; i < D; ++i) x[i] = Real(0.5) * (x[i] + xt[i]);
 }
-__device__ __forceinline__ double* patch_init(double* tl, int row) {
-    for (int e = threadIdx.x; e < 4 * kPatch; e += 64) tl[e] = 0.0;
+template <typename Real>
+__device__ __forceinline__ Real* patch_init(Real* tl, int row) {
+    for (int e = threadIdx.x; e < 4 * kPatch; e += 64) tl[e] = Real(0.0);
     sync();
     return tl + row * kPatch;
 }
 
 template <int K>
 __device__ __forceinline__ double bcast(double x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + K, 0xf, 0xf, true); }
+template <int K>
+__device__ __forceinline__ float bcast(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x150 + K, 0xf,
+                                                                 0xf, true));
+}
 
 // maximum of a distributed vector over the row (every lane gets it)
 template <int D, int K = 0>
@@ -141,20 +153,26 @@ __device__ __forceinline__ double rcp_nr(double x) {
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
 }
+__device__ __forceinline__ float rcp_nr(float x) {      // v_rcp_f32 is good to 1 ulp: one Newton step rounds it off
+    float r = __builtin_amdgcn_rcpf(x);
+    r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
 
 // Gauss-Jordan without pivoting (M symmetric positive definite): B <- M^-1 B.  Row operations in column layout:
 // row_r -= M[r][c] * row_c / M[c][c], the factor M[r][c] being lane c's register r broadcast to the row.
 // M is destroyed.
 template <int D, int C>
 struct GjStep {
-    static __device__ __forceinline__ void run(double* M, double* B) {
-        const double inv = rcp_nr(bcast<C>(M[C]));
-        const double mc = M[C] * inv, bv = B[C] * inv;
+    template <typename Real>
+    static __device__ __forceinline__ void run(Real* M, Real* B) {
+        const Real inv = rcp_nr(bcast<C>(M[C]));
+        const Real mc = M[C] * inv, bv = B[C] * inv;
         if constexpr (D <= 8) {
-            Gj<D, C>::run(M, B, -mc, -bv);
+            Gj<Real, D, C>::run(M, B, -mc, -bv);
         } else {
-            Gj<8, C>::run(M, B, -mc, -bv);
-            Gj<D - 8, C>::run(M + 8, B + 8, -mc, -bv);
+            Gj<Real, 8, C>::run(M, B, -mc, -bv);
+            Gj<Real, D - 8, C>::run(M + 8, B + 8, -mc, -bv);
         }
         M[C] = mc;                       // the pivot row itself (whatever the block did to it is discarded)
         B[C] = bv;
@@ -165,73 +183,113 @@ struct GjStep {
 // Per-lane addressing of one chain's records.  The four chains of a wave sit Lw steps apart, so every access is
 // (wave-uniform base of row 0's step) + (one loop-invariant 32-bit byte offset per lane and layout) + (a
 // compile-time offset per register, which rides in the instruction's immediate field): element (i, lane) for the
-// column layout, (lane, i) for the row layout.  FAST = every chain of the wave is inside the series for the
-// whole loop (all waves but the first / last): the loads of a step are one EXEC-masked block (lanes < D) with no
-// selects behind them, so they stay in flight until their first use.
-template <int D>
+// column layout, (lane, i) for the row layout.
+//
+// FAST = every chain of the wave is inside the series for the whole loop (all waves but the first / last).  Its
+// accesses are RAW BUFFER loads / stores through a descriptor that spans the four rows' records of the step: lanes
+// >= D carry an out-of-range offset, so the hardware returns zeros to them and drops their stores -- no EXEC-masked
+// branch around the memory instructions and no select behind a load.  That matters twice: the loads stay in flight
+// until their first use, and -- straight-line code -- the compiler counts the outstanding memory operations exactly,
+// so waiting for a load does not also wait for the younger stores of the step (a branch around a store makes the
+// count unknown at the join and every later wait a full `s_waitcnt vmcnt(0)`: measured, that drained the stores'
+// round trip into every time step).
+constexpr unsigned kOob = 0x7ffff000u;         // + any immediate offset: beyond every descriptor's range, no 32-bit wrap
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_ld(__amdgpu_buffer_rsrc_t r, unsigned off, double& x) {
+    using U2 = __attribute__((ext_vector_type(2))) unsigned int;
+    const U2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    x = __builtin_bit_cast(double, v);
+}
+__device__ __forceinline__ void buf_ld(__amdgpu_buffer_rsrc_t r, unsigned off, float& x) {
+    x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned off, double x) {
+    using U2 = __attribute__((ext_vector_type(2))) unsigned int;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2, x), r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned off, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, (int)off, 0, 0);
+}
+
+template <int D, typename Real>
 struct Io {
+    static constexpr unsigned W = sizeof(Real);
     unsigned oc, orw, ov, ro8;          // byte offsets of (0, lane), (lane, 0), vector element `lane`; of the row's step
+    unsigned foc, forw, fov;            // the same for the buffer accesses: out of range for lanes >= D
+    unsigned span_m, span_v;            // bytes from row 0's record to the end of row 3's: matrices, vectors
     bool lv;
     int lane;
     __device__ __forceinline__ void init(int lane_, int row, int Lw) {
         lane = lane_;
         lv = lane < D;
         const unsigned ro = (unsigned)row * (unsigned)Lw * (unsigned)(D * D);
-        ro8 = ro * 8u;
-        oc = lv ? (ro + (unsigned)lane) * 8u : 0u;
-        orw = lv ? (ro + (unsigned)(lane * D)) * 8u : 0u;
-        ov = lv ? ((unsigned)row * (unsigned)Lw * (unsigned)D + (unsigned)lane) * 8u : 0u;
+        ro8 = ro * W;
+        oc = lv ? (ro + (unsigned)lane) * W : 0u;
+        orw = lv ? (ro + (unsigned)(lane * D)) * W : 0u;
+        ov = lv ? ((unsigned)row * (unsigned)Lw * (unsigned)D + (unsigned)lane) * W : 0u;
+        foc = lv ? oc : kOob; forw = lv ? orw : kOob; fov = lv ? ov : kOob;
+        span_m = (3u * (unsigned)Lw + 1u) * (unsigned)(D * D) * W;
+        span_v = (3u * (unsigned)Lw + 1u) * (unsigned)D * W;
     }
     template <bool ROWL>
-    static constexpr int step_bytes() { return ROWL ? 8 : 8 * D; }      // from register i to register i + 1
-    // fast path: X (lanes < D) <- the matrix; lanes >= D keep their zeros
+    static constexpr int step_bytes() { return ROWL ? (int)W : (int)W * D; }      // from register i to register i + 1
+    // fast path: X <- the matrix (zeros in lanes >= D)
     template <bool ROWL>
-    __device__ __forceinline__ void mat_fast(const double* base, double* X) const {
-        if (lv) {
-            const char* p = reinterpret_cast<const char*>(base) + (ROWL ? orw : oc);
+    __device__ __forceinline__ void mat_fast(const Real* base, Real* X) const {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(base, span_m);
+        const unsigned o = ROWL ? forw : foc;
 #pragma unroll
-            for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const double*>(p + i * step_bytes<ROWL>());
-        }
+        for (int i = 0; i < D; ++i) buf_ld(r, o + (unsigned)(i * step_bytes<ROWL>()), X[i]);
     }
     // general path: rows that are not `real` get dg * I.  One divergent if / else around the whole block, no
     // selects behind the loads (a select would wait for them on the spot).
     template <bool ROWL>
-    __device__ __forceinline__ void mat_slow(const double* base, bool real, double dg, double* X) const {
+    __device__ __forceinline__ void mat_slow(const Real* base, bool real, Real dg, Real* X) const {
         if (lv && real) {
             const char* p = reinterpret_cast<const char*>(base) + (ROWL ? orw : oc);
 #pragma unroll
-            for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const double*>(p + i * step_bytes<ROWL>());
+            for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const Real*>(p + i * step_bytes<ROWL>());
         } else {
 #pragma unroll
-            for (int i = 0; i < D; ++i) X[i] = (i == lane && lv) ? dg : 0.0;
+            for (int i = 0; i < D; ++i) X[i] = (i == lane && lv) ? dg : Real(0.0);
         }
     }
-    // fast path: x (lanes < D) <- the vector element; lanes >= D keep their zero
-    __device__ __forceinline__ void vec_fast(const double* base, double& x) const {
-        if (lv) x = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ov);
-    }
-    __device__ __forceinline__ double vec(const double* base, bool real) const {
-        double v = 0.0;
-        if (lv && real) v = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ov);
+    // fast path: x <- the vector element (zero in lanes >= D)
+    __device__ __forceinline__ void vec_fast(const Real* base, Real& x) const { buf_ld(make_rsrc(base, span_v), fov, x); }
+    __device__ __forceinline__ Real vec(const Real* base, bool real) const {
+        Real v = Real(0.0);
+        if (lv && real) v = *reinterpret_cast<const Real*>(reinterpret_cast<const char*>(base) + ov);
         return v;
     }
-    __device__ __forceinline__ void st_mat(double* base, bool pred, const double* X) const {
-        if (lv && pred) {
+    // stores: FAST through the descriptor (every lane executes them, lanes >= D are out of range), otherwise predicated
+    template <bool FAST>
+    __device__ __forceinline__ void st_mat(Real* base, bool pred, const Real* X) const {
+        if constexpr (FAST) {
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(base, span_m);
+#pragma unroll
+            for (int i = 0; i < D; ++i) buf_st(r, foc + (unsigned)(i * (int)W * D), X[i]);
+        } else if (lv && pred) {
             char* p = reinterpret_cast<char*>(base) + oc;
 #pragma unroll
-            for (int i = 0; i < D; ++i) *reinterpret_cast<double*>(p + i * 8 * D) = X[i];
+            for (int i = 0; i < D; ++i) *reinterpret_cast<Real*>(p + i * (int)W * D) = X[i];
         }
     }
-    __device__ __forceinline__ void st_vec(double* base, bool pred, double x) const {
-        if (lv && pred) *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + ov) = x;
+    template <bool FAST>
+    __device__ __forceinline__ void st_vec(Real* base, bool pred, Real x) const {
+        if constexpr (FAST) buf_st(make_rsrc(base, span_v), fov, x);
+        else if (lv && pred) *reinterpret_cast<Real*>(reinterpret_cast<char*>(base) + ov) = x;
     }
 };
 
 // Batched evaluation (pgps_lti_ll_batch_*): blockIdx.y selects one of `batch` models over the same series; each
 // model has its own slice of the discretised arrays, of the scan scratch and of the model table
 // [F | Pinf | H | R] (stride bs_model).  The kernel bodies below never see the difference.
-__device__ __forceinline__ RcArgs model_view(const RcArgs& a) {
-    RcArgs b = a;
+template <typename Real>
+__device__ __forceinline__ RcArgsT<Real> model_view(const RcArgsT<Real>& a) {
+    RcArgsT<Real> b = a;
     if (a.Rs) {
         const long mb = blockIdx.y;
         b.Fs += mb * a.bs_F;
@@ -253,35 +311,35 @@ __device__ __forceinline__ RcArgs model_view(const RcArgs& a) {
 // ====================================================================================================
 // level 1: reduce -- filt_extend over the chunk (pgps_math.h filt_extend, parallel.py:46-72,100-118)
 // ====================================================================================================
-template <int D, bool FAST>
-__device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int lane, int row) {
+template <typename Real, int D, bool FAST>
+__device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;        // row 0's first step
     const long c = (long)blockIdx.x * 4 + row;
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
-    Io<D> io;
+    Io<D, Real> io;
     io.init(lane, row, a.Lw);
     const bool lv = io.lv;
-    double h[D];
+    Real h[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) h[i] = a.H[i];
-    double A[D], C[D], J[D], b = 0.0, eta = 0.0;
+    Real A[D], C[D], J[D], b = Real(0.0), eta = Real(0.0);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         // chunk 0 starts from (0, 0, P0, 0, 0) and takes step 0 with F = I, Q = 0: that is filt_first
         const bool head = (c == 0 && a.seg_first);
-        A[i] = (!head && i == lane) ? 1.0 : 0.0;
-        C[i] = (head && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
-        J[i] = 0.0;
+        A[i] = (!head && i == lane) ? Real(1.0) : Real(0.0);
+        C[i] = (head && lv) ? Real(0.5) * (a.P0[i * D + lane] + a.P0[lane * D + i]) : Real(0.0);
+        J[i] = Real(0.0);
     }
-    double Fc[D], Fr[D], Q[D], y;
+    Real Fc[D], Fr[D], Q[D], y;
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
     // Implicit process noise (general-LTI log-likelihood calls): Q_k = Pinf - F_k Pinf F_k^T is never formed --
     // F C F^T + Q = F (C - Pinf) F^T + Pinf -- so the (N, d, d) array Qs does not exist; F = I gives Q = 0 by itself.
     const bool impq = a.implicit_q != 0;         // bit 0: Qs absent; bit 1: Qs there, but P0 known stationary -- skip reading it
-    double Pinf[D];
+    Real Pinf[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
+    for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? Real(0.5) * (a.P0[i * D + lane] + a.P0[lane * D + i]) : Real(0.0);
     // inputs of this row's step kw + row Lw + s; steps outside the chunk and step 0 of the series run as F = I, Q = 0
     auto load = [&](int s) {
         const long ku = kw + s, k = k0 + s;
@@ -293,19 +351,19 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
             const bool real = k < k1 && !(k == 0 && a.seg_first);
-            io.template mat_slow<false>(a.Fs + kc * dd, real, 1.0, Fc);
-            io.template mat_slow<true>(a.Fs + kc * dd, real, 1.0, Fr);
-            if (!impq) io.template mat_slow<false>(a.Qs + kc * dd, real, 0.0, Q);
+            io.template mat_slow<false>(a.Fs + kc * dd, real, Real(1.0), Fc);
+            io.template mat_slow<true>(a.Fs + kc * dd, real, Real(1.0), Fr);
+            if (!impq) io.template mat_slow<false>(a.Qs + kc * dd, real, Real(0.0), Q);
             y = __builtin_nan("");
             if (k < k1) y = a.ys[k];
         }
     };
     load(0);
     for (int s = 0; s < a.Lw; ++s) {
-        double Ap[D], FC[D], Cp[D];
+        Real Ap[D], FC[D], Cp[D];
         zero<D>(Ap); mm<D>(Ap, Fc, A);
         if (impq) {
-            double Cm[D];
+            Real Cm[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) Cm[i] = C[i] - Pinf[i];
             zero<D>(FC); mm<D>(FC, Fc, Cm);
@@ -315,15 +373,15 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
             copy<D>(Cp, Q);
         }
         mm<D>(Cp, FC, Fr);
-        const double bp = mvr<D>(Fr, b, 0.0);
-        const double yk = y;
+        const Real bp = mvr<D>(Fr, b, Real(0.0));
+        const Real yk = y;
         if (s + 1 < a.Lw) load(s + 1);          // next step's inputs: their registers are free from here on
         symmetrise<D>(Cp, patch, lane);
-        const double u = dot_h<D>(Cp, h), v = dot_h<D>(Ap, h);
-        const double S = mvr<D>(h, u, a.R), hb = mvr<D>(h, bp, 0.0);
+        const Real u = dot_h<D>(Cp, h), v = dot_h<D>(Ap, h);
+        const Real S = mvr<D>(h, u, a.R), hb = mvr<D>(h, bp, Real(0.0));
         const bool obs = !(yk != yk);
-        const double inv = obs ? 1.0 / S : 0.0;
-        const double res = obs ? yk - hb : 0.0;
+        const Real inv = obs ? Real(1.0) / S : Real(0.0);
+        const Real res = obs ? yk - hb : Real(0.0);
         copy<D>(A, Ap); rank1<D>(A, u, -v * inv);
         copy<D>(C, Cp); rank1<D>(C, u, -u * inv);
         rank1<D>(J, v, v * inv);
@@ -331,7 +389,7 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
         eta += v * (res * inv);
     }
     if (c < a.nchunk && lv) {
-        double* rec = a.agg1 + c * nfilt(D);
+        Real* rec = a.agg1 + c * nfilt(D);
 #pragma unroll
         for (int i = 0; i < D; ++i) { rec[i * D + lane] = A[i]; rec[dd + i * D + lane] = C[i]; rec[2 * dd + i * D + lane] = J[i]; }
         rec[3 * dd + lane] = b;
@@ -339,58 +397,58 @@ __device__ __forceinline__ void reduce1_body(const RcArgs& a, double* patch, int
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(64) void rc_reduce1(const RcArgs a0) {
-    __shared__ double tl[4 * kPatch];
+template <typename Real, int D>
+__global__ __launch_bounds__(64) void rc_reduce1(const RcArgsT<Real> a0) {
+    __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
-    const RcArgs a = model_view(a0);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<D, true>(a, patch, lane, row);
-    else reduce1_body<D, false>(a, patch, lane, row);
+    Real* patch = patch_init(tl, row);
+    const RcArgsT<Real> a = model_view(a0);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<Real, D, true>(a, patch, lane, row);
+    else reduce1_body<Real, D, false>(a, patch, lane, row);
 }
 
 // ====================================================================================================
 // level 1: apply -- Kalman pass, log-likelihood, smoothing elements and the chunk's smoothing total
 // (kf_step / smth_element / smth_combine of pgps_math.h; parallel.py:135-151, 155-184)
 // ====================================================================================================
-template <int D, bool SMOOTH, bool FAST, bool IMPQS = false>
-__device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int lane, int row) {
+template <typename Real, int D, bool SMOOTH, bool FAST, bool IMPQS, bool STORE>
+__device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
-    Io<D> io;
+    Io<D, Real> io;
     io.init(lane, row, a.Lw);
     const bool lv = io.lv, cv = c < a.nchunk;
-    double h[D];
+    Real h[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) h[i] = a.H[i];
-    const double hl = lv ? a.H[lane] : 0.0;     // this lane's entry of H: row sums of hl * v replace H-weighted ones
+    const Real hl = lv ? a.H[lane] : Real(0.0);     // this lane's entry of H: row sums of hl * v replace H-weighted ones
     // state entering the chunk: (b, C) of the inclusive prefix of the chunk before (A = 0 there); prior for chunk 0
-    double m, P[D];
+    Real m, P[D];
     {
         // (a later segment of a sharded series enters its first chain with the carry-in of the ranks before it)
         const bool pr = cv && (c > 0 || !a.seg_first);
-        const double* rec = c > 0 ? a.pre + (cv ? c - 1 : 0) * nfilt(D) : (a.seg_first ? a.pre : a.carry);
-        m = (pr && lv) ? rec[3 * dd + lane] : 0.0;
+        const Real* rec = c > 0 ? a.pre + (cv ? c - 1 : 0) * nfilt(D) : (a.seg_first ? a.pre : a.carry);
+        m = (pr && lv) ? rec[3 * dd + lane] : Real(0.0);
 #pragma unroll
         for (int i = 0; i < D; ++i)
-            P[i] = !lv ? 0.0 : pr ? rec[dd + i * D + lane] : (c == 0 ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0);
+            P[i] = !lv ? Real(0.0) : pr ? rec[dd + i * D + lane] : (c == 0 ? Real(0.5) * (a.P0[i * D + lane] + a.P0[lane * D + i]) : Real(0.0));
     }
-    double Ec[D], L[D], g = 0.0;               // smoothing total of the steps seen so far
+    Real Ec[D], L[D], g = Real(0.0);               // smoothing total of the steps seen so far
     if (SMOOTH) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) { Ec[i] = (i == lane) ? 1.0 : 0.0; L[i] = 0.0; }
+        for (int i = 0; i < D; ++i) { Ec[i] = (i == lane) ? Real(1.0) : Real(0.0); L[i] = Real(0.0); }
     }
     LogLik ll;
-    double Fc[D], Fr[D], Q[D], y;
+    Real Fc[D], Fr[D], Q[D], y;
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
     // see rc_reduce1.  Filter only: a runtime flag; with the smoothing elements (which need F P itself: one more
     // product) a separate instantiation, so that the array path's kernel stays exactly as it was
     const bool impq = SMOOTH ? IMPQS : (a.implicit_q & 1);
-    double Pinf[D];
+    Real Pinf[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? 0.5 * (a.P0[i * D + lane] + a.P0[lane * D + i]) : 0.0;
+    for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? Real(0.5) * (a.P0[i * D + lane] + a.P0[lane * D + i]) : Real(0.0);
     // steps at or beyond N run with F = 0, Q = I: the element built from them is (0, m, P), i.e. the last
     // element of the series (parallel.py:155-156), and a total whose E is 0 absorbs whatever follows unchanged
     auto load = [&](int s) {
@@ -407,21 +465,27 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             const bool real = k < a.N || hal;
             const char* bF = hal ? reinterpret_cast<const char*>(a.halo_F) - io.ro8 : reinterpret_cast<const char*>(a.Fs + kc * dd);
             const char* bQ = hal ? reinterpret_cast<const char*>(a.halo_Q) - io.ro8 : reinterpret_cast<const char*>(a.Qs + kc * dd);
-            io.template mat_slow<false>(reinterpret_cast<const double*>(bF), real, 0.0, Fc);
-            io.template mat_slow<true>(reinterpret_cast<const double*>(bF), real, 0.0, Fr);
-            if (!impq) io.template mat_slow<false>(reinterpret_cast<const double*>(bQ), real, 1.0, Q);
+            io.template mat_slow<false>(reinterpret_cast<const Real*>(bF), real, Real(0.0), Fc);
+            io.template mat_slow<true>(reinterpret_cast<const Real*>(bF), real, Real(0.0), Fr);
+            if (!impq) io.template mat_slow<false>(reinterpret_cast<const Real*>(bQ), real, Real(1.0), Q);
             y = __builtin_nan("");
             if (s < a.Lw && k < k1) y = a.ys[k];
         }
     };
     load(0);
-    const int iters = SMOOTH ? a.Lw + 1 : a.Lw;
-    for (int s = 0; s < iters; ++s) {
+    // One step, in three flavours so that the loop proper is straight-line code (see Io): FIRST has no smoothing element
+    // to build (there is no step before the chunk's first), LAST (the step after the chunk, SMOOTH only) builds the
+    // last step's element and does not filter.  Next step's inputs are requested as soon as this step's are dead when the
+    // registers allow (EARLY), otherwise -- fp64 from d = 9 with the smoothing total on board -- just before this
+    // step's own stores, so that waiting for them never waits for those stores.
+    constexpr bool EARLY = !SMOOTH || sizeof(Real) == 4 || D <= 8;
+    auto step = [&](auto first_c, auto last_c, const int s) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
         const long ku = kw + s, k = k0 + s;
         // predict
-        double FP[D], Pp[D];
+        Real FP[D], Pp[D];
         if (impq && !SMOOTH) {
-            double Pm[D];
+            Real Pm[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) Pm[i] = P[i] - Pinf[i];
             zero<D>(FP); mm<D>(FP, Fc, Pm);
@@ -429,7 +493,7 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             mm<D>(Pp, FP, Fr);
         } else if (impq) {
             // with the smoothing elements F P is needed as it is: Pp = Pinf + (F P - F Pinf) F^T
-            double FI[D], Dm[D];
+            Real FI[D], Dm[D];
             zero<D>(FP); mm<D>(FP, Fc, P);
             zero<D>(FI); mm<D>(FI, Fc, Pinf);
 #pragma unroll
@@ -441,35 +505,32 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
             copy<D>(Pp, Q);
             mm<D>(Pp, FP, Fr);
         }
-        const double mp = mvr<D>(Fr, m, 0.0);
-        const double yk = y;
-        // Next step's inputs.  The filter-only kernel has the registers to fetch them a whole step ahead; with
-        // the smoothing total on board the fetch waits until the end of the step so that the kernel fits 256
-        // registers and two waves share a SIMD (they cover each other's latency instead).
-        if (!SMOOTH && s + 1 < iters) load(s + 1);
+        const Real mp = mvr<D>(Fr, m, Real(0.0));
+        const Real yk = y;
+        if constexpr (!LAST && EARLY) load(s + 1);
         symmetrise<D>(Pp, patch, lane);
-        if (SMOOTH && s > 0) {
+        if constexpr (SMOOTH && !FIRST) {
             // element of step k-1: W = Pp^-1 F P = E^T (i.e. E in row layout), g = m - E mp, L = P - E F P
-            double M[D], W[D];
+            Real M[D], W[D];
             copy<D>(M, Pp); copy<D>(W, FP);
             GjStep<D, 0>::run(M, W);
-            const double gn = m - mvr<D>(W, mp, 0.0);
-            double En[D], Ln[D], T[D];
+            const Real gn = m - mvr<D>(W, mp, Real(0.0));
+            Real En[D], Ln[D], T[D];
             transpose<D>(W, En, patch, lane);
             zero<D>(T); mm<D>(T, En, FP);
 #pragma unroll
             for (int i = 0; i < D; ++i) Ln[i] = P[i] - T[i];
             {
                 const bool st = FAST || (k - 1 < k1);
-                io.st_mat(a.Es + (ku - 1) * dd, st, En);
-                io.st_mat(a.Lws + (ku - 1) * dd, st, Ln);
-                io.st_vec(a.gs + (ku - 1) * D, st, gn);
+                io.template st_mat<FAST>(a.Es + (ku - 1) * dd, st, En);
+                io.template st_mat<FAST>(a.Lws + (ku - 1) * dd, st, Ln);
+                io.template st_vec<FAST>(a.gs + (ku - 1) * D, st, gn);
             }
             // total <- total (x) element:  E = Ea En, g = Ea gn + ga, L = Ea Ln Ea^T + La
-            double E2[D];
+            Real E2[D];
             zero<D>(E2); mm<D>(E2, Ec, En);
             zero<D>(T); mm<D>(T, Ec, Ln);
-            double Er[D];                       // the total's E in row layout, made where it is used
+            Real Er[D];                       // the total's E in row layout, made where it is used
             transpose<D>(Ec, Er, patch, lane);
             if (FAST) {
                 g = mvr<D>(Er, gn, g);
@@ -480,8 +541,8 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
                 // Beyond the end of a segment that is NOT the last of its series there is nothing to fold: the
                 // F = 0 steps would put E = 0 into a total that the ranks after this one still have to extend.
                 const bool fold = a.seg_last || (k - 1 < a.N);
-                const double g2 = mvr<D>(Er, gn, g);
-                double L2[D];
+                const Real g2 = mvr<D>(Er, gn, g);
+                Real L2[D];
                 copy<D>(L2, L); mm<D>(L2, T, Er);
                 symmetrise<D>(L2, patch, lane);
                 g = fold ? g2 : g;
@@ -489,19 +550,19 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
                 for (int i = 0; i < D; ++i) { L[i] = fold ? L2[i] : L[i]; Ec[i] = fold ? E2[i] : Ec[i]; }
             }
         }
-        if (s < a.Lw) {
+        if constexpr (!LAST) {
             const bool upd = FAST || k < k1;
             const bool obs = !(yk != yk);
-            double u = dot_h<D>(Pp, h);
-            double S = rowsum<D>(hl * u, a.R), mu = rowsum<D>(hl * mp, 0.0);
-            if (obs) ll.add(yk - mu, S);
-            double mb = mp;
+            Real u = dot_h<D>(Pp, h);
+            Real S = rowsum<D>(hl * u, a.R), mu = rowsum<D>(hl * mp, Real(0.0));
+            if (obs) ll.add((double)yk - (double)mu, (double)S);
+            Real mb = mp;
             if (!FAST && blockIdx.x == 0 && s == 0) {
                 // first step of the series (chain 0 only): the update uses the prior itself (parallel.py:24-30),
                 // the likelihood term above used F0 P0 F0^T + Q0 (parallel.py:136-141)
                 const bool first = (c == 0 && a.seg_first);
-                const double u0 = dot_h<D>(P, h);
-                const double S0 = rowsum<D>(hl * u0, a.R), mu0 = rowsum<D>(hl * m, 0.0);
+                const Real u0 = dot_h<D>(P, h);
+                const Real S0 = rowsum<D>(hl * u0, a.R), mu0 = rowsum<D>(hl * m, Real(0.0));
 #pragma unroll
                 for (int i = 0; i < D; ++i) Pp[i] = first ? P[i] : Pp[i];
                 mb = first ? m : mp;
@@ -509,20 +570,30 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
                 S = first ? S0 : S;
                 mu = first ? mu0 : mu;
             }
-            const double inv = obs ? 1.0 / S : 0.0;
-            const double res = obs ? yk - mu : 0.0;
+            const Real inv = obs ? Real(1.0) / S : Real(0.0);
+            const Real res = obs ? yk - mu : Real(0.0);
             m = mb + u * (inv * res);
             copy<D>(P, Pp); rank1<D>(P, u, -u * inv);
-            if (a.store_f) {                    // log-likelihood-only and projected-posterior calls skip these
-                io.st_mat(a.fPs + ku * dd, upd, P);
-                io.st_vec(a.fms + ku * D, upd, m);
+            if constexpr (!EARLY) load(s + 1);
+            if constexpr (STORE) {              // log-likelihood-only and projected-posterior calls skip these
+                io.template st_mat<FAST>(a.fPs + ku * dd, upd, P);
+                io.template st_vec<FAST>(a.fms + ku * D, upd, m);
             }
         }
-        if (SMOOTH && s + 1 < iters) load(s + 1);
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    if constexpr (SMOOTH) {
+        step(Yes{}, No{}, 0);
+        for (int s = 1; s < a.Lw; ++s) step(No{}, No{}, s);
+        step(No{}, Yes{}, a.Lw);
+    } else {
+        // (the last step requests one step beyond the chunk: inside the series for a FAST wave, clamped otherwise)
+        for (int s = 0; s < a.Lw; ++s) step(Yes{}, No{}, s);
     }
     if (cv) {
         if (SMOOTH && lv) {
-            double* rec = a.sagg1 + c * nsmth(D);
+            Real* rec = a.sagg1 + c * nsmth(D);
 #pragma unroll
             for (int i = 0; i < D; ++i) { rec[i * D + lane] = Ec[i]; rec[dd + i * D + lane] = L[i]; }
             rec[2 * dd + lane] = g;
@@ -531,15 +602,16 @@ __device__ __forceinline__ void apply1_body(const RcArgs& a, double* patch, int 
     }
 }
 
-template <int D, bool SMOOTH, bool IMPQS = false>
-__global__ __launch_bounds__(64) void rc_apply1(const RcArgs a0) {
+// STORE: the filtered moments are written (pkf / pkfs); not for the log-likelihood-only and projected-posterior calls
+template <typename Real, int D, bool SMOOTH, bool IMPQS, bool STORE>
+__global__ __launch_bounds__(64) void rc_apply1(const RcArgsT<Real> a0) {
     static_assert(SMOOTH || !IMPQS, "the implicit-noise instantiation is the smoothing one");
-    __shared__ double tl[4 * kPatch];
+    __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
-    const RcArgs a = model_view(a0);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<D, SMOOTH, true, IMPQS>(a, patch, lane, row);
-    else apply1_body<D, SMOOTH, false, IMPQS>(a, patch, lane, row);
+    Real* patch = patch_init(tl, row);
+    const RcArgsT<Real> a = model_view(a0);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, lane, row);
+    else apply1_body<Real, D, SMOOTH, false, IMPQS, STORE>(a, patch, lane, row);
 }
 
 // ====================================================================================================
@@ -547,19 +619,19 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgs a0) {
 // moments -- the element part of rc_apply1 with (m, P) of step k read from fms / fPs and the predict taken with
 // F, Q of step k + 1 (parallel.py:159-173); stores E, g, L and the chain's smoothing total.
 // ====================================================================================================
-template <int D, bool FAST>
-__device__ __forceinline__ void selem1_body(const RcArgs& a, double* patch, int lane, int row) {
+template <typename Real, int D, bool FAST>
+__device__ __forceinline__ void selem1_body(const RcArgsT<Real>& a, Real* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
-    Io<D> io;
+    Io<D, Real> io;
     io.init(lane, row, a.Lw);
     const bool lv = io.lv, cv = c < a.nchunk;
-    double Ec[D], L[D], g = 0.0;               // smoothing total of the steps seen so far
+    Real Ec[D], L[D], g = Real(0.0);               // smoothing total of the steps seen so far
 #pragma unroll
-    for (int i = 0; i < D; ++i) { Ec[i] = (i == lane) ? 1.0 : 0.0; L[i] = 0.0; }
-    double Fc[D], Fr[D], Q[D], P[D], m = 0.0;
+    for (int i = 0; i < D; ++i) { Ec[i] = (i == lane) ? Real(1.0) : Real(0.0); L[i] = Real(0.0); }
+    Real Fc[D], Fr[D], Q[D], P[D], m = Real(0.0);
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q); zero<D>(P);
     // step k's filtered moments and step k + 1's (F, Q); at or beyond the end of the series F = 0, Q = I, which
     // makes the element (0, m, P): the last element for k = N - 1, a no-op on a total whose E is already 0 after it
@@ -574,42 +646,42 @@ __device__ __forceinline__ void selem1_body(const RcArgs& a, double* patch, int 
         } else {
             const long kc = ku < a.N ? ku : a.N - 1, kn = ku + 1 < a.N ? ku + 1 : a.N - 1;
             const bool real = k < k1, nreal = k + 1 < a.N;
-            io.template mat_slow<false>(a.Fs + kn * dd, nreal, 0.0, Fc);
-            io.template mat_slow<true>(a.Fs + kn * dd, nreal, 0.0, Fr);
-            io.template mat_slow<false>(a.Qs + kn * dd, nreal, 1.0, Q);
-            io.template mat_slow<false>(a.fPs + kc * dd, real, 0.0, P);
+            io.template mat_slow<false>(a.Fs + kn * dd, nreal, Real(0.0), Fc);
+            io.template mat_slow<true>(a.Fs + kn * dd, nreal, Real(0.0), Fr);
+            io.template mat_slow<false>(a.Qs + kn * dd, nreal, Real(1.0), Q);
+            io.template mat_slow<false>(a.fPs + kc * dd, real, Real(0.0), P);
             m = io.vec(a.fms + kc * D, real);
         }
     };
     load(0);
     for (int s = 0; s < a.Lw; ++s) {
         const long ku = kw + s, k = k0 + s;
-        double Ps[D];
+        Real Ps[D];
         symmetrise<D>(P, patch, lane);           // the caller's filtered covariances need not be exactly symmetric
         copy<D>(Ps, P);
-        const double ms = m;
-        double FP[D], Pp[D];
+        const Real ms = m;
+        Real FP[D], Pp[D];
         zero<D>(FP); mm<D>(FP, Fc, Ps);
         copy<D>(Pp, Q); mm<D>(Pp, FP, Fr);
-        const double mp = mvr<D>(Fr, ms, 0.0);
+        const Real mp = mvr<D>(Fr, ms, Real(0.0));
         if (s + 1 < a.Lw) load(s + 1);
         symmetrise<D>(Pp, patch, lane);
-        double W[D];
+        Real W[D];
         copy<D>(W, FP);
         GjStep<D, 0>::run(Pp, W);                // Pp is not needed afterwards: eliminated in place
-        const double gn = ms - mvr<D>(W, mp, 0.0);
-        double En[D], Ln[D], T[D];
+        const Real gn = ms - mvr<D>(W, mp, Real(0.0));
+        Real En[D], Ln[D], T[D];
         transpose<D>(W, En, patch, lane);
         zero<D>(T); mm<D>(T, En, FP);
 #pragma unroll
         for (int i = 0; i < D; ++i) Ln[i] = Ps[i] - T[i];
         {
             const bool st = FAST || k < k1;
-            io.st_mat(a.Es + ku * dd, st, En);
-            io.st_mat(a.Lws + ku * dd, st, Ln);
-            io.st_vec(a.gs + ku * D, st, gn);
+            io.template st_mat<FAST>(a.Es + ku * dd, st, En);
+            io.template st_mat<FAST>(a.Lws + ku * dd, st, Ln);
+            io.template st_vec<FAST>(a.gs + ku * D, st, gn);
         }
-        double E2[D], Er[D];
+        Real E2[D], Er[D];
         zero<D>(E2); mm<D>(E2, Ec, En);
         zero<D>(T); mm<D>(T, Ec, Ln);
         transpose<D>(Ec, Er, patch, lane);
@@ -619,20 +691,20 @@ __device__ __forceinline__ void selem1_body(const RcArgs& a, double* patch, int 
         copy<D>(Ec, E2);
     }
     if (cv && lv) {
-        double* rec = a.sagg1 + c * nsmth(D);
+        Real* rec = a.sagg1 + c * nsmth(D);
 #pragma unroll
         for (int i = 0; i < D; ++i) { rec[i * D + lane] = Ec[i]; rec[dd + i * D + lane] = L[i]; }
         rec[2 * dd + lane] = g;
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(64) void rc_selem1(const RcArgs a) {
-    __shared__ double tl[4 * kPatch];
+template <typename Real, int D>
+__global__ __launch_bounds__(64) void rc_selem1(const RcArgsT<Real> a) {
+    __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
-    if (blockIdx.x < a.wfast) selem1_body<D, true>(a, patch, lane, row);    // no first-step special case here
-    else selem1_body<D, false>(a, patch, lane, row);
+    Real* patch = patch_init(tl, row);
+    if (blockIdx.x < a.wfast) selem1_body<Real, D, true>(a, patch, lane, row);    // no first-step special case here
+    else selem1_body<Real, D, false>(a, patch, lane, row);
 }
 
 // ====================================================================================================
@@ -640,31 +712,31 @@ __global__ __launch_bounds__(64) void rc_selem1(const RcArgs a) {
 // ====================================================================================================
 // PROJ (pgps_lti_predict_*): nothing is stored per step; step k writes  H sm_k  and  H sP_k H^T  to slot qslot[k]
 // when that is >= 0 (StateSpaceGP.predict_f keeps exactly those, pssgp/model.py:107-111)
-template <int D, bool FAST, bool PROJ>
-__device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int lane, int row) {
+template <typename Real, int D, bool FAST, bool PROJ>
+__device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
-    Io<D> io;
+    Io<D, Real> io;
     io.init(lane, row, a.Lw);
     const bool lv = io.lv;
     // smoothed moments of the first step after the chunk: (g, L) of the inclusive suffix of the next chunk
     // (E = 0 there: every suffix contains the last element); nothing (0, 0) after the last chunk, whose own
     // last element has E = 0
-    double sm, sP[D];
+    Real sm, sP[D];
     {
         // (the last chain of a segment that is not the last takes what follows from the ranks after it)
         const bool inner = c + 1 < a.nchunk;
         const bool nx = inner || (c + 1 == a.nchunk && a.carry_back != nullptr);
-        const double* rec = inner ? a.suf + (c + 1) * nsmth(D) : (a.carry_back ? a.carry_back : a.suf);
-        sm = (nx && lv) ? rec[2 * dd + lane] : 0.0;
+        const Real* rec = inner ? a.suf + (c + 1) * nsmth(D) : (a.carry_back ? a.carry_back : a.suf);
+        sm = (nx && lv) ? rec[2 * dd + lane] : Real(0.0);
 #pragma unroll
-        for (int i = 0; i < D; ++i) sP[i] = (nx && lv) ? rec[dd + i * D + lane] : 0.0;
+        for (int i = 0; i < D; ++i) sP[i] = (nx && lv) ? rec[dd + i * D + lane] : Real(0.0);
     }
-    double Ec[D], Er[D], L[D], g = 0.0;
+    Real Ec[D], Er[D], L[D], g = Real(0.0);
     zero<D>(Ec); zero<D>(Er); zero<D>(L);
-    double h[D];
+    Real h[D];
     int q = -1;
     if (PROJ) {
 #pragma unroll
@@ -681,16 +753,16 @@ __device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int
         } else {
             const long kc = ku < a.N ? ku : a.N - 1;
             const bool real = k < k1;
-            io.template mat_slow<false>(a.Es + kc * dd, real, 1.0, Ec);
-            io.template mat_slow<true>(a.Es + kc * dd, real, 1.0, Er);
-            io.template mat_slow<false>(a.Lws + kc * dd, real, 0.0, L);
+            io.template mat_slow<false>(a.Es + kc * dd, real, Real(1.0), Ec);
+            io.template mat_slow<true>(a.Es + kc * dd, real, Real(1.0), Er);
+            io.template mat_slow<false>(a.Lws + kc * dd, real, Real(0.0), L);
             g = io.vec(a.gs + kc * D, real);
         }
     };
     load(a.Lw - 1);
     for (int s = a.Lw - 1; s >= 0; --s) {
         const long ku = kw + s, k = k0 + s;
-        double T[D], nP[D];
+        Real T[D], nP[D];
         if (FAST) transpose<D>(Ec, Er, patch, lane);   // E in row layout through LDS: a second global read costs more
         zero<D>(T); mm<D>(T, Ec, sP);
         copy<D>(nP, L); mm<D>(nP, T, Er);
@@ -700,24 +772,27 @@ __device__ __forceinline__ void smooth1_body(const RcArgs& a, double* patch, int
         symmetrise<D>(nP, patch, lane);
         copy<D>(sP, nP);
         if (PROJ) {
-            const double mean = mvr<D>(h, sm, 0.0);                     // H sm            (every lane of the row)
-            const double var = mvr<D>(h, dot_h<D>(sP, h), 0.0);         // H sP H^T
-            if (qk >= 0 && lane == 0) { a.pmean[qk] = mean; a.pvar[qk] = var; }
+            const Real mean = mvr<D>(h, sm, Real(0.0));                     // H sm            (every lane of the row)
+            const Real var = mvr<D>(h, dot_h<D>(sP, h), Real(0.0));         // H sP H^T
+            // branch-free: a descriptor over the K outputs, offset out of range unless this step is a query (lane 0 writes)
+            const unsigned qo = (qk >= 0 && lane == 0) ? (unsigned)qk * (unsigned)sizeof(Real) : kOob;
+            buf_st(make_rsrc(a.pmean, 0x7fff0000u), qo, mean);
+            buf_st(make_rsrc(a.pvar, 0x7fff0000u), qo, var);
         } else {
             const bool st = FAST || k < k1;
-            io.st_mat(a.sPs + ku * dd, st, sP);
-            io.st_vec(a.sms + ku * D, st, sm);
+            io.template st_mat<FAST>(a.sPs + ku * dd, st, sP);
+            io.template st_vec<FAST>(a.sms + ku * D, st, sm);
         }
     }
 }
 
-template <int D, bool PROJ>
-__global__ __launch_bounds__(64) void rc_smooth1(const RcArgs a) {
-    __shared__ double tl[4 * kPatch];
+template <typename Real, int D, bool PROJ>
+__global__ __launch_bounds__(64) void rc_smooth1(const RcArgsT<Real> a) {
+    __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<D, true, PROJ>(a, patch, lane, row);
-    else smooth1_body<D, false, PROJ>(a, patch, lane, row);
+    Real* patch = patch_init(tl, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<Real, D, true, PROJ>(a, patch, lane, row);
+    else smooth1_body<Real, D, false, PROJ>(a, patch, lane, row);
 }
 
 // ====================================================================================================
@@ -728,24 +803,25 @@ __global__ __launch_bounds__(64) void rc_smooth1(const RcArgs a) {
 // the candidates by broadcast and applies the same predicated row swaps to its own registers.
 template <int D, int C>
 struct GjPivStep {
-    static __device__ __forceinline__ void run(double* M, double* B) {
-        double pv = bcast<C>(M[C]);
+    template <typename Real>
+    static __device__ __forceinline__ void run(Real* M, Real* B) {
+        Real pv = bcast<C>(M[C]);
 #pragma unroll
         for (int r = C + 1; r < D; ++r) {
-            const double t = bcast<C>(M[r]);
+            const Real t = bcast<C>(M[r]);
             const bool sw = __builtin_fabs(t) > __builtin_fabs(pv);
-            const double mc = M[C], mr = M[r], bc = B[C], br = B[r];
+            const Real mc = M[C], mr = M[r], bc = B[C], br = B[r];
             M[C] = sw ? mr : mc; M[r] = sw ? mc : mr;
             B[C] = sw ? br : bc; B[r] = sw ? bc : br;
             pv = sw ? t : pv;
         }
-        const double inv = 1.0 / pv;
-        const double mc = M[C] * inv, bv = B[C] * inv;
+        const Real inv = Real(1.0) / pv;
+        const Real mc = M[C] * inv, bv = B[C] * inv;
         if constexpr (D <= 8) {
-            Gj<D, C>::run(M, B, -mc, -bv);
+            Gj<Real, D, C>::run(M, B, -mc, -bv);
         } else {
-            Gj<8, C>::run(M, B, -mc, -bv);
-            Gj<D - 8, C>::run(M + 8, B + 8, -mc, -bv);
+            Gj<Real, 8, C>::run(M, B, -mc, -bv);
+            Gj<Real, D - 8, C>::run(M + 8, B + 8, -mc, -bv);
         }
         M[C] = mc;
         B[C] = bv;
@@ -753,15 +829,15 @@ struct GjPivStep {
     }
 };
 
-template <int D>
-__device__ __forceinline__ void ld_rec_mat(const double* g, bool ok, int lane, double* X) {
+template <int D, typename Real>
+__device__ __forceinline__ void ld_rec_mat(const Real* g, bool ok, int lane, Real* X) {
     if (ok) {
 #pragma unroll
         for (int i = 0; i < D; ++i) X[i] = g[i * D + lane];
     }
 }
-template <int D>
-__device__ __forceinline__ void st_rec_mat(double* g, bool ok, int lane, const double* X) {
+template <int D, typename Real>
+__device__ __forceinline__ void st_rec_mat(Real* g, bool ok, int lane, const Real* X) {
     if (ok) {
 #pragma unroll
         for (int i = 0; i < D; ++i) g[i * D + lane] = X[i];
@@ -773,28 +849,28 @@ __device__ __forceinline__ void st_rec_mat(double* g, bool ok, int lane, const d
 //   M = I + C1 J2;  Nm = M^-1 C1 (symmetric);  z = eta2 - J2 b1;  W = J2 A1;  G = M^-1 A1 = A1 - Nm W
 //   A = A2 G;  b = A2 (b1 + Nm z) + b2;  C = sym(A2 Nm A2^T) + C2;  eta = G^T z + eta1;  J = sym(G^T W) + J1
 // Outputs: Ao, bo, eo, and C2 / J1 updated in place to the result's C / J.
-template <int D>
-__device__ __forceinline__ void filt_combine_rc(double* patch, int lane, const double* A1, const double* C1, double* J1,
-                                                double b1, double e1, const double* A2, double* C2, const double* J2,
-                                                double b2, double e2, double* Ao, double& bo, double& eo) {
-    double M[D], Nm[D];
+template <int D, typename Real>
+__device__ __forceinline__ void filt_combine_rc(Real* patch, int lane, const Real* A1, const Real* C1, Real* J1,
+                                                Real b1, Real e1, const Real* A2, Real* C2, const Real* J2,
+                                                Real b2, Real e2, Real* Ao, Real& bo, Real& eo) {
+    Real M[D], Nm[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { M[i] = (i == lane) ? 1.0 : 0.0; Nm[i] = C1[i]; }
+    for (int i = 0; i < D; ++i) { M[i] = (i == lane) ? Real(1.0) : Real(0.0); Nm[i] = C1[i]; }
     mm<D>(M, C1, J2);
     GjPivStep<D, 0>::run(M, Nm);
-    const double z = e2 - mvr<D>(J2, b1, 0.0);
-    double W[D], T[D], G[D];
+    const Real z = e2 - mvr<D>(J2, b1, Real(0.0));
+    Real W[D], T[D], G[D];
     zero<D>(W); mm<D>(W, J2, A1);
     zero<D>(T); mm<D>(T, Nm, W);
 #pragma unroll
     for (int i = 0; i < D; ++i) G[i] = A1[i] - T[i];
-    double X[D], A2r[D], Gt[D];
+    Real X[D], A2r[D], Gt[D];
     zero<D>(Ao); mm<D>(Ao, A2, G);
     zero<D>(X); mm<D>(X, A2, Nm);
     transpose<D>(A2, A2r, patch, lane);
     mm<D>(C2, X, A2r);                          // C2 <- C2 + A2 Nm A2^T
     symmetrise<D>(C2, patch, lane);
-    const double w = mvr<D>(Nm, z, b1);         // b1 + Nm z   (Nm symmetric: its column layout is its row layout)
+    const Real w = mvr<D>(Nm, z, b1);         // b1 + Nm z   (Nm symmetric: its column layout is its row layout)
     bo = mvr<D>(A2r, w, b2);
     eo = mvr<D>(G, z, e1);                      // G^T z + eta1
     transpose<D>(G, Gt, patch, lane);
@@ -803,11 +879,11 @@ __device__ __forceinline__ void filt_combine_rc(double* patch, int lane, const d
 }
 
 // a (x) b in time order (smth_combine, parallel.py:176-184):  E = Ea Eb;  g = Ea gb + ga;  L = sym(Ea Lb Ea^T) + La
-template <int D>
-__device__ __forceinline__ void smth_combine_rc(double* patch, int lane, const double* Ea, const double* La, double ga,
-                                                const double* Eb, const double* Lb, double gb, double* Eo, double* Lo,
-                                                double& go) {
-    double T[D], Ear[D];
+template <int D, typename Real>
+__device__ __forceinline__ void smth_combine_rc(Real* patch, int lane, const Real* Ea, const Real* La, Real ga,
+                                                const Real* Eb, const Real* Lb, Real gb, Real* Eo, Real* Lo,
+                                                Real& go) {
+    Real T[D], Ear[D];
     zero<D>(Eo); mm<D>(Eo, Ea, Eb);
     zero<D>(T); mm<D>(T, Ea, Lb);
     transpose<D>(Ea, Ear, patch, lane);
@@ -817,16 +893,16 @@ __device__ __forceinline__ void smth_combine_rc(double* patch, int lane, const d
 }
 
 // compact records in global memory: filter [A | C | J | b | eta], smoother [E | L | g]
-template <int D>
-__device__ __forceinline__ void ld_filt(const double* r, bool ok, int lane, double* A, double* C, double* J, double& b,
-                                        double& e) {
+template <int D, typename Real>
+__device__ __forceinline__ void ld_filt(const Real* r, bool ok, int lane, Real* A, Real* C, Real* J, Real& b,
+                                        Real& e) {
     constexpr int dd = D * D;
     ld_rec_mat<D>(r, ok, lane, A); ld_rec_mat<D>(r + dd, ok, lane, C); ld_rec_mat<D>(r + 2 * dd, ok, lane, J);
     if (ok) { b = r[3 * dd + lane]; e = r[3 * dd + D + lane]; }
 }
-template <int D>
-__device__ __forceinline__ void st_filt(double* r, bool ok, int lane, const double* A, const double* C, const double* J,
-                                        double b, double e) {
+template <int D, typename Real>
+__device__ __forceinline__ void st_filt(Real* r, bool ok, int lane, const Real* A, const Real* C, const Real* J,
+                                        Real b, Real e) {
     constexpr int dd = D * D;
     st_rec_mat<D>(r, ok, lane, A); st_rec_mat<D>(r + dd, ok, lane, C); st_rec_mat<D>(r + 2 * dd, ok, lane, J);
     if (ok) { r[3 * dd + lane] = b; r[3 * dd + D + lane] = e; }
@@ -834,12 +910,12 @@ __device__ __forceinline__ void st_filt(double* r, bool ok, int lane, const doub
 
 // out[c] = in[c - stride] (x) in[c]; with `fixed` given: out[c] = fixed (x) in[c] for every c (a segment's
 // carry-in combined into all its prefixes)
-template <int D>
-__global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const double* in, double* out, long bstride,
-                                                   const double* fixed) {
-    __shared__ double tl[4 * kPatch];
+template <typename Real, int D>
+__global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const Real* in, Real* out, long bstride,
+                                                   const Real* fixed) {
+    __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
+    Real* patch = patch_init(tl, row);
     in += blockIdx.y * bstride;
     out += blockIdx.y * bstride;
     constexpr int dd = D * D, nf = 3 * D * D + 2 * D;
@@ -847,19 +923,19 @@ __global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const do
     const bool lv = lane < D, cv = c < n, comb = cv && (fixed != nullptr || c >= stride);
     const bool ok = lv && cv;
     // later operand (also the pass-through value)
-    double A2[D], C2[D], J2[D], b2 = 0.0, e2 = 0.0;
+    Real A2[D], C2[D], J2[D], b2 = Real(0.0), e2 = Real(0.0);
     zero<D>(A2); zero<D>(C2); zero<D>(J2);
-    const double* r2 = in + (cv ? c : 0) * nf;
+    const Real* r2 = in + (cv ? c : 0) * nf;
     ld_filt<D>(r2, ok, lane, A2, C2, J2, b2, e2);
     // earlier operand; rows that only pass through combine with the identity (A = I): same arithmetic, result unused
-    double A1[D], C1[D], J1[D], b1 = 0.0, e1 = 0.0;
+    Real A1[D], C1[D], J1[D], b1 = Real(0.0), e1 = Real(0.0);
 #pragma unroll
-    for (int i = 0; i < D; ++i) { A1[i] = (i == lane) ? 1.0 : 0.0; C1[i] = 0.0; J1[i] = 0.0; }
-    const double* r1 = fixed ? fixed : in + (comb ? c - stride : 0) * nf;
+    for (int i = 0; i < D; ++i) { A1[i] = (i == lane) ? Real(1.0) : Real(0.0); C1[i] = Real(0.0); J1[i] = Real(0.0); }
+    const Real* r1 = fixed ? fixed : in + (comb ? c - stride : 0) * nf;
     ld_filt<D>(r1, lv && comb, lane, A1, C1, J1, b1, e1);
-    double Ao[D], bo, eo;
+    Real Ao[D], bo, eo;
     filt_combine_rc<D>(patch, lane, A1, C1, J1, b1, e1, A2, C2, J2, b2, e2, Ao, bo, eo);
-    double* ro = out + (cv ? c : 0) * nf;
+    Real* ro = out + (cv ? c : 0) * nf;
     if (comb) {
         st_filt<D>(ro, ok, lane, Ao, C2, J1, bo, eo);
     } else if (ok) {
@@ -876,29 +952,29 @@ __global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const do
 }
 
 // out[c] = in[c] (x) in[c + stride] in time order; with `fixed` given: out[c] = in[c] (x) fixed for every c
-template <int D>
-__global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const double* in, double* out, const double* fixed) {
-    __shared__ double tl[4 * kPatch];
+template <typename Real, int D>
+__global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const Real* in, Real* out, const Real* fixed) {
+    __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
+    Real* patch = patch_init(tl, row);
     constexpr int dd = D * D, ns = 2 * D * D + D;
     const long c = (long)blockIdx.x * 4 + row;
     const bool lv = lane < D, cv = c < n, comb = cv && (fixed != nullptr || c + stride < n);
     const bool ok = lv && cv, okb = lv && comb;
-    double Ea[D], La[D], ga = 0.0;
+    Real Ea[D], La[D], ga = Real(0.0);
     zero<D>(Ea); zero<D>(La);
-    const double* ra = in + (cv ? c : 0) * ns;
+    const Real* ra = in + (cv ? c : 0) * ns;
     ld_rec_mat<D>(ra, ok, lane, Ea); ld_rec_mat<D>(ra + dd, ok, lane, La);
     if (ok) ga = ra[2 * dd + lane];
-    double Eb[D], Lb[D], gb = 0.0;
+    Real Eb[D], Lb[D], gb = Real(0.0);
 #pragma unroll
-    for (int i = 0; i < D; ++i) { Eb[i] = (i == lane) ? 1.0 : 0.0; Lb[i] = 0.0; }      // identity when passing through
-    const double* rb = fixed ? fixed : in + (comb ? c + stride : 0) * ns;
+    for (int i = 0; i < D; ++i) { Eb[i] = (i == lane) ? Real(1.0) : Real(0.0); Lb[i] = Real(0.0); }      // identity when passing through
+    const Real* rb = fixed ? fixed : in + (comb ? c + stride : 0) * ns;
     ld_rec_mat<D>(rb, okb, lane, Eb); ld_rec_mat<D>(rb + dd, okb, lane, Lb);
     if (okb) gb = rb[2 * dd + lane];
-    double Eo[D], Lo[D], go;
+    Real Eo[D], Lo[D], go;
     smth_combine_rc<D>(patch, lane, Ea, La, ga, Eb, Lb, gb, Eo, Lo, go);
-    double* ro = out + (cv ? c : 0) * ns;
+    Real* ro = out + (cv ? c : 0) * ns;
     if (comb) {
         st_rec_mat<D>(ro, ok, lane, Eo); st_rec_mat<D>(ro + dd, ok, lane, Lo);
         if (ok) ro[2 * dd + lane] = go;
@@ -915,16 +991,16 @@ __device__ __forceinline__ int symidx(int i, int j) { return i <= j ? (i * D - (
 
 // carry-in of segment `rank` (> 0): total_0 (x) ... (x) total_{rank-1}, written as a compact filter record.  One
 // wave; the four rows do the same work, row 0 stores.
-template <int D>
-__global__ __launch_bounds__(64) void rc_seg_carry_f(const double* gathered, int rank, int reclen, double* out) {
-    __shared__ double tl[4 * kPatch];
+template <typename Real, int D>
+__global__ __launch_bounds__(64) void rc_seg_carry_f(const Real* gathered, int rank, int reclen, Real* out) {
+    __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
+    Real* patch = patch_init(tl, row);
     constexpr int dd = D * D, SYM = D * (D + 1) / 2;
     const bool lv = lane < D;
-    auto load = [&](int j, double* A, double* C, double* J, double& b, double& e) {
-        const double* r = gathered + (long)j * reclen;
-        zero<D>(A); zero<D>(C); zero<D>(J); b = 0.0; e = 0.0;
+    auto load = [&](int j, Real* A, Real* C, Real* J, Real& b, Real& e) {
+        const Real* r = gathered + (long)j * reclen;
+        zero<D>(A); zero<D>(C); zero<D>(J); b = Real(0.0); e = Real(0.0);
         if (lv) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
@@ -936,10 +1012,10 @@ __global__ __launch_bounds__(64) void rc_seg_carry_f(const double* gathered, int
             e = r[dd + D + 2 * SYM + lane];
         }
     };
-    double A1[D], C1[D], J1[D], b1, e1;
+    Real A1[D], C1[D], J1[D], b1, e1;
     load(0, A1, C1, J1, b1, e1);
     for (int j = 1; j < rank; ++j) {
-        double A2[D], C2[D], J2[D], b2, e2, Ao[D], bo, eo;
+        Real A2[D], C2[D], J2[D], b2, e2, Ao[D], bo, eo;
         load(j, A2, C2, J2, b2, e2);
         filt_combine_rc<D>(patch, lane, A1, C1, J1, b1, e1, A2, C2, J2, b2, e2, Ao, bo, eo);
         copy<D>(A1, Ao); copy<D>(C1, C2);       // J1 already holds the result's J
@@ -949,26 +1025,26 @@ __global__ __launch_bounds__(64) void rc_seg_carry_f(const double* gathered, int
 }
 
 // what follows segment `rank` (< nranks - 1): total_{rank+1} (x) ... (x) total_{nranks-1} as a compact smoother record
-template <int D>
-__global__ __launch_bounds__(64) void rc_seg_carry_s(const double* gathered, int rank, int nranks, int reclen, double* out) {
-    __shared__ double tl[4 * kPatch];
+template <typename Real, int D>
+__global__ __launch_bounds__(64) void rc_seg_carry_s(const Real* gathered, int rank, int nranks, int reclen, Real* out) {
+    __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    double* patch = patch_init(tl, row);
+    Real* patch = patch_init(tl, row);
     constexpr int dd = D * D;
     const bool lv = lane < D;
-    auto load = [&](int j, double* E, double* L, double& g) {
-        const double* r = gathered + (long)j * reclen;
-        zero<D>(E); zero<D>(L); g = 0.0;
+    auto load = [&](int j, Real* E, Real* L, Real& g) {
+        const Real* r = gathered + (long)j * reclen;
+        zero<D>(E); zero<D>(L); g = Real(0.0);
         if (lv) {
 #pragma unroll
             for (int i = 0; i < D; ++i) { E[i] = r[i * D + lane]; L[i] = r[dd + D + symidx<D>(i, lane)]; }
             g = r[dd + lane];
         }
     };
-    double Ea[D], La[D], ga;
+    Real Ea[D], La[D], ga;
     load(rank + 1, Ea, La, ga);
     for (int j = rank + 2; j < nranks; ++j) {
-        double Eb[D], Lb[D], gb, Eo[D], Lo[D], go;
+        Real Eb[D], Lb[D], gb, Eo[D], Lo[D], go;
         load(j, Eb, Lb, gb);
         smth_combine_rc<D>(patch, lane, Ea, La, ga, Eb, Lb, gb, Eo, Lo, go);
         copy<D>(Ea, Eo); copy<D>(La, Lo); ga = go;
@@ -1104,31 +1180,40 @@ __global__ __launch_bounds__(64) void rc_discretise(long N, int per, const doubl
 // ---- host side: the level-1 launches of one instantiation ---------------------------------------------
 // phase 0: reduce, 1: apply + smoothing elements, 2: apply only, 3: smoother, 4: smoother writing projections,
 // 5: smoothing elements from given filtered moments (stand-alone pks)
-template <int D>
-int launch_rc_level1(pgps_ctx* ctx, const RcArgs& a, int phase) {
+template <typename Real, int D>
+int launch_rc_level1(pgps_ctx* ctx, const RcArgsT<Real>& a, int phase) {
     const dim3 blk(64), g1((unsigned)((a.nchunk + 3) / 4), (unsigned)(a.batch > 1 ? a.batch : 1));
+    const bool st = a.store_f != 0;
     switch (phase) {
-        case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_reduce1<D>, g1, blk, 0u, a); break;
+        case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_reduce1<Real, D>, g1, blk, 0u, a); break;
         case 1:
-            if (a.implicit_q & 1) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, true, true>, g1, blk, 0u, a);
-            else timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, true>, g1, blk, 0u, a);
+            if (a.implicit_q & 1) {
+                if (st) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, true, true>, g1, blk, 0u, a);
+                else timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, true, false>, g1, blk, 0u, a);
+            } else {
+                if (st) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, false, true>, g1, blk, 0u, a);
+                else timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, false, false>, g1, blk, 0u, a);
+            }
             break;
-        case 2: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<D, false>, g1, blk, 0u, a); break;
-        case 3: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D, false>, g1, blk, 0u, a); break;
-        case 5: timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_selem1<D>, g1, blk, 0u, a); break;
-        default: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<D, true>, g1, blk, 0u, a); break;
+        case 2:
+            if (st) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, false, false, true>, g1, blk, 0u, a);
+            else timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, false, false, false>, g1, blk, 0u, a);
+            break;
+        case 3: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<Real, D, false>, g1, blk, 0u, a); break;
+        case 5: timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_selem1<Real, D>, g1, blk, 0u, a); break;
+        default: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc_smooth1<Real, D, true>, g1, blk, 0u, a); break;
     }
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }
 
 // one Kogge-Stone step over n records: which = 0 filter totals (prefix), 1 smoothing totals (suffix)
-template <int D>
-int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const double* in, double* out, int batch, long bstride,
-                 const double* fixed) {
+template <typename Real, int D>
+int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const Real* in, Real* out, int batch, long bstride,
+                 const Real* fixed) {
     const dim3 blk(64), g((unsigned)((n + 3) / 4), (unsigned)batch);
-    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<D>, g, blk, 0u, n, stride, in, out, bstride, fixed);
-    else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<D>, g, blk, 0u, n, stride, in, out, fixed);
+    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<Real, D>, g, blk, 0u, n, stride, in, out, bstride, fixed);
+    else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<Real, D>, g, blk, 0u, n, stride, in, out, fixed);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }
@@ -1145,10 +1230,10 @@ int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, c
 }
 
 // carry records of a segment from the gathered packed totals: which = 0 carry-in (filter), 1 carry-back (smoother)
-template <int D>
-int launch_rc_seg_carry(pgps_ctx* ctx, int which, const double* gathered, int rank, int nranks, int reclen, double* out) {
-    if (which == 0) hipLaunchKernelGGL(rc_seg_carry_f<D>, dim3(1), dim3(64), 0, ctx->stream, gathered, rank, reclen, out);
-    else hipLaunchKernelGGL(rc_seg_carry_s<D>, dim3(1), dim3(64), 0, ctx->stream, gathered, rank, nranks, reclen, out);
+template <typename Real, int D>
+int launch_rc_seg_carry(pgps_ctx* ctx, int which, const Real* gathered, int rank, int nranks, int reclen, Real* out) {
+    if (which == 0) hipLaunchKernelGGL((rc_seg_carry_f<Real, D>), dim3(1), dim3(64), 0, ctx->stream, gathered, rank, reclen, out);
+    else hipLaunchKernelGGL((rc_seg_carry_s<Real, D>), dim3(1), dim3(64), 0, ctx->stream, gathered, rank, nranks, reclen, out);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

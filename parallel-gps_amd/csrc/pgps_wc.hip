@@ -1360,9 +1360,10 @@ static __global__ __launch_bounds__(1024) void ll_finalize(const double* llpart,
     }
 }
 
-static int level1(pgps_ctx* ctx, int d, const RcArgs& a, int phase) {
+template <typename Real>
+static int level1(pgps_ctx* ctx, int d, const RcArgsT<Real>& a, int phase) {
     switch (d) {
-#define PGPS_RC_CASE(DV) case DV: return launch_rc_level1<DV>(ctx, a, phase);
+#define PGPS_RC_CASE(DV) case DV: return launch_rc_level1<Real, DV>(ctx, a, phase);
         PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
         PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
         PGPS_RC_CASE(15) PGPS_RC_CASE(16)
@@ -1371,10 +1372,11 @@ static int level1(pgps_ctx* ctx, int d, const RcArgs& a, int phase) {
     return PGPS_E_UNSUPPORTED_DIM;
 }
 
-static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const double* in, double* out, int batch = 1,
-                   long bstride = 0, const double* fixed = nullptr) {
+template <typename Real>
+static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const Real* in, Real* out, int batch = 1,
+                   long bstride = 0, const Real* fixed = nullptr) {
     switch (d) {
-#define PGPS_RC_CASE(DV) case DV: return launch_rc_ks<DV>(ctx, which, n, stride, in, out, batch, bstride, fixed);
+#define PGPS_RC_CASE(DV) case DV: return launch_rc_ks<Real, DV>(ctx, which, n, stride, in, out, batch, bstride, fixed);
         PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
         PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
         PGPS_RC_CASE(15) PGPS_RC_CASE(16)
@@ -1383,9 +1385,10 @@ static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const d
     return PGPS_E_UNSUPPORTED_DIM;
 }
 
-static int seg_carry(pgps_ctx* ctx, int d, int which, const double* gathered, int rank, int nranks, int reclen, double* out) {
+template <typename Real>
+static int seg_carry(pgps_ctx* ctx, int d, int which, const Real* gathered, int rank, int nranks, int reclen, Real* out) {
     switch (d) {
-#define PGPS_RC_CASE(DV) case DV: return launch_rc_seg_carry<DV>(ctx, which, gathered, rank, nranks, reclen, out);
+#define PGPS_RC_CASE(DV) case DV: return launch_rc_seg_carry<Real, DV>(ctx, which, gathered, rank, nranks, reclen, out);
         PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
         PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
         PGPS_RC_CASE(15) PGPS_RC_CASE(16)
@@ -1398,7 +1401,8 @@ __host__ __device__ inline int sym_index(int d, int i, int j) {
     return i <= j ? (i * d - (i * (i - 1)) / 2 + (j - i)) : (j * d - (j * (j - 1)) / 2 + (i - j));
 }
 // this segment's filter record [A | b | C sym | J sym | eta | F_0 | Q_0] from the compact total [A | C | J | b | eta]
-static __global__ __launch_bounds__(256) void seg_pack_f(int d, const double* tot, const double* Fs, const double* Qs, double* rec) {
+template <typename Real>
+static __global__ __launch_bounds__(256) void seg_pack_f(int d, const Real* tot, const Real* Fs, const Real* Qs, Real* rec) {
     const int dd = d * d, sym = d * (d + 1) / 2;
     for (int e = threadIdx.x; e < dd; e += 256) {
         const int i = e / d, j = e % d;
@@ -1413,8 +1417,9 @@ static __global__ __launch_bounds__(256) void seg_pack_f(int d, const double* to
     for (int e = threadIdx.x; e < d; e += 256) { rec[dd + e] = tot[3 * dd + e]; rec[dd + d + 2 * sym + e] = tot[3 * dd + d + e]; }
 }
 // this segment's smoother record [E | g | L sym | pad | ll partial] from the compact total [E | L | g]
-static __global__ __launch_bounds__(256) void seg_pack_s(int d, const double* tot, const double* llpart, long nchunk, int pad,
-                                                         double* rec) {
+template <typename Real>
+static __global__ __launch_bounds__(256) void seg_pack_s(int d, const Real* tot, const double* llpart, long nchunk, int pad,
+                                                         Real* rec) {
     __shared__ double part[4];
     const int dd = d * d;
     for (int e = threadIdx.x; e < dd; e += 256) {
@@ -1428,25 +1433,29 @@ static __global__ __launch_bounds__(256) void seg_pack_s(int d, const double* to
     t = wc::wave_sum(t);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0) rec[pad] = part[0] + part[1] + part[2] + part[3];
+    // the log-likelihood partial travels as a double whatever the record's type (two floats' worth of room: pad is even)
+    if (threadIdx.x == 0) *reinterpret_cast<double*>(rec + pad) = part[0] + part[1] + part[2] + part[3];
 }
-static __global__ void seg_ll_sum(const double* gathered_s, int nranks, int reclen, int pad, double* ll) {
+template <typename Real>
+static __global__ void seg_ll_sum(const Real* gathered_s, int nranks, int reclen, int pad, double* ll) {
     if (threadIdx.x == 0) {
         double t = 0.0;
-        for (int r = 0; r < nranks; ++r) t += gathered_s[(long)r * reclen + pad];
+        for (int r = 0; r < nranks; ++r) t += *reinterpret_cast<const double*>(gathered_s + (long)r * reclen + pad);
         *ll = t;
     }
 }
 
+template <typename Real>
 struct SegInfo {
     int rank, nranks;
-    double* rec_f; const double* gathered_f;
-    double* rec_s; const double* gathered_s;
-    double *carry_rec, *cb_rec;         // scratch: compact carry-in / carry-back records
+    Real* rec_f; const Real* gathered_f;
+    Real* rec_s; const Real* gathered_s;
+    Real *carry_rec, *cb_rec;         // scratch: compact carry-in / carry-back records
 };
 
 // number of Kogge-Stone steps over n records, and the buffer the result ends up in
-static inline double* ks_result(long n, double* A, double* B) {
+template <typename Real>
+static inline Real* ks_result(long n, Real* A, Real* B) {
     int steps = 0;
     for (long s = 1; s < n; s *= 2) ++steps;
     return (steps & 1) ? B : A;
@@ -1454,8 +1463,9 @@ static inline double* ks_result(long n, double* A, double* B) {
 
 // One phase of the segment protocol (pssgp/distributed.py): scratch (chain totals, their scans, the stored smoothing
 // elements) stays in the context's workspace between the three calls of a pass.
-static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, double* aggB, double* saggA, double* saggB,
-                       const SegInfo& sg, double* ll) {
+template <typename Real>
+static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgsT<Real> a, Mode mode, Real* aggA, Real* aggB, Real* saggA, Real* saggB,
+                       const SegInfo<Real>& sg, double* ll) {
     int rcode;
     const int nf = wc::nfilt(d), ns = wc::nsmth(d);
     const int rf = seg_rec_f_len(d), rs = seg_rec_s_len(d), pad = seg_rec_s_pad(d);
@@ -1465,22 +1475,22 @@ static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, 
     if (mode == MODE_SEG_REDUCE) {
         a.agg1 = aggA;
         if ((rcode = level1(ctx, d, a, 0))) return rcode;
-        double *src = aggA, *dst = aggB;
+        Real *src = aggA, *dst = aggB;
         for (long s = 1; s < a.nchunk; s *= 2) {
             if ((rcode = ks_step(ctx, d, 0, a.nchunk, s, src, dst))) return rcode;
-            double* t = src; src = dst; dst = t;
+            Real* t = src; src = dst; dst = t;
         }
-        hipLaunchKernelGGL(seg_pack_f, dim3(1), dim3(256), 0, ctx->stream, d, (const double*)(src + (a.nchunk - 1) * nf), a.Fs,
+        hipLaunchKernelGGL(seg_pack_f<Real>, dim3(1), dim3(256), 0, ctx->stream, d, (const Real*)(src + (a.nchunk - 1) * nf), a.Fs,
                            a.Qs, sg.rec_f);
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
     }
     if (mode == MODE_SEG_FILTER) {
-        double* pre = ks_result(a.nchunk, aggA, aggB);
+        Real* pre = ks_result(a.nchunk, aggA, aggB);
         if (!a.seg_first) {
             // everything before this segment, combined into every local prefix (and the entry state of chain 0)
             if ((rcode = seg_carry(ctx, d, 0, sg.gathered_f, sg.rank, sg.nranks, rf, sg.carry_rec))) return rcode;
-            double* other = pre == aggA ? aggB : aggA;
+            Real* other = pre == aggA ? aggB : aggA;
             if ((rcode = ks_step(ctx, d, 0, a.nchunk, 0, pre, other, 1, 0, sg.carry_rec))) return rcode;
             pre = other;
             a.carry = sg.carry_rec;
@@ -1492,54 +1502,55 @@ static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, 
         a.pre = pre;
         a.sagg1 = saggA;
         if ((rcode = level1(ctx, d, a, 1))) return rcode;
-        double *src = saggA, *dst = saggB;
+        Real *src = saggA, *dst = saggB;
         for (long s = 1; s < a.nchunk; s *= 2) {
             if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, src, dst))) return rcode;
-            double* t = src; src = dst; dst = t;
+            Real* t = src; src = dst; dst = t;
         }
-        hipLaunchKernelGGL(seg_pack_s, dim3(1), dim3(256), 0, ctx->stream, d, (const double*)src, (const double*)a.llpart,
+        hipLaunchKernelGGL(seg_pack_s<Real>, dim3(1), dim3(256), 0, ctx->stream, d, (const Real*)src, (const double*)a.llpart,
                            (long)a.nchunk, pad, sg.rec_s);
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
     }
     // MODE_SEG_SMOOTHER
-    double* suf = ks_result(a.nchunk, saggA, saggB);
+    Real* suf = ks_result(a.nchunk, saggA, saggB);
     if (!a.seg_last) {
         if ((rcode = seg_carry(ctx, d, 1, sg.gathered_s, sg.rank, sg.nranks, rs, sg.cb_rec))) return rcode;
-        double* other = suf == saggA ? saggB : saggA;
+        Real* other = suf == saggA ? saggB : saggA;
         if ((rcode = ks_step(ctx, d, 1, a.nchunk, 0, suf, other, 1, 0, sg.cb_rec))) return rcode;
         suf = other;
         a.carry_back = sg.cb_rec;
     }
     a.suf = suf;
     if ((rcode = level1(ctx, d, a, 3))) return rcode;
-    if (ll) hipLaunchKernelGGL(seg_ll_sum, dim3(1), dim3(64), 0, ctx->stream, sg.gathered_s, sg.nranks, rs, pad, ll);
+    if (ll) hipLaunchKernelGGL(seg_ll_sum<Real>, dim3(1), dim3(64), 0, ctx->stream, sg.gathered_s, sg.nranks, rs, pad, ll);
     HIPCHK(ctx, hipGetLastError());
     (void)ns;
     return PGPS_OK;
 }
 
-static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, double* aggB, double* saggA, double* saggB,
+template <typename Real>
+static int scan_rc(pgps_ctx* ctx, int d, RcArgsT<Real> a, Mode mode, Real* aggA, Real* aggB, Real* saggA, Real* saggB,
                    double* ll) {
     int rcode;
     if (mode == MODE_PKS) {                     // stand-alone smoother: elements from the given filtered moments
         a.sagg1 = saggA;
         if ((rcode = level1(ctx, d, a, 5))) return rcode;
-        double *ssrc = saggA, *sdst = saggB;
+        Real *ssrc = saggA, *sdst = saggB;
         for (long s = 1; s < a.nchunk; s *= 2) {
             if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, ssrc, sdst))) return rcode;
-            double* t = ssrc; ssrc = sdst; sdst = t;
+            Real* t = ssrc; ssrc = sdst; sdst = t;
         }
         a.suf = ssrc;
         return level1(ctx, d, a, 3);
     }
     a.agg1 = aggA;
     if ((rcode = level1(ctx, d, a, 0))) return rcode;
-    double *src = aggA, *dst = aggB;
+    Real *src = aggA, *dst = aggB;
     const int nb = a.batch > 1 ? a.batch : 1;
     for (long s = 1; s < a.nchunk; s *= 2) {
         if ((rcode = ks_step(ctx, d, 0, a.nchunk, s, src, dst, nb, a.bs_agg))) return rcode;
-        double* t = src; src = dst; dst = t;
+        Real* t = src; src = dst; dst = t;
     }
     a.pre = src;
     if (mode == MODE_PKFS) {
@@ -1548,7 +1559,7 @@ static int scan_rc(pgps_ctx* ctx, int d, RcArgs a, Mode mode, double* aggA, doub
         src = saggA; dst = saggB;
         for (long s = 1; s < a.nchunk; s *= 2) {
             if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, src, dst))) return rcode;
-            double* t = src; src = dst; dst = t;
+            Real* t = src; src = dst; dst = t;
         }
         a.suf = src;
         if ((rcode = level1(ctx, d, a, a.qslot ? 4 : 3))) return rcode;
@@ -1579,16 +1590,20 @@ int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* 
 
 static inline size_t rc_align(size_t x) { return (x + 255) / 256 * 256; }
 
-static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, int store_f, const int* qslot, double* pmean,
-                         double* pvar, int batch = 1, long bs_model = 0);
+template <typename Real>
+static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode, int store_f, const int* qslot, Real* pmean,
+                         Real* pvar, int batch = 1, long bs_model = 0);
 
-// fp64, 2 <= d <= 16, pkf / pkfs on one device
-int launch_scan_rc(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode) {
-    return scan_rc_entry(ctx, sa, d, mode, 1, nullptr, nullptr, nullptr);
+// 2 <= d <= 16, pkf / pks / pkfs on one device and the three segment phases
+template <typename Real>
+int launch_scan_rc(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode) {
+    return scan_rc_entry<Real>(ctx, sa, d, mode, 1, nullptr, nullptr, nullptr);
 }
+template int launch_scan_rc<double>(pgps_ctx*, ScanArgs<double>, int, Mode);
+template int launch_scan_rc<float>(pgps_ctx*, ScanArgs<float>, int, Mode);
 int launch_scan_rc_proj(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, const int* qslot, double* pmean, double* pvar) {
     if (mode == MODE_PKFS && (!qslot || !pmean || !pvar)) return PGPS_E_INVALID;
-    return scan_rc_entry(ctx, sa, d, mode, 0, mode == MODE_PKFS ? qslot : nullptr, pmean, pvar);
+    return scan_rc_entry<double>(ctx, sa, d, mode, 0, mode == MODE_PKFS ? qslot : nullptr, pmean, pvar);
 }
 
 int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* table, long bs_model, const double* Fs,
@@ -1601,15 +1616,16 @@ int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* ta
     a.ll = ll;
     // R of model b sits at table[b * bs_model + 2 dd + d]; scan_rc_entry turns that into RcArgs::Rs
     a.carry_in = table + 2 * dd + d;
-    return scan_rc_entry(ctx, a, d, MODE_PKF, 0, nullptr, nullptr, nullptr, batch, bs_model);
+    return scan_rc_entry<double>(ctx, a, d, MODE_PKF, 0, nullptr, nullptr, nullptr, batch, bs_model);
 }
 
-static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, int store_f, const int* qslot, double* pmean,
-                         double* pvar, int batch, long bs_model) {
+template <typename Real>
+static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode, int store_f, const int* qslot, Real* pmean,
+                         Real* pvar, int batch, long bs_model) {
     const bool seg = mode == MODE_SEG_REDUCE || mode == MODE_SEG_FILTER || mode == MODE_SEG_SMOOTHER;
     if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    rc::RcArgs a{};
+    rc::RcArgsT<Real> a{};
     a.N = sa.N;
     if (ctx->chunk > 0) {
         a.Lw = ctx->chunk;
@@ -1649,31 +1665,31 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, i
         a.Rs = sa.carry_in;
     }
     size_t off = 0;
-    const size_t o_aggA = off;  off = rc_align(off + nbm * nc * nf * sizeof(double));
-    const size_t o_aggB = off;  off = rc_align(off + nbm * nc * nf * sizeof(double));
-    const size_t o_sagA = off;  off = rc_align(off + nc * ns * sizeof(double));
-    const size_t o_sagB = off;  off = rc_align(off + nc * ns * sizeof(double));
+    const size_t o_aggA = off;  off = rc_align(off + nbm * nc * nf * sizeof(Real));
+    const size_t o_aggB = off;  off = rc_align(off + nbm * nc * nf * sizeof(Real));
+    const size_t o_sagA = off;  off = rc_align(off + nc * ns * sizeof(Real));
+    const size_t o_sagB = off;  off = rc_align(off + nc * ns * sizeof(Real));
     const size_t o_ll = off;    off = rc_align(off + nbm * nc * sizeof(double));
-    const size_t o_cf = off;    off = rc_align(off + nf * sizeof(double));
-    const size_t o_cs = off;    off = rc_align(off + ns * sizeof(double));
-    const size_t o_L = off;     if (mode != MODE_PKF) off = rc_align(off + (size_t)sa.N * dd * sizeof(double));
+    const size_t o_cf = off;    off = rc_align(off + nf * sizeof(Real));
+    const size_t o_cs = off;    off = rc_align(off + ns * sizeof(Real));
+    const size_t o_L = off;     if (mode != MODE_PKF) off = rc_align(off + (size_t)sa.N * dd * sizeof(Real));
     // segments: the smoothing elements wait in scratch until the smoother phase brings sms / sPs
-    const size_t o_E = off;     if (seg) off = rc_align(off + (size_t)sa.N * dd * sizeof(double));
-    const size_t o_g = off;     if (seg) off = rc_align(off + (size_t)sa.N * d * sizeof(double));
+    const size_t o_E = off;     if (seg) off = rc_align(off + (size_t)sa.N * dd * sizeof(Real));
+    const size_t o_g = off;     if (seg) off = rc_align(off + (size_t)sa.N * d * sizeof(Real));
     int rcode = ensure(ctx, ctx->ws, off);
     if (rcode) return rcode;
     char* base = (char*)ctx->ws.p;
     a.llpart = (double*)(base + o_ll);
-    a.Lws = (double*)(base + o_L);
-    a.Es = seg ? (double*)(base + o_E) : a.sPs;
-    a.gs = seg ? (double*)(base + o_g) : a.sms;
-    double* aggA = (double*)(base + o_aggA); double* aggB = (double*)(base + o_aggB);
-    double* sagA = (double*)(base + o_sagA); double* sagB = (double*)(base + o_sagB);
+    a.Lws = (Real*)(base + o_L);
+    a.Es = seg ? (Real*)(base + o_E) : a.sPs;
+    a.gs = seg ? (Real*)(base + o_g) : a.sms;
+    Real* aggA = (Real*)(base + o_aggA); Real* aggB = (Real*)(base + o_aggB);
+    Real* sagA = (Real*)(base + o_sagA); Real* sagB = (Real*)(base + o_sagB);
     if (seg) {
-        rc::SegInfo sg{};
+        rc::SegInfo<Real> sg{};
         sg.rank = sa.rank; sg.nranks = sa.nranks;
         sg.rec_f = sa.rec_f; sg.gathered_f = sa.gathered_f; sg.rec_s = sa.rec_s; sg.gathered_s = sa.gathered_s;
-        sg.carry_rec = (double*)(base + o_cf); sg.cb_rec = (double*)(base + o_cs);
+        sg.carry_rec = (Real*)(base + o_cf); sg.cb_rec = (Real*)(base + o_cs);
         return rc::scan_rc_seg(ctx, d, a, mode, aggA, aggB, sagA, sagB, sg, sa.ll);
     }
     return rc::scan_rc(ctx, d, a, mode, aggA, aggB, sagA, sagB, sa.ll);
