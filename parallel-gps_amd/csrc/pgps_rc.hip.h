@@ -106,8 +106,17 @@ __device__ __forceinline__ void rank1(Real* z, Id<Real> p, Id<Real> q) { Asm<Rea
 
 // xt = X^T through the row's LDS patch.  Patch rows >= D are zero (cleared once, never written), so lanes >= D
 // read zeros.
-template <int D, typename Real>
+constexpr int kTrDimMax = 8;                // fp32: in-register transposes up to this d (Asm<float, D>::tr)
+// INREG (fp32, d <= 8): d^2 DPP selects instead of the round trip through LDS.  Worth it only where many waves share a
+// SIMD -- measured at d = 6, fp32, 2^20 steps: rc_smooth1 (6 waves) 0.180 -> 0.152 ms, but rc_reduce1 / rc_apply1
+// (3-4 waves) 0.234 -> 0.276 / 0.350 -> 0.433 ms -- so only the smoother asks for it.
+template <int D, bool INREG = false, typename Real>
 __device__ __forceinline__ void transpose(const Real* x, Real* xt, Real* patch, int lane) {
+    if constexpr (INREG && sizeof(Real) == 4 && D <= kTrDimMax) {
+        zero<D>(xt);
+        Asm<Real, D>::tr(xt, x);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < D; ++i) patch[i * kLdT + lane] = x[i];
     sync();
@@ -115,13 +124,19 @@ __device__ __forceinline__ void transpose(const Real* x, Real* xt, Real* patch, 
     for (int i = 0; i < D; ++i) xt[i] = patch[lane * kLdT + i];
     sync();
 }
-template <int D, typename Real>
+template <int D, bool INREG = false, typename Real>
 __device__ __forceinline__ void symmetrise(Real* x, Real* patch, int lane) {
     Real xt[D];
-    transpose<D>(x, xt, patch, lane);
+    transpose<D, INREG>(x, xt, patch, lane);
 #pragma unroll
     for (int i = 0; i < D; ++i) x[i] = Real(0.5) * (x[i] + xt[i]);
 }
+// zero-initialised wave-private LDS area of `bytes` bytes (the WIDE slots: their last 16 bytes are the zeros that
+// lanes >= D read)
+__device__ __forceinline__ void lds_clear(char* p, int bytes) {
+    for (int e = threadIdx.x * 16; e < bytes; e += 64 * 16) *reinterpret_cast<float4*>(p + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <typename Real>
 __device__ __forceinline__ Real* patch_init(Real* tl, int row) {
     for (int e = threadIdx.x; e < 4 * kPatch; e += 64) tl[e] = Real(0.0);
@@ -193,6 +208,10 @@ struct GjStep {
 // so waiting for a load does not also wait for the younger stores of the step (a branch around a store makes the
 // count unknown at the join and every later wait a full `s_waitcnt vmcnt(0)`: measured, that drained the stores'
 // round trip into every time step).
+// The prefetch of the next step's inputs has no dependence on anything in the step, so the machine scheduler would sink
+// it to the end of the loop body (shortest live ranges) and expose the whole memory latency: fence it in.
+#define PGPS_RC_PIN() __builtin_amdgcn_sched_barrier(0)
+
 constexpr unsigned kOob = 0x7ffff000u;         // + any immediate offset: beyond every descriptor's range, no 32-bit wrap
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -237,12 +256,15 @@ struct Io {
     template <bool ROWL>
     static constexpr int step_bytes() { return ROWL ? (int)W : (int)W * D; }      // from register i to register i + 1
     // fast path: X <- the matrix (zeros in lanes >= D)
+    // (EXEC-masked global loads: range-checked buffer loads make every lane of the wave do address work, the
+    // out-of-range ones included -- measured on c5's rc_reduce1: 0.69 -> 0.91 ms)
     template <bool ROWL>
     __device__ __forceinline__ void mat_fast(const Real* base, Real* X) const {
-        const __amdgpu_buffer_rsrc_t r = make_rsrc(base, span_m);
-        const unsigned o = ROWL ? forw : foc;
+        if (lv) {
+            const char* p = reinterpret_cast<const char*>(base) + (ROWL ? orw : oc);
 #pragma unroll
-        for (int i = 0; i < D; ++i) buf_ld(r, o + (unsigned)(i * step_bytes<ROWL>()), X[i]);
+            for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const Real*>(p + i * step_bytes<ROWL>());
+        }
     }
     // general path: rows that are not `real` get dg * I.  One divergent if / else around the whole block, no
     // selects behind the loads (a select would wait for them on the spot).
@@ -258,7 +280,9 @@ struct Io {
         }
     }
     // fast path: x <- the vector element (zero in lanes >= D)
-    __device__ __forceinline__ void vec_fast(const Real* base, Real& x) const { buf_ld(make_rsrc(base, span_v), fov, x); }
+    __device__ __forceinline__ void vec_fast(const Real* base, Real& x) const {
+        if (lv) x = *reinterpret_cast<const Real*>(reinterpret_cast<const char*>(base) + ov);
+    }
     __device__ __forceinline__ Real vec(const Real* base, bool real) const {
         Real v = Real(0.0);
         if (lv && real) v = *reinterpret_cast<const Real*>(reinterpret_cast<const char*>(base) + ov);
@@ -281,6 +305,100 @@ struct Io {
     __device__ __forceinline__ void st_vec(Real* base, bool pred, Real x) const {
         if constexpr (FAST) buf_st(make_rsrc(base, span_v), fov, x);
         else if (lv && pred) *reinterpret_cast<Real*>(reinterpret_cast<char*>(base) + ov) = x;
+    }
+
+    // ---- WIDE path of the FAST bodies: whole records as 16-byte pieces, staged through wave-private LDS ------------
+    // The per-register accesses above move 4 rows x D scalars (96 .. 512 bytes) per memory instruction, and the level-1
+    // kernels issue 45 .. 70 of them per step: measured, their time is the memory pipeline's per-instruction cost
+    // (about 12 cycles + 0.11 cycles per byte per CU), not HBM bandwidth and not latency.  So the four rows' records
+    // of a step travel as 16-byte pieces -- piece q of the step belongs to row q / NPC and is handled by lane q % 64 of
+    // instruction q / 64: a full kilobyte per instruction -- into registers, from there into an LDS slot (row r at
+    // r * RECPAD), and the lanes read both layouts they need out of LDS (the second global read of F disappears too).
+    // Results take the same road back.  The loads of step s + 1 are issued right after step s's pieces have been
+    // committed to LDS, a whole step ahead of their use, at the price of NVW x 4 registers per matrix.
+    static constexpr int REC = D * D * (int)W;              // bytes of one matrix record
+    static constexpr int RECPAD = (REC + 15) / 16 * 16;
+    static constexpr int NPC = RECPAD / 16;                 // pieces per row (the last one may reach 8 bytes beyond)
+    static constexpr int NPF = REC / 16;                    // whole pieces per row
+    static constexpr int TAILB = REC % 16;                  // bytes of the tail piece of a row: 8 (odd d, fp64), 4 (odd d, fp32)
+    static constexpr bool TAIL = TAILB != 0;
+    static constexpr int NVW = (4 * NPC + 63) / 64;         // wide instructions per matrix and step
+    static constexpr int SLOT = NVW * 1024;                 // bytes of one LDS slot (whole instructions: no masking)
+    // rc_apply1: five slots (two inputs, three results) when four such waves plus their transpose patches fit a CU's LDS
+#ifdef PGPS_RC_NO_BATCH
+    static constexpr bool kBatchOut = false;
+#else
+    static constexpr bool kBatchOut = 5 * (SLOT + 16) + 4 * 16 * 17 * (int)W <= 40 * 1024;
+#endif
+    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+    unsigned wg[NVW], wgs[NVW], wtail;  // global byte offsets of this lane's pieces: loads / stores (out of range when
+                                        // there is no such piece; stores: also for the tail piece) / the 8-byte tail
+    unsigned lc, lr, ltail;             // LDS byte offsets of (0, lane) column layout, (lane, 0) row layout; tail
+    int tid;
+    __device__ __forceinline__ void init_wide(int row, int Lw, unsigned zero_off) {
+        tid = threadIdx.x & 63;
+        const unsigned pitch = (unsigned)Lw * (unsigned)REC;
+#pragma unroll
+        for (int v = 0; v < NVW; ++v) {
+            const int q = v * 64 + tid, r = q / NPC, idx = q % NPC;
+            const bool ok = q < 4 * NPC;
+            wg[v] = ok ? (unsigned)r * pitch + (unsigned)idx * 16u : kOob;
+            wgs[v] = (ok && idx < NPF) ? (unsigned)r * pitch + (unsigned)idx * 16u : kOob;
+        }
+        wtail = (TAIL && tid < 4) ? (unsigned)tid * pitch + (unsigned)NPF * 16u : kOob;
+        ltail = (unsigned)(tid & 3) * (unsigned)RECPAD + (unsigned)NPF * 16u;
+        // lanes >= D read the zeros at zero_off (relative to the slot) in both layouts: no select behind the LDS read
+        lc = lv ? (unsigned)row * (unsigned)RECPAD + (unsigned)lane * W : zero_off;
+        lr = lv ? (unsigned)row * (unsigned)RECPAD + (unsigned)(lane * D) * W : zero_off;
+    }
+    __device__ __forceinline__ void wide_load(const Real* base, V4* r) const {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, span_m + 16u);    // (+16: the last piece of a TAIL record)
+#pragma unroll
+        for (int v = 0; v < NVW; ++v) r[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wg[v], 0, 0);
+    }
+    __device__ __forceinline__ void wide_commit(char* slot, const V4* r) const {
+#pragma unroll
+        for (int v = 0; v < NVW; ++v) *reinterpret_cast<V4*>(slot + (v * 64 + tid) * 16) = r[v];
+    }
+    // X <- the slot's matrix in column (ROWL = false) or row layout; lanes >= D get zeros.  `stride0` = 0 for them.
+    template <bool ROWL>
+    __device__ __forceinline__ void lds_get(const char* slot, Real* X) const {
+        const char* p = slot + (ROWL ? lr : lc);
+        const int st = lv ? step_bytes<ROWL>() : 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const Real*>(p + i * st);
+    }
+    // results: the slot <- X (column layout) ... (several slots may be filled before one sync() and their drains)
+    __device__ __forceinline__ void lds_put(char* slot, const Real* X) const {
+        if (lv) {
+            char* p = slot + lc;
+#pragma unroll
+            for (int i = 0; i < D; ++i) *reinterpret_cast<Real*>(p + i * (int)W * D) = X[i];
+        }
+    }
+    // ... and, after a sync(), the slot's four records out as 16-byte pieces (+ the 8-byte tails)
+    __device__ __forceinline__ void wide_drain(Real* base, const char* slot) const {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, span_m);
+#pragma unroll
+        for (int v = 0; v < NVW; ++v) {
+            const V4 x = *reinterpret_cast<const V4*>(slot + (v * 64 + tid) * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(x, rs, (int)wgs[v], 0, 0);
+        }
+        static_assert(TAILB == 0 || TAILB == 4 || TAILB == 8, "a record is a whole number of scalars, d^2 of them");
+        if constexpr (TAILB == 8) {
+            using U2 = __attribute__((ext_vector_type(2))) unsigned int;
+            const U2 t = *reinterpret_cast<const U2*>(slot + ltail);
+            __builtin_amdgcn_raw_buffer_store_b64(t, rs, (int)wtail, 0, 0);
+        } else if constexpr (TAILB == 4) {
+            const unsigned int t = *reinterpret_cast<const unsigned int*>(slot + ltail);
+            __builtin_amdgcn_raw_buffer_store_b32(t, rs, (int)wtail, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void wide_store(Real* base, char* slot, const Real* X) const {
+        sync();                                             // earlier readers of the slot are done
+        lds_put(slot, X);
+        sync();
+        wide_drain(base, slot);
     }
 };
 
@@ -312,7 +430,7 @@ __device__ __forceinline__ RcArgsT<Real> model_view(const RcArgsT<Real>& a) {
 // level 1: reduce -- filt_extend over the chunk (pgps_math.h filt_extend, parallel.py:46-72,100-118)
 // ====================================================================================================
 template <typename Real, int D, bool FAST>
-__device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch, int lane, int row) {
+__device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;        // row 0's first step
     const long c = (long)blockIdx.x * 4 + row;
@@ -341,25 +459,44 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
 #pragma unroll
     for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? Real(0.5) * (a.P0[i * D + lane] + a.P0[lane * D + i]) : Real(0.0);
     // inputs of this row's step kw + row Lw + s; steps outside the chunk and step 0 of the series run as F = I, Q = 0
-    auto load = [&](int s) {
+    auto load = [&](int s) {                    // the general body's per-register loads
         const long ku = kw + s, k = k0 + s;
-        if (FAST) {
-            io.template mat_fast<false>(a.Fs + ku * dd, Fc);
-            io.template mat_fast<true>(a.Fs + ku * dd, Fr);
-            if (!impq) io.template mat_fast<false>(a.Qs + ku * dd, Q);
-            y = a.ys[k];
-        } else {
-            const long kc = ku < a.N ? ku : a.N - 1;
-            const bool real = k < k1 && !(k == 0 && a.seg_first);
-            io.template mat_slow<false>(a.Fs + kc * dd, real, Real(1.0), Fc);
-            io.template mat_slow<true>(a.Fs + kc * dd, real, Real(1.0), Fr);
-            if (!impq) io.template mat_slow<false>(a.Qs + kc * dd, real, Real(0.0), Q);
-            y = __builtin_nan("");
-            if (k < k1) y = a.ys[k];
-        }
+        const long kc = ku < a.N ? ku : a.N - 1;
+        const bool real = k < k1 && !(k == 0 && a.seg_first);
+        io.template mat_slow<false>(a.Fs + kc * dd, real, Real(1.0), Fc);
+        io.template mat_slow<true>(a.Fs + kc * dd, real, Real(1.0), Fr);
+        if (!impq) io.template mat_slow<false>(a.Qs + kc * dd, real, Real(0.0), Q);
+        y = __builtin_nan("");
+        if (k < k1) y = a.ys[k];
     };
-    load(0);
+    // FAST: whole records as 16-byte pieces through LDS (Io, WIDE path), requested a whole step ahead
+    using IOT = Io<D, Real>;
+    typename IOT::V4 pF[IOT::NVW], pQ[IOT::NVW];
+    Real ny = Real(0.0);
+    char* slotF = wslots;
+    char* slotQ = wslots + (IOT::SLOT + 16);
+    auto prefetch = [&](int s) {
+        io.wide_load(a.Fs + (kw + s) * dd, pF);
+        if (!impq) io.wide_load(a.Qs + (kw + s) * dd, pQ);
+        ny = a.ys[k0 + s];
+    };
+    auto take = [&](int s) {                    // step s's pieces into LDS, step s + 1's on their way, both layouts out
+        sync();
+        io.wide_commit(slotF, pF);
+        if (!impq) io.wide_commit(slotQ, pQ);
+        y = ny;
+        sync();
+        PGPS_RC_PIN();
+        prefetch(s + 1);                        // (one step beyond the chunk at the end: inside the series for a FAST wave)
+        PGPS_RC_PIN();
+        io.template lds_get<false>(slotF, Fc);
+        io.template lds_get<true>(slotF, Fr);
+        if (!impq) io.template lds_get<false>(slotQ, Q);
+    };
+    if constexpr (FAST) { io.init_wide(row, a.Lw, (unsigned)IOT::SLOT); prefetch(0); }
+    else load(0);
     for (int s = 0; s < a.Lw; ++s) {
+        if constexpr (FAST) take(s);
         Real Ap[D], FC[D], Cp[D];
         zero<D>(Ap); mm<D>(Ap, Fc, A);
         if (impq) {
@@ -375,7 +512,9 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
         mm<D>(Cp, FC, Fr);
         const Real bp = mvr<D>(Fr, b, Real(0.0));
         const Real yk = y;
-        if (s + 1 < a.Lw) load(s + 1);          // next step's inputs: their registers are free from here on
+        if constexpr (!FAST) {
+            if (s + 1 < a.Lw) load(s + 1);      // next step's inputs: their registers are free from here on
+        }
         symmetrise<D>(Cp, patch, lane);
         const Real u = dot_h<D>(Cp, h), v = dot_h<D>(Ap, h);
         const Real S = mvr<D>(h, u, a.R), hb = mvr<D>(h, bp, Real(0.0));
@@ -401,10 +540,12 @@ template <typename Real, int D>
 __global__ __launch_bounds__(64) void rc_reduce1(const RcArgsT<Real> a0) {
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    __shared__ __attribute__((aligned(16))) char wslots[2 * (Io<D, Real>::SLOT + 16)];
+    lds_clear(wslots, (int)sizeof(wslots));
     Real* patch = patch_init(tl, row);
     const RcArgsT<Real> a = model_view(a0);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<Real, D, true>(a, patch, lane, row);
-    else reduce1_body<Real, D, false>(a, patch, lane, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<Real, D, true>(a, patch, wslots, lane, row);
+    else reduce1_body<Real, D, false>(a, patch, wslots, lane, row);
 }
 
 // ====================================================================================================
@@ -412,7 +553,7 @@ __global__ __launch_bounds__(64) void rc_reduce1(const RcArgsT<Real> a0) {
 // (kf_step / smth_element / smth_combine of pgps_math.h; parallel.py:135-151, 155-184)
 // ====================================================================================================
 template <typename Real, int D, bool SMOOTH, bool FAST, bool IMPQS, bool STORE>
-__device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch, int lane, int row) {
+__device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
@@ -451,14 +592,9 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
     for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? Real(0.5) * (a.P0[i * D + lane] + a.P0[lane * D + i]) : Real(0.0);
     // steps at or beyond N run with F = 0, Q = I: the element built from them is (0, m, P), i.e. the last
     // element of the series (parallel.py:155-156), and a total whose E is 0 absorbs whatever follows unchanged
-    auto load = [&](int s) {
+    auto load = [&](int s) {                    // the general body's per-register loads
         const long ku = kw + s, k = k0 + s;
-        if (FAST) {
-            io.template mat_fast<false>(a.Fs + ku * dd, Fc);
-            io.template mat_fast<true>(a.Fs + ku * dd, Fr);
-            if (!impq) io.template mat_fast<false>(a.Qs + ku * dd, Q);
-            y = a.ys[k];
-        } else {
+        {
             const long kc = ku < a.N ? ku : a.N - 1;
             // step N of a segment that is not the last: the first step of the next rank (halo), out of its record
             const bool hal = (k == a.N) && a.halo_F != nullptr;
@@ -472,7 +608,45 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
             if (s < a.Lw && k < k1) y = a.ys[k];
         }
     };
-    load(0);
+    // FAST: whole records as 16-byte pieces through LDS (Io, WIDE path), requested a whole step ahead; the results
+    // leave the same way through a third slot
+    using IOT = Io<D, Real>;
+    typename IOT::V4 pF[IOT::NVW], pQ[IOT::NVW];
+    Real ny = Real(0.0);
+    char* slotF = wslots;
+    char* slotQ = wslots + (IOT::SLOT + 16);
+    // results: E, L of the step before, P of this step.  BATCH (the LDS of four waves per CU allows five slots): written
+    // as they are made, drained together at the end of the step -- one LDS round trip for the three; otherwise one
+    // slot, each result out on the spot
+    constexpr bool BATCH = IOT::kBatchOut;
+    char* slotE = wslots + 2 * (IOT::SLOT + 16);
+    char* slotL = wslots + (BATCH ? 3 : 2) * (IOT::SLOT + 16);
+    char* slotP = wslots + (BATCH ? 4 : 2) * (IOT::SLOT + 16);
+    auto prefetch = [&](int s) {
+        io.wide_load(a.Fs + (kw + s) * dd, pF);
+        if (!impq) io.wide_load(a.Qs + (kw + s) * dd, pQ);
+        ny = a.ys[k0 + s];
+    };
+    auto take = [&](auto more_c, int s) {       // step s's pieces into LDS, step s + 1's on their way, both layouts out
+        sync();
+        io.wide_commit(slotF, pF);
+        if (!impq) io.wide_commit(slotQ, pQ);
+        y = ny;
+        sync();
+        if constexpr (decltype(more_c)::value) { PGPS_RC_PIN(); prefetch(s + 1); PGPS_RC_PIN(); }
+        io.template lds_get<false>(slotF, Fc);
+        io.template lds_get<true>(slotF, Fr);
+        if (!impq) io.template lds_get<false>(slotQ, Q);
+    };
+    // a matrix result of step `ku`: FAST into its output slot (drained at the end of the step), otherwise predicated
+    // per-register stores
+    auto put = [&](char* slot, Real* arr, long ku, bool pred, const Real* X) {
+        if constexpr (FAST && BATCH) io.lds_put(slot, X);
+        else if constexpr (FAST) io.wide_store(arr + ku * dd, slot, X);
+        else io.template st_mat<false>(arr + ku * dd, pred, X);
+    };
+    if constexpr (FAST) { io.init_wide(row, a.Lw, (unsigned)IOT::SLOT); prefetch(0); }
+    else load(0);
     // One step, in three flavours so that the loop proper is straight-line code (see Io): FIRST has no smoothing element
     // to build (there is no step before the chunk's first), LAST (the step after the chunk, SMOOTH only) builds the
     // last step's element and does not filter.  Next step's inputs are requested as soon as this step's are dead when the
@@ -482,6 +656,7 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
     auto step = [&](auto first_c, auto last_c, const int s) {
         constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
         const long ku = kw + s, k = k0 + s;
+        if constexpr (FAST) take(std::integral_constant<bool, !LAST>{}, s);
         // predict
         Real FP[D], Pp[D];
         if (impq && !SMOOTH) {
@@ -507,7 +682,7 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
         }
         const Real mp = mvr<D>(Fr, m, Real(0.0));
         const Real yk = y;
-        if constexpr (!LAST && EARLY) load(s + 1);
+        if constexpr (!FAST && !LAST && EARLY) load(s + 1);
         symmetrise<D>(Pp, patch, lane);
         if constexpr (SMOOTH && !FIRST) {
             // element of step k-1: W = Pp^-1 F P = E^T (i.e. E in row layout), g = m - E mp, L = P - E F P
@@ -522,8 +697,8 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
             for (int i = 0; i < D; ++i) Ln[i] = P[i] - T[i];
             {
                 const bool st = FAST || (k - 1 < k1);
-                io.template st_mat<FAST>(a.Es + (ku - 1) * dd, st, En);
-                io.template st_mat<FAST>(a.Lws + (ku - 1) * dd, st, Ln);
+                put(slotE, a.Es, ku - 1, st, En);
+                put(slotL, a.Lws, ku - 1, st, Ln);
                 io.template st_vec<FAST>(a.gs + (ku - 1) * D, st, gn);
             }
             // total <- total (x) element:  E = Ea En, g = Ea gn + ga, L = Ea Ln Ea^T + La
@@ -574,11 +749,16 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
             const Real res = obs ? yk - mu : Real(0.0);
             m = mb + u * (inv * res);
             copy<D>(P, Pp); rank1<D>(P, u, -u * inv);
-            if constexpr (!EARLY) load(s + 1);
+            if constexpr (!FAST && !EARLY) load(s + 1);
             if constexpr (STORE) {              // log-likelihood-only and projected-posterior calls skip these
-                io.template st_mat<FAST>(a.fPs + ku * dd, upd, P);
+                put(slotP, a.fPs, ku, upd, P);
                 io.template st_vec<FAST>(a.fms + ku * D, upd, m);
             }
+        }
+        if constexpr (FAST && BATCH) {          // the step's matrix results leave together
+            sync();
+            if constexpr (SMOOTH && !FIRST) { io.wide_drain(a.Es + (ku - 1) * dd, slotE); io.wide_drain(a.Lws + (ku - 1) * dd, slotL); }
+            if constexpr (!LAST && STORE) io.wide_drain(a.fPs + ku * dd, slotP);
         }
     };
     using Yes = std::integral_constant<bool, true>;
@@ -608,10 +788,12 @@ __global__ __launch_bounds__(64) void rc_apply1(const RcArgsT<Real> a0) {
     static_assert(SMOOTH || !IMPQS, "the implicit-noise instantiation is the smoothing one");
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    __shared__ __attribute__((aligned(16))) char wslots[(Io<D, Real>::kBatchOut ? 5 : 3) * (Io<D, Real>::SLOT + 16)];
+    lds_clear(wslots, (int)sizeof(wslots));
     Real* patch = patch_init(tl, row);
     const RcArgsT<Real> a = model_view(a0);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, lane, row);
-    else apply1_body<Real, D, SMOOTH, false, IMPQS, STORE>(a, patch, lane, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, wslots, lane, row);
+    else apply1_body<Real, D, SMOOTH, false, IMPQS, STORE>(a, patch, wslots, lane, row);
 }
 
 // ====================================================================================================
@@ -713,7 +895,7 @@ __global__ __launch_bounds__(64) void rc_selem1(const RcArgsT<Real> a) {
 // PROJ (pgps_lti_predict_*): nothing is stored per step; step k writes  H sm_k  and  H sP_k H^T  to slot qslot[k]
 // when that is >= 0 (StateSpaceGP.predict_f keeps exactly those, pssgp/model.py:107-111)
 template <typename Real, int D, bool FAST, bool PROJ>
-__device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch, int lane, int row) {
+__device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
@@ -743,33 +925,58 @@ __device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch
         for (int i = 0; i < D; ++i) h[i] = a.H[i];
     }
     // stored element of this row's step; steps outside the chunk run as the identity element (I, 0, 0)
-    auto load = [&](int s) {
+    auto load = [&](int s) {                    // the general body's per-register loads
         const long ku = kw + s, k = k0 + s;
-        if (PROJ) { q = -1; if (FAST || k < k1) q = a.qslot[k]; }
-        if (FAST) {
-            io.template mat_fast<false>(a.Es + ku * dd, Ec);
-            io.template mat_fast<false>(a.Lws + ku * dd, L);
-            io.vec_fast(a.gs + ku * D, g);
-        } else {
-            const long kc = ku < a.N ? ku : a.N - 1;
-            const bool real = k < k1;
-            io.template mat_slow<false>(a.Es + kc * dd, real, Real(1.0), Ec);
-            io.template mat_slow<true>(a.Es + kc * dd, real, Real(1.0), Er);
-            io.template mat_slow<false>(a.Lws + kc * dd, real, Real(0.0), L);
-            g = io.vec(a.gs + kc * D, real);
-        }
+        if (PROJ) { q = -1; if (k < k1) q = a.qslot[k]; }
+        const long kc = ku < a.N ? ku : a.N - 1;
+        const bool real = k < k1;
+        io.template mat_slow<false>(a.Es + kc * dd, real, Real(1.0), Ec);
+        io.template mat_slow<true>(a.Es + kc * dd, real, Real(1.0), Er);
+        io.template mat_slow<false>(a.Lws + kc * dd, real, Real(0.0), L);
+        g = io.vec(a.gs + kc * D, real);
     };
-    load(a.Lw - 1);
+    // FAST: the stored elements as 16-byte pieces through LDS (Io, WIDE path), a whole step ahead; E's row layout
+    // comes out of the same slot
+    using IOT = Io<D, Real>;
+    typename IOT::V4 pE[IOT::NVW], pL[IOT::NVW];
+    Real ng = Real(0.0);
+    int nq = -1;
+    char* slotE = wslots;
+    char* slotL = wslots + (IOT::SLOT + 16);
+    char* slotO = wslots + 2 * (IOT::SLOT + 16);
+    auto prefetch = [&](int s) {                // (s = -1 at the end: the step before the chunk, >= 0 for a FAST wave)
+        io.wide_load(a.Es + (kw + s) * dd, pE);
+        io.wide_load(a.Lws + (kw + s) * dd, pL);
+        io.vec_fast(a.gs + (kw + s) * D, ng);
+        if (PROJ) nq = a.qslot[k0 + s];
+    };
+    auto take = [&](int s) {
+        sync();
+        io.wide_commit(slotE, pE);
+        io.wide_commit(slotL, pL);
+        g = ng; q = nq;
+        sync();
+        PGPS_RC_PIN();
+        prefetch(s - 1);
+        PGPS_RC_PIN();
+        io.template lds_get<false>(slotE, Ec);
+        io.template lds_get<true>(slotE, Er);
+        io.template lds_get<false>(slotL, L);
+    };
+    if constexpr (FAST) { io.init_wide(row, a.Lw, (unsigned)IOT::SLOT); prefetch(a.Lw - 1); }
+    else load(a.Lw - 1);
     for (int s = a.Lw - 1; s >= 0; --s) {
         const long ku = kw + s, k = k0 + s;
+        if constexpr (FAST) take(s);
         Real T[D], nP[D];
-        if (FAST) transpose<D>(Ec, Er, patch, lane);   // E in row layout through LDS: a second global read costs more
         zero<D>(T); mm<D>(T, Ec, sP);
         copy<D>(nP, L); mm<D>(nP, T, Er);
         sm = mvr<D>(Er, sm, g);
         const int qk = q;
-        if (s > 0) load(s - 1);
-        symmetrise<D>(nP, patch, lane);
+        if constexpr (!FAST) {
+            if (s > 0) load(s - 1);
+        }
+        symmetrise<D, true>(nP, patch, lane);
         copy<D>(sP, nP);
         if (PROJ) {
             const Real mean = mvr<D>(h, sm, Real(0.0));                     // H sm            (every lane of the row)
@@ -780,7 +987,8 @@ __device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch
             buf_st(make_rsrc(a.pvar, 0x7fff0000u), qo, var);
         } else {
             const bool st = FAST || k < k1;
-            io.template st_mat<FAST>(a.sPs + ku * dd, st, sP);
+            if constexpr (FAST) io.wide_store(a.sPs + ku * dd, slotO, sP);
+            else io.template st_mat<false>(a.sPs + ku * dd, st, sP);
             io.template st_vec<FAST>(a.sms + ku * D, st, sm);
         }
     }
@@ -790,9 +998,11 @@ template <typename Real, int D, bool PROJ>
 __global__ __launch_bounds__(64) void rc_smooth1(const RcArgsT<Real> a) {
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    __shared__ __attribute__((aligned(16))) char wslots[3 * (Io<D, Real>::SLOT + 16)];
+    lds_clear(wslots, (int)sizeof(wslots));
     Real* patch = patch_init(tl, row);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<Real, D, true, PROJ>(a, patch, lane, row);
-    else smooth1_body<Real, D, false, PROJ>(a, patch, lane, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<Real, D, true, PROJ>(a, patch, wslots, lane, row);
+    else smooth1_body<Real, D, false, PROJ>(a, patch, wslots, lane, row);
 }
 
 // ====================================================================================================

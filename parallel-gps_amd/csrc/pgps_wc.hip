@@ -1646,7 +1646,8 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode, int
         a.Lw = (int)(lw < 8 ? 8 : lw > 512 ? 512 : lw);
     }
     a.nchunk = (sa.N + a.Lw - 1) / a.Lw;
-    a.wfast = (sa.N - 1) / (4L * a.Lw);         // (w + 1) 4 Lw + 1 <= N
+    // (w + 1) 4 Lw + 2 <= N: the wide loads of a FAST wave reach at most 8 bytes into the record after its halo step
+    a.wfast = sa.N >= 2 ? (sa.N - 2) / (4L * a.Lw) : 0;
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs;
     a.store_f = store_f; a.qslot = qslot; a.pmean = pmean; a.pvar = pvar;

@@ -309,7 +309,10 @@ def test_full_size_against_c_oracle(dtype, kname, n):
     assert relerr(got["sms"], cs) < tol and relerr(got["sPs"], csP) < tol
     assert abs(got["ll"][0] - cll) < (1e-9 if dtype == np.float64 else 1e-4) * abs(cll)
     # properties
-    assert relerr(got["sms"][-1], got["fms"][-1]) < 1e-12 and relerr(got["sPs"][-1], got["fPs"][-1]) < 1e-12
+    # (exact in fp64 and on the lane-chunk kernels; the fp32 row-cooperative kernels symmetrise the last smoothed
+    # covariance once more: a rounding of an already symmetric matrix in the last bit of its small entries)
+    ptol = 1e-12 if dtype == np.float64 else 1e-6
+    assert relerr(got["sms"][-1], got["fms"][-1]) < ptol and relerr(got["sPs"][-1], got["fPs"][-1]) < ptol
     d = Fs.shape[1]
     slack = 1e-9 if dtype == np.float64 else 1e-3
     for i in range(d):

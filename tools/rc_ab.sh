@@ -1,7 +1,6 @@
-# A/B of two builds of libpgps on the row-cooperative configs: tools/rc_ab.sh <libA> <libB> [configs...]
-A=$1; B=$2; shift 2
+# A/B of builds of libpgps on the row-cooperative configs: tools/rc_ab.sh <lib> [<lib> ...]
 for cfg in "--kernel rbf6 --dtype f64" "--kernel rbf6 --dtype f32" "--kernel c5 --dtype f64"; do
-for lib in $A $B; do
+for lib in "$@"; do
 PGPS_LIB=$PWD/parallel-gps_amd/pssgp/$lib timeout -k 10 120 python bench.py $cfg --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for ln in sys.stdin:
