@@ -12,12 +12,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liboracle_seq.so")
+_SAN = os.environ.get("PGPS_SAN") == "1"            # ASan + UBSan build (tests/test_sanitizers.py)
+_BUILD = "_build_san" if _SAN else "_build"
+_SO = os.path.join(_HERE, _BUILD, "liboracle_seq.so")
 _lib = None
 
 
 def build():
-    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    subprocess.run(["make", "-s", "-C", _HERE] + (["SAN=1"] if _SAN else []), check=True)
     return _SO
 
 
@@ -51,7 +53,7 @@ def kfs(lgssm, ys, dtype=np.float64):
     return fms, fPs, sms, sPs, ll.value
 
 
-_SO_PAR = os.path.join(_HERE, "_build", "liboracle_par.so")
+_SO_PAR = os.path.join(_HERE, _BUILD, "liboracle_par.so")
 _lib_par = None
 
 

@@ -14,7 +14,9 @@ from oracle import np_oracle as O
 from tests.conftest import make_times, relerr, sample_series
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "tests", "cpu_math", "_build")
+SAN = os.environ.get("PGPS_SAN") == "1"             # ASan + UBSan build of the harness (tests/test_sanitizers.py)
+BUILD = os.path.join(ROOT, "tests", "cpu_math", "_build_san" if SAN else "_build")
+SAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
 
 
 @pytest.fixture(scope="module")
@@ -25,8 +27,8 @@ def emul():
     hdr = os.path.join(ROOT, "parallel-gps_amd", "csrc", "pgps_math.h")
     hdr2 = os.path.join(ROOT, "parallel-gps_amd", "csrc", "pgps_dual.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in (src, hdr, hdr2)):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.dirname(hdr), src, "-o", so],
-                       check=True)
+        subprocess.run(["g++"] + (SAN_FLAGS if SAN else ["-O2"]) + ["-std=c++17", "-shared", "-fPIC", "-I",
+                                                                     os.path.dirname(hdr), src, "-o", so], check=True)
     return ctypes.CDLL(so)
 
 
