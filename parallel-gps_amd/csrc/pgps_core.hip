@@ -378,6 +378,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <typename T>
 static int pkf_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
                    const T* ys, T* fms, T* fPs, double* ll) {
+    RoctxRange range_("parallel_filter");
     if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs) return PGPS_E_INVALID;
     if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs)) return PGPS_E_INVALID;
@@ -391,6 +392,7 @@ static int pkf_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const
 template <typename T>
 static int pks_dev(pgps_ctx* ctx, long N, int d, const T* Fs, const T* Qs, const T* fms, const T* fPs,
                    T* sms, T* sPs) {
+    RoctxRange range_("parallel_smoother");
     if (!ctx || N < 1 || !Fs || !Qs || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
     if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs) || !aligned16(sms) ||
@@ -406,6 +408,7 @@ static int pks_dev(pgps_ctx* ctx, long N, int d, const T* Fs, const T* Qs, const
 template <typename T>
 static int pkfs_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
                     const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {
+    RoctxRange range_("parallel_filter");
     if (!ctx || N < 1 || !P0 || !Fs || !Qs || !H || !ys || !fms || !fPs || !sms || !sPs) return PGPS_E_INVALID;
     if (d < 1 || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
     if (!aligned16(Fs) || !aligned16(Qs) || !aligned16(fms) || !aligned16(fPs) || !aligned16(sms) ||
@@ -420,6 +423,7 @@ static int pkfs_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, cons
 
 template <typename T>
 static int disc_dev(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
+    RoctxRange range_("make_model");
     if (!ctx || N < 1 || !F || !Pinf || !ts || !Fs || !Qs) return PGPS_E_INVALID;
     if constexpr (sizeof(T) == 8) {
         const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
@@ -720,6 +724,7 @@ PGPS_DEFINE_SEG(f32, float)
 template <typename T>
 static int pkfs_seg_run(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R, const T* ys,
                         T* fms, T* fPs, T* sms, T* sPs, double* ll) {
+    RoctxRange range_("parallel_filter");
     const int rank = ctx->comm_rank, nranks = ctx->comm_nranks;
     const size_t rf = ((size_t)seg_rec_f_len(d) * sizeof(T) + 15) / 16 * 16, rs = ((size_t)seg_rec_s_len(d) * sizeof(T) + 15) / 16 * 16;
     TRY(ensure(ctx, ctx->comm_buf, (rf + rs) * (size_t)(nranks + 1)));
@@ -763,6 +768,7 @@ template <typename T>
 static int gp_dev(pgps_ctx* ctx, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
                   const double* H, double R, const T* ts, double t0, const T* ys, T* fms, T* fPs, T* sms, T* sPs,
                   double* ll) {
+    RoctxRange range_("parallel_filter");
     if (!ctx || N < 1 || !N1 || !Pinf || !H || !ts || !ys) return PGPS_E_INVALID;
     if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
     if ((fms == nullptr) != (fPs == nullptr) || (sms == nullptr) != (sPs == nullptr)) return PGPS_E_INVALID;
@@ -882,6 +888,7 @@ __global__ __launch_bounds__(kBlock) void k_merge_sorted(long N, long K, const T
 
 template <typename T>
 int launch_merge(pgps_ctx* ctx, long N, long K, const T* ts, const T* ys, const T* tq, T* ts_m, T* ys_m, int* qslot) {
+    RoctxRange range_("merge_sorted");
     const long M = N + K;
     const dim3 grid((unsigned)((M + kBlock - 1) / kBlock)), block(kBlock);
     k_merge_sorted<T><<<grid, block, 0, ctx->stream>>>(N, K, ts, ys, tq, ts_m, ys_m, qslot);

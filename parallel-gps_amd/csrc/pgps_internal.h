@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <string>
 #include <vector>
@@ -47,6 +48,15 @@ struct pgps_ctx {
     size_t ev_used = 0;
     double prof_ms[PGPS_K_COUNT] = {0};
     long prof_n[PGPS_K_COUNT] = {0};
+};
+
+// roctx range named after the reference's tf.name_scope of the same work (pssgp/kalman/parallel.py:122 "parallel_filter",
+// pssgp/model.py:35 "merge_sorted", model.py:87 "make_model"): visible in `rocprofv3 --marker-trace`, a no-op otherwise
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { roctxRangePushA(name); }
+    ~RoctxRange() { roctxRangePop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
 };
 
 #define HIPCHK(ctx, expr)                                                        \

@@ -1321,6 +1321,7 @@ static int launch_disc_wc_dp(pgps_ctx* ctx, long N, int d, const T* F, const T* 
 
 template <typename T>
 int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
+    RoctxRange range_("make_model");
     if (d < 1 || d > 32) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (d <= 8) return launch_disc_wc_dp<T, 8>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
@@ -1577,6 +1578,7 @@ static int scan_rc(pgps_ctx* ctx, int d, RcArgsT<Real> a, Mode mode, Real* aggA,
 
 int launch_disc_rc(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* ts, double t0,
                    double* Fs, double* Qs, int batch, long bs_model) {
+    RoctxRange range_("make_model");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     switch (d) {
 #define PGPS_RC_CASE(DV) case DV: return rc::launch_rc_disc<DV>(ctx, N, F, Pinf, ts, t0, Fs, Qs, batch, bs_model);
@@ -1602,12 +1604,14 @@ int launch_scan_rc(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode) {
 template int launch_scan_rc<double>(pgps_ctx*, ScanArgs<double>, int, Mode);
 template int launch_scan_rc<float>(pgps_ctx*, ScanArgs<float>, int, Mode);
 int launch_scan_rc_proj(pgps_ctx* ctx, ScanArgs<double> sa, int d, Mode mode, const int* qslot, double* pmean, double* pvar) {
+    RoctxRange range_("parallel_filter");
     if (mode == MODE_PKFS && (!qslot || !pmean || !pvar)) return PGPS_E_INVALID;
     return scan_rc_entry<double>(ctx, sa, d, mode, 0, mode == MODE_PKFS ? qslot : nullptr, pmean, pvar);
 }
 
 int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* table, long bs_model, const double* Fs,
                        const double* Qs, const double* ys, double* ll) {
+    RoctxRange range_("parallel_filter");
     if (batch < 1 || !table || !Fs || !ys || !ll) return PGPS_E_INVALID;      // Qs == nullptr: implicit process noise
     const long dd = (long)d * d;
     ScanArgs<double> a{};
