@@ -1,22 +1,23 @@
 #!/bin/bash
 # PMC passes for the bench workload (run on the GPU box via gpurun). Usage: tools/pmc.sh <outdir> [bench args...]
+# Counters in their own runs, --kernel-trace only (never with --sys-trace / hip / marker domains: refused on this pool).
 out=$1; shift
+R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$out
 i=0
-for ctrs in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
-            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
+            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/$out/p$i -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --event-every 0 "$@" > $R/gpurun_out/$out/p$i.log 2>&1
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/$out/p$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --event-every 0 "$@" > $R/gpurun_out/$out/p$i.log 2>&1
   echo "pass $i rc=$?"
 done
 python3 - "$R/gpurun_out/$out" <<'PY'
 import csv, glob, sys, collections
 root=sys.argv[1]
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(root+"/p*/*/*counter_collection.csv"):
+for f in glob.glob(root+"/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
         if "pgps" not in k: continue
@@ -25,5 +26,6 @@ for f in glob.glob(root+"/p*/*/*counter_collection.csv"):
 with open(root+"/summary.txt","w") as out:
     for k,v in agg.items():
         line=k+"\n"+"\n".join("   %-32s mean %.6g  (n=%d)"%(c,sum(x)/len(x),len(x)) for c,x in sorted(v.items()))
-        print(line); out.write(line+"\n")
+        out.write(line+"\n")
+print("summary written")
 PY

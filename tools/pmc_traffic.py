@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per launch from rocprofv3 PMC passes -> profiles/rNN_traffic.json entries.
+
+  tools/pmc_traffic.py <pmc dir of tools/pmc.sh> <workload key> [<existing json to update>]
+
+The PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, rocprofv3 PMC
+slots); traffic = 2 * FETCH_SIZE + WRITE_SIZE in bytes (counters are KiB): on gfx950 FETCH_SIZE reports half the bytes
+of wide coalesced reads (same guide, HBM section).  Kernels are mapped to bench.py's launch slots; a slot that holds
+several launches per pass (the Kogge-Stone levels of the row-cooperative family sit in the reduce slots) gets the SUM
+over its kernels per pass."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+SLOT_OF = [("k_filter_reduce", "k_filter_reduce"), ("k_filter_apply", "k_filter_apply"), ("k_filter_single", "k_filter_apply"),
+           ("k_smoother_apply", "k_smoother_apply"), ("k_smoother_reduce", "k_smoother_reduce"),
+           ("rc_reduce1", "k_filter_reduce"), ("rc_ks_filter", "k_filter_reduce"), ("rc_apply1", "k_filter_apply"),
+           ("rc_ks_smoother", "k_smoother_reduce"), ("rc_selem1", "k_smoother_reduce"), ("rc_smooth1", "k_smoother_apply")]
+
+
+def main():
+    root, key = sys.argv[1], sys.argv[2]
+    out_path = sys.argv[3] if len(sys.argv) > 3 else None
+    per = collections.defaultdict(lambda: collections.defaultdict(list))    # kernel -> counter -> values per dispatch
+    for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    slots = collections.defaultdict(lambda: {"FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0, "kernels": []})
+    passes = None
+    for kname, ctr in per.items():
+        slot = next((s for pat, s in SLOT_OF if pat in kname), None)
+        if slot is None or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
+            continue
+        short = kname.split("(")[0].replace("void pgps::", "")
+        n = len(ctr["FETCH_SIZE"])
+        slots[slot]["kernels"].append({"name": short, "dispatches": n, "FETCH_SIZE_KiB_mean": sum(ctr["FETCH_SIZE"]) / n,
+                                       "WRITE_SIZE_KiB_mean": sum(ctr["WRITE_SIZE"]) / len(ctr["WRITE_SIZE"])})
+        # single-launch kernels fix the number of passes that were profiled
+        if any(p in kname for p in ("rc_apply1", "k_filter_apply", "k_filter_single")):
+            passes = n
+        slots[slot]["FETCH_SIZE_KiB"] += sum(ctr["FETCH_SIZE"])
+        slots[slot]["WRITE_SIZE_KiB"] += sum(ctr["WRITE_SIZE"])
+    assert passes, "no filter-apply dispatches found"
+    entry = {}
+    for slot, v in slots.items():
+        f, w = v["FETCH_SIZE_KiB"] / passes, v["WRITE_SIZE_KiB"] / passes
+        entry[slot] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "traffic_bytes": int((2 * f + w) * 1024),
+                       "kernels": v["kernels"]}
+    doc = {}
+    if out_path:
+        try:
+            doc = json.load(open(out_path))
+        except Exception:
+            doc = {}
+    doc.setdefault("_comment", "HBM-side bytes per pass and launch slot from rocprofv3 PMC (separate --pmc passes, tools/pmc.sh + "
+                               "tools/pmc_traffic.py): traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); FETCH_SIZE reports half "
+                               "the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section)")
+    doc[key] = entry
+    text = json.dumps(doc, indent=1)
+    if out_path:
+        open(out_path, "w").write(text + "\n")
+    print(json.dumps({key: {k: v["traffic_bytes"] for k, v in entry.items()}}))
+
+
+if __name__ == "__main__":
+    main()
