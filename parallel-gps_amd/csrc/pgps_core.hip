@@ -301,7 +301,7 @@ extern "C" int pgps_profile_read(pgps_ctx* ctx, double* total_ms, long* launches
 // launch geometry
 // ---------------------------------------------------------------------------------------------
 namespace pgps {
-void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks) {
+void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks, int d) {
     int c = ctx->chunk;
     if (c <= 0) {
         // 16 steps per lane (the lane-serial part then outweighs the scan trees: measured at 2^20)
@@ -309,7 +309,11 @@ void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks) {
         // on its side); shorter series use fewer steps per lane so the chip is still covered;
         // multiples of 4 = whole LDS-staged sub-tiles.
         long v = 16;
-        const long max_blocks = 1024;
+        // from 2^21 steps 32 per lane still fill every CU (>= 256 workgroups) and halve the scan trees and their scratch
+        // per step: 2^21 0.166 -> 0.154 ms, 2^24 1.27 -> 1.13 ms; at 2^20 half the CUs would idle (0.086 -> 0.092 ms)
+        if (d >= 1 && d <= 2 && N >= (long)kBlock * 32 * 256) v = 32;        // (measured on the array path at d = 2)
+        // (2^24 steps, d = 2: 2048 workgroups of 32 steps per lane 1.13 ms, 1024 of 64 steps 1.29 ms)
+        const long max_blocks = (d >= 1 && d <= 2) ? 2048 : 1024;
         if (N > (long)kBlock * v * max_blocks) v = (N + (long)kBlock * max_blocks - 1) / ((long)kBlock * max_blocks);
         while (v > 4 && (long)kBlock * v * 128 > N) v /= 2;   // keep >= 128 workgroups when N allows
         if (N < (long)kBlock * 4) v = (N + kBlock - 1) / kBlock;

@@ -52,7 +52,7 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
 template <typename T, int D, int G, bool NT>
 static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    geometry(ctx, a.N, &a.Lc, &a.nblocks);
+    geometry(ctx, a.N, &a.Lc, &a.nblocks, D);
     a.nlanes = (long)a.nblocks * kBlock;
     a.nt = NT ? 1 : 0;
     int rc = carve_workspace<T, D>(ctx, a);

@@ -81,7 +81,7 @@ int ensure(pgps_ctx* ctx, DevBuf& b, size_t bytes);
 // all-gather of `bytes` per rank on the context's stream through the context's RCCL communicator (pgps_comm.hip)
 int comm_allgather(pgps_ctx* ctx, const void* send, void* recv, size_t bytes);
 int prof_flush(pgps_ctx* ctx);
-void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks);
+void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks, int d = 0);
 
 // Per-kernel timing: when the launch is sampled (pgps_profile_enable / _sample) the kernel goes out
 // through hipExtLaunchKernelGGL, which stamps the two events with the dispatch's own start / end

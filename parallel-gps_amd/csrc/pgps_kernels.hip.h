@@ -732,9 +732,9 @@ struct FilterApplyStaged {
     __device__ __forceinline__ void prefetch(const ScanArgs<T>& a, long wbase) {
         const int lane = threadIdx.x & (kWave - 1);
         const long pitchF = (long)a.Lc * MAT * sizeof(T);
-        stage_issue<GF>(reinterpret_cast<const char*>(a.Fs + wbase * MAT), pitchF, rF);
-        stage_issue<GF>(reinterpret_cast<const char*>(a.Qs + wbase * MAT), pitchF, rQ);
-        y_issue<T, G>(a.ys + wbase + (long)lane * a.Lc, yn);
+        // No register prefetch of the first sub-tile here (nor of the next one in run()): 72 registers less put the kernel
+        // at 206 VGPRs, two waves per SIMD, and the second wave covers the latency instead -- equal at 2^20 steps (one
+        // wave per SIMD's worth of work), 5-10 % faster from 2^21 on (2^24: 0.52 -> 0.47 ms)
         // the halo step of lane l is the first step of lane l+1: after the first sub-tile is in LDS
         // it is fetched from there (run()); only the wave's last lane reads global memory
         have_next = false;
@@ -756,16 +756,14 @@ struct FilterApplyStaged {
         const long k0 = wbase + (long)lane * a.Lc;
         for (int sb = 0; sb < S; ++sb) {
             wave_lds_sync();
+            stage_issue<GF>(gF + (long)sb * GF::SEG, pitchF, rF);
+            stage_issue<GF>(gQ + (long)sb * GF::SEG, pitchF, rQ);
+            y_issue<T, G>(gY + sb * G, yn);
             stage_commit<GF>(lF, rF);
             stage_commit<GF>(lQ, rQ);
             T yv[G];
 #pragma unroll
             for (int i = 0; i < G; ++i) yv[i] = yn[i];
-            if (sb + 1 < S) {
-                stage_issue<GF>(gF + (long)(sb + 1) * GF::SEG, pitchF, rF);
-                stage_issue<GF>(gQ + (long)(sb + 1) * GF::SEG, pitchF, rQ);
-                y_issue<T, G>(gY + (sb + 1) * G, yn);
-            }
             wave_lds_sync();
             if (SMOOTH && sb == 0 && lane < kWave - 1) {
                 // record 0 of the next lane = this lane's halo step
