@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """HBM-side traffic per launch from rocprofv3 PMC passes -> profiles/rNN_traffic.json entries.
 
-  tools/pmc_traffic.py <pmc dir of tools/pmc.sh> <workload key> [<existing json to update>]
+  tools/pmc_traffic.py <pmc dir of tools/pmc.sh> <workload key> [<existing json to update>] [<fetch factor>]
 
 The PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, rocprofv3 PMC
-slots); traffic = 2 * FETCH_SIZE + WRITE_SIZE in bytes (counters are KiB): on gfx950 FETCH_SIZE reports half the bytes
-of wide coalesced reads (same guide, HBM section).  Kernels are mapped to bench.py's launch slots; a slot that holds
+slots); traffic = factor * FETCH_SIZE + WRITE_SIZE in bytes (counters are KiB).  factor = 2 for kernels whose reads are
+wide coalesced 16-byte accesses: on gfx950 FETCH_SIZE reports half their bytes (same guide, HBM section; confirmed here
+on k_filter_reduce / rc_reduce1, whose reads are exactly Fs, Qs, ys: 0.55-0.57 of the known volume).  Other access
+widths are uncalibrated, the guide says, so the lane-chunk kernels at d >= 4 (direct 64 / 100 / 144-byte record
+accesses) are calibrated the same way: their k_filter_reduce reads exactly (2 d^2 + 1) w bytes per step and reports
+0.82 of that -- factor 1.22.  Kernels are mapped to bench.py's launch slots; a slot that holds
 several launches per pass (the Kogge-Stone levels of the row-cooperative family sit in the reduce slots) gets the SUM
 over its kernels per pass."""
 import collections
@@ -23,6 +27,7 @@ SLOT_OF = [("k_filter_reduce", "k_filter_reduce"), ("k_filter_apply", "k_filter_
 def main():
     root, key = sys.argv[1], sys.argv[2]
     out_path = sys.argv[3] if len(sys.argv) > 3 else None
+    factor = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
     per = collections.defaultdict(lambda: collections.defaultdict(list))    # kernel -> counter -> values per dispatch
     for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -46,8 +51,8 @@ def main():
     entry = {}
     for slot, v in slots.items():
         f, w = v["FETCH_SIZE_KiB"] / passes, v["WRITE_SIZE_KiB"] / passes
-        entry[slot] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "traffic_bytes": int((2 * f + w) * 1024),
-                       "kernels": v["kernels"]}
+        entry[slot] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "fetch_factor": factor,
+                       "traffic_bytes": int((factor * f + w) * 1024), "kernels": v["kernels"]}
     doc = {}
     if out_path:
         try:
@@ -55,8 +60,10 @@ def main():
         except Exception:
             doc = {}
     doc.setdefault("_comment", "HBM-side bytes per pass and launch slot from rocprofv3 PMC (separate --pmc passes, tools/pmc.sh + "
-                               "tools/pmc_traffic.py): traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); FETCH_SIZE reports half "
-                               "the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section)")
+                               "tools/pmc_traffic.py): traffic = fetch_factor*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); FETCH_SIZE "
+                               "reports half the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section) -- "
+                               "factor 2; kernels with direct record accesses are calibrated on their reduce kernel's known read "
+                               "volume (see tools/pmc_traffic.py)")
     doc[key] = entry
     text = json.dumps(doc, indent=1)
     if out_path:
