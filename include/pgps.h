@@ -267,6 +267,20 @@ int pgps_gp_ll_grad_f64(pgps_ctx*, long N, int d, int np, const double* model, c
 int pgps_gp_ll_grad_dev_f64(pgps_ctx*, long N, int d, int np, const double* model, const double* ts, double t0,
                             const double* ys, double* out);
 
+/* The same for composite kernels whose drift is block diagonal with blocks  F_b = -lam_b I + N_b,  N_b nilpotent --
+ * sums and products of Matern kernels, balanced or not (kernels/base.py:130-244; a product of Matern kernels is one
+ * block: lam = the sum of the factors', N = the Kronecker sum of theirs) -- state dimension 2 <= d <= 6, nblk <= 4
+ * blocks of sizes bsize[] (sum d), np <= 16 hyper-parameters: the reference's gradient test kernels `Matern32 +
+ * Matern52` and `Matern32 * Matern52` (tests/test_gp_vs_kfs.py:40-41,53-78) differentiated exactly, by dual numbers
+ * through the scan, one direction per pass.  `model` (HOST memory): 1 + np rows of
+ * [lam (4, unused ones 0) | N (d*d) | Pinf (d*d) | H (d) | R], row 0 the values, row p the partial derivatives with
+ * respect to hyper-parameter p.  out[0] = log-likelihood, out[1..np] = gradient; the _dev form takes device pointers
+ * for ts, ys, out, and its `out` must hold 1 + 3 np doubles (the tail is scratch). */
+int pgps_gp_ll_grad_blocks_f64(pgps_ctx*, long N, int d, int nblk, const int* bsize, int np, const double* model,
+                               const double* ts, double t0, const double* ys, double* out);
+int pgps_gp_ll_grad_blocks_dev_f64(pgps_ctx*, long N, int d, int nblk, const int* bsize, int np, const double* model,
+                                   const double* ts, double t0, const double* ys, double* out);
+
 /* ---- one series sharded over several GPUs (contiguous time segments) -------------------
  * No reference equivalent (the reference is single-device).  Rank r of
  * `nranks` owns steps [r*N, (r+1)*N) -- every rank passes its own N -- and calls, in order:

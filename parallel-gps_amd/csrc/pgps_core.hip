@@ -1416,6 +1416,45 @@ extern "C" int pgps_gp_ll_grad_dev_f64(pgps_ctx* ctx, long N, int d, int np, con
     return launch_grad(ctx, N, d, np, model, ts, t0, ys, out);
 }
 
+static int gradb_dispatch(pgps_ctx* ctx, long N, int d, int nblk, const int* bsize, int np, const double* model,
+                          const double* ts, double t0, const double* ys, double* out) {
+    if (!ctx || N < 1 || !bsize || !model || !ts || !ys || !out) return PGPS_E_INVALID;
+    if (nblk < 1 || nblk > 4 || np < 1 || np > 16) return PGPS_E_INVALID;
+    int sum = 0;
+    for (int b = 0; b < nblk; ++b) { if (bsize[b] < 1) return PGPS_E_INVALID; sum += bsize[b]; }
+    if (sum != d) return PGPS_E_INVALID;
+    RoctxRange range_("parallel_filter");
+    switch (d) {
+        case 2: return launch_gradb<2>(ctx, N, nblk, bsize, np, model, ts, t0, ys, out);
+        case 3: return launch_gradb<3>(ctx, N, nblk, bsize, np, model, ts, t0, ys, out);
+        case 4: return launch_gradb<4>(ctx, N, nblk, bsize, np, model, ts, t0, ys, out);
+        case 5: return launch_gradb<5>(ctx, N, nblk, bsize, np, model, ts, t0, ys, out);
+        case 6: return launch_gradb<6>(ctx, N, nblk, bsize, np, model, ts, t0, ys, out);
+        default: return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
+
+extern "C" int pgps_gp_ll_grad_blocks_dev_f64(pgps_ctx* ctx, long N, int d, int nblk, const int* bsize, int np,
+                                              const double* model, const double* ts, double t0, const double* ys,
+                                              double* out) {
+    return gradb_dispatch(ctx, N, d, nblk, bsize, np, model, ts, t0, ys, out);
+}
+
+extern "C" int pgps_gp_ll_grad_blocks_f64(pgps_ctx* ctx, long N, int d, int nblk, const int* bsize, int np,
+                                          const double* model, const double* ts, double t0, const double* ys, double* out) {
+    if (!ctx || N < 1 || !model || !ts || !ys || !out || np < 1 || np > 16) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *dts, *dys, *dout;
+    TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
+    TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, (size_t)(1 + 3 * np), &dout));
+    TRY(gradb_dispatch(ctx, N, d, nblk, bsize, np, model, dts, t0, dys, dout));
+    TRY(stage_out(ctx, out, dout, (size_t)(1 + np)));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!std::isfinite(out[0])) return PGPS_E_NUMERIC;
+    return PGPS_OK;
+}
+
 extern "C" int pgps_gp_ll_grad_f64(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts,
                                    double t0, const double* ys, double* out) {
     if (!ctx || N < 1 || !model || !ts || !ys || !out) return PGPS_E_INVALID;

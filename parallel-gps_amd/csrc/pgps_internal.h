@@ -200,6 +200,12 @@ int launch_merge(pgps_ctx* ctx, long N, long K, const T* ts, const T* ys, const 
 int launch_grad(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts, double t0,
                 const double* ys, double* out_dev);
 
+// the same for block-nilpotent composite models (sums / products of Matern kernels), d = 2..6 (pgps_gradb.hip, one
+// instantiation per d): model rows [lam (4) | N (d*d) | Pinf (d*d) | H (d) | R], bsize = the nblk block sizes
+template <int D>
+int launch_gradb(pgps_ctx* ctx, long N, int nblk, const int* bsize, int np, const double* model, const double* ts, double t0,
+                 const double* ys, double* out_dev);
+
 enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS, MODE_SEG_REDUCE, MODE_SEG_FILTER, MODE_SEG_SMOOTHER };
 
 // defined in pgps_inst.hip, one explicit instantiation per compiled (T, D)

@@ -80,6 +80,8 @@ def _declare(lib):
         getattr(lib, f"pgps_seg_smoother_apply_dev_{suf}").argtypes = [P, c_long, c_int, c_int, c_int, P, P, P, P, P,
                                                                        P, P, P]
         getattr(lib, f"pgps_pkfs_seg_dev_{suf}").argtypes = [P, c_long, c_int, P, P, P, P, real, P, P, P, P, P, P]
+    for dev in ("", "_dev"):
+        getattr(lib, f"pgps_gp_ll_grad_blocks{dev}_f64").argtypes = [P, c_long, c_int, c_int, P, c_int, P, P, c_double, P, P]
     return lib
 
 
@@ -613,6 +615,70 @@ def pack_grad_model(blocks):
     if model.shape[1] != 1 + 2 * d * d + d + 1:
         raise ValueError("malformed model block")
     return model, d, len(blocks) - 1
+
+
+GRAD_BLOCKS_DIM_MAX = 6        # pgps_gp_ll_grad_blocks_*: state dimension, blocks
+GRAD_BLOCKS_MAX = 4
+
+
+def nilpotent_blocks(F, tol=1e-9):
+    """[(start, size, lam, N)] when F is block diagonal (contiguous blocks) with every block -lam I + N, N nilpotent --
+    sums and products of Matern kernels, balanced or not -- else None.  Blocks = connected components of F's pattern."""
+    F = np.asarray(F, np.float64)
+    d = F.shape[0]
+    scale = max(1.0, float(np.max(np.abs(F))))
+    adj = (np.abs(F) > tol * scale) | (np.abs(F.T) > tol * scale) | np.eye(d, dtype=bool)
+    comp = -np.ones(d, int)
+    ncomp = 0
+    for i in range(d):
+        if comp[i] >= 0:
+            continue
+        stack, comp[i] = [i], ncomp
+        while stack:
+            u = stack.pop()
+            for v in np.nonzero(adj[u])[0]:
+                if comp[v] < 0:
+                    comp[v] = ncomp
+                    stack.append(v)
+        ncomp += 1
+    if np.any(np.diff(comp) < 0) or np.any(np.diff(comp) > 1):
+        return None                                 # components must be contiguous index ranges, in order
+    blocks = []
+    for b in range(ncomp):
+        idx = np.nonzero(comp == b)[0]
+        lo, n = int(idx[0]), int(idx.size)
+        Fb = F[lo:lo + n, lo:lo + n]
+        lam = -float(np.trace(Fb)) / n              # all eigenvalues of a Matern block equal -lam (companion form)
+        Nb = Fb + lam * np.eye(n)
+        if not np.all(np.isfinite(Nb)) or np.max(np.abs(np.linalg.matrix_power(Nb, 4))) > tol * scale ** 4:
+            return None                             # not nilpotent, or beyond the device series (it stops at N^3 / 6)
+        blocks.append((lo, n, lam, Nb))
+    return blocks
+
+
+def gp_ll_grad_blocks(rows, bsizes, ts, ys, t0=0.0, device=0):
+    """Log-likelihood and its exact gradient for a block-nilpotent composite model (pgps_gp_ll_grad_blocks_f64, fp64,
+    2 <= d <= 6).  `rows`: 1 + np tuples (lams [nblk], N (d, d), Pinf (d, d), H (d,), R) -- the model, then its partial
+    derivative with respect to each hyper-parameter; `bsizes`: the block sizes.  Returns (ll, grad[np])."""
+    d = int(np.asarray(rows[0][1]).shape[0])
+    nblk = len(bsizes)
+    packed = []
+    for lams, Nm, Pinf, H, R in rows:
+        lam4 = np.zeros(GRAD_BLOCKS_MAX)
+        lam4[:nblk] = np.asarray(lams, np.float64).reshape(-1)
+        packed.append(np.concatenate([lam4, np.asarray(Nm, np.float64).reshape(-1), np.asarray(Pinf, np.float64).reshape(-1),
+                                      np.asarray(H, np.float64).reshape(-1), [float(R)]]))
+    model = np.ascontiguousarray(np.stack(packed), dtype=np.float64)
+    npar = len(rows) - 1
+    ts_a = _prep(ts, np.float64, (-1,))
+    ys_a = _prep(ys, np.float64, (-1,))
+    if ys_a.shape[0] != ts_a.shape[0]:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
+    bs = np.ascontiguousarray(bsizes, dtype=np.int32)
+    out = np.zeros(1 + npar, np.float64)
+    get_context(device).call("pgps_gp_ll_grad_blocks_f64", c_long(ts_a.shape[0]), c_int(d), c_int(nblk), _ptr(bs), c_int(npar),
+                             _ptr(model), _ptr(ts_a), c_double(float(t0)), _ptr(ys_a), _ptr(out))
+    return out[0], out[1:]
 
 
 def gp_ll_grad(blocks, ts, ys, t0=0.0, device=0):

@@ -217,6 +217,51 @@ class StateSpaceGP:
                 setattr(owner, name, x0)
         return blocks
 
+    def _grad_rows_composite(self):
+        """(rows, block sizes) for pgps_gp_ll_grad_blocks_*: the block-nilpotent model (lam_b, N, Pinf, H, R) of a sum /
+        product of Matern kernels and its partial derivatives with respect to each trainable parameter (Richardson
+        central differences of get_sde(): its entries are low-degree rational functions of the parameters, exact to
+        ~1e-11), or None when the kernel's drift does not have that form / the state dimension is not 2..6."""
+        from . import _backend
+
+        def row():
+            sde = self.kernel.get_sde()
+            F = np.asarray(sde.F, np.float64)
+            blocks = _backend.nilpotent_blocks(F)
+            if blocks is None:
+                return None, None
+            Nm = F.copy()
+            for lo, n, lam, _ in blocks:
+                Nm[lo:lo + n, lo:lo + n] += lam * np.eye(n)
+            return ([np.array([b[2] for b in blocks]), Nm, np.asarray(sde.P0, np.float64),
+                     np.asarray(sde.H, np.float64).reshape(-1), np.float64(self.noise_variance)],
+                    [b[1] for b in blocks])
+
+        base, sizes = row()
+        d = None if base is None else base[1].shape[0]
+        if base is None or not (2 <= d <= _backend.GRAD_BLOCKS_DIM_MAX) or len(sizes) > _backend.GRAD_BLOCKS_MAX:
+            return None, None
+        rows = [tuple(base)]
+        for owner, name in self.trainable_parameters():
+            x0 = getattr(owner, name)
+
+            def central(h):
+                setattr(owner, name, x0 + h)
+                up, su = row()
+                setattr(owner, name, x0 - h)
+                dn, sd = row()
+                if up is None or dn is None or su != sizes or sd != sizes:
+                    raise NotImplementedError("the kernel's block structure changes with its parameters")
+                return [(u - v) / (2.0 * h) for u, v in zip(up, dn)]
+
+            try:
+                h = 1e-3 * max(abs(x0), 1e-3)
+                d1, d2 = central(h), central(0.5 * h)
+                rows.append(tuple((4.0 * b - a) / 3.0 for a, b in zip(d1, d2)))
+            finally:
+                setattr(owner, name, x0)
+        return rows, sizes
+
     def log_likelihood_and_grad(self, wrt=None):
         """(ll, grad): the marginal log-likelihood and its gradient with respect to
         `trainable_parameters()` -- what the reference obtains from tf.GradientTape over
@@ -230,6 +275,12 @@ class StateSpaceGP:
         ts, Y = self.data
         fused, lti = self._device_forms()
         if fused is None:
+            # sums / products of Matern kernels (block-nilpotent drift, d <= 6): exact, dual numbers through the scan
+            rows, sizes = (None, None)
+            if lti is not None and lti.F.shape[0] <= _backend.GRAD_BLOCKS_DIM_MAX:
+                rows, sizes = self._grad_rows_composite()
+            if rows is not None:
+                return _backend.gp_ll_grad_blocks(rows, sizes, ts.reshape(-1), Y.reshape(-1))
             # no dual-number path: batched differences on the general-LTI kernels (d <= 16), one evaluation at a
             # time above that (e.g. the CO2 kernel at its reference order, d = 18)
             return self._lti_ll_and_grad(batched=lti is not None, wrt=wrt)

@@ -90,3 +90,62 @@ def test_gradient_rejects_unsupported():
     m = StateSpaceGP((t[:, None], np.sin(t)[:, None]), RBF(1.0, 1.0, order=6, balancing_iter=5), 0.1, parallel=False)
     with pytest.raises(NotImplementedError):
         m.log_likelihood_and_grad()
+
+
+# ---- composite kernels: exact gradients (dual numbers through the scan, block-nilpotent drift) --------------------------
+def _dense_ll_and_grad(kernel_factory, theta, t, y):
+    """Dense-GP log marginal likelihood and its gradient by 6th-order central differences in fp64 (truncation ~1e-10)."""
+    def ll(th):
+        k, noise = kernel_factory(th)
+        K = k.K(t[:, None]) + noise * np.eye(t.size)
+        L = np.linalg.cholesky(K)
+        a = np.linalg.solve(L, y)
+        return -0.5 * a @ a - np.sum(np.log(np.diag(L))) - 0.5 * t.size * np.log(2 * np.pi)
+    g = np.zeros(theta.size)
+    for i in range(theta.size):
+        h = 1e-3 * max(abs(theta[i]), 1e-2)
+        e = np.zeros(theta.size); e[i] = h
+        g[i] = (45 * (ll(theta + e) - ll(theta - e)) - 9 * (ll(theta + 2 * e) - ll(theta - 2 * e)) + (ll(theta + 3 * e) - ll(theta - 3 * e))) / (60 * h)
+    return ll(theta), g
+
+
+@pytest.mark.parametrize("kind", ["sum", "prod", "sum3"])
+def test_composite_matern_gradient_is_exact(kind):
+    """`Matern32 + Matern52` and `Matern32 * Matern52` -- the composite kernels of the reference's gradient test
+    (tests/test_gp_vs_kfs.py:40-41,53-78, tolerance 1e-2 there) -- and a sum of two Matern-5/2: log_likelihood_and_grad
+    runs ONE dual-number pass per parameter through the scan (pgps_gp_ll_grad_blocks_*), no finite differences of the
+    likelihood; against the dense GP's gradient at 1e-6."""
+    from pssgp.kernels import Matern32, Matern52
+    from pssgp.model import StateSpaceGP
+    from pssgp import _backend as B
+    rng = np.random.default_rng(3)
+    t = np.sort(rng.uniform(0.0, 4.0, 160))
+    y = np.sin(2.0 * t) + 0.4 * np.cos(5.0 * t) + 0.2 * rng.standard_normal(t.size)
+
+    def factory(th):
+        if kind == "sum":
+            return Matern32(th[0], th[1]) + Matern52(th[2], th[3]), th[4]
+        if kind == "prod":
+            return Matern32(th[0], th[1]) * Matern52(th[2], th[3]), th[4]
+        return Matern52(th[0], th[1]) + Matern52(th[2], th[3]), th[4]
+
+    theta = np.array([0.8, 0.6, 1.3, 0.9, 0.15])
+    kern, noise = factory(theta)
+    m = StateSpaceGP((t[:, None], y[:, None]), kern, noise_variance=noise, parallel=True)
+    names = [n for _, n in m.trainable_parameters()]
+    assert names == ["variance", "lengthscales", "variance", "lengthscales", "noise_variance"]
+    rows, sizes = m._grad_rows_composite()
+    assert rows is not None and sizes == {"sum": [2, 3], "prod": [6], "sum3": [3, 3]}[kind]
+    ll, g = m.log_likelihood_and_grad()
+    ll_d, g_d = _dense_ll_and_grad(factory, theta, t, y)
+    assert abs(ll - ll_d) < 1e-8 * abs(ll_d)
+    assert np.max(np.abs(g - g_d)) < 1e-6 * np.max(np.abs(g_d)), (g, g_d)
+    # and the device call really is the dual-number one
+    calls = []
+    orig = B.gp_ll_grad_blocks
+    B.gp_ll_grad_blocks = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        m.log_likelihood_and_grad()
+    finally:
+        B.gp_ll_grad_blocks = orig
+    assert calls
