@@ -349,11 +349,34 @@ def main():
             dist.broadcast_object_list(box, src=0)
             return box[0]
 
-        seg = pdist.ShardedScan(ctx, pdist.share_unique_id(rank, broadcast=bcast), rank, world, d, dtype_np)
-        ptrs = [t.data_ptr() for t in (P0_d, Fs_d, Qs_d, H_d)] + [noise] + [t.data_ptr() for t in (ys_d, fms, fPs, sms, sPs, ll_d)]
+        lib_ok = 1
+        try:
+            seg = pdist.ShardedScan(ctx, pdist.share_unique_id(rank, broadcast=bcast), rank, world, d, dtype_np)
+        except Exception as e:                      # noqa: BLE001 -- reported, and decided together below
+            lib_ok = 0
+            print(f"[bench rank {rank}] RCCL communicator inside libpgps failed ({e!r}); "
+                  "falling back to --exchange torch", file=sys.stderr)
+        if world > 1:                               # every rank takes the same path
+            flag = torch.tensor([lib_ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            lib_ok = int(flag.item())
+        if lib_ok:
+            ptrs = [t.data_ptr() for t in (P0_d, Fs_d, Qs_d, H_d)] + [noise] + [t.data_ptr() for t in (ys_d, fms, fPs, sms, sPs, ll_d)]
 
-        def step():
-            seg.pkfs(n_local, *ptrs)
+            def step():
+                seg.pkfs(n_local, *ptrs)
+        else:
+            # the framework-hosted variant: the three library phases with torch.distributed's RCCL collectives in between
+            use_lib_exchange = False
+            try:
+                ctx.comm_destroy()
+            except Exception:                       # noqa: BLE001
+                pass
+            group = dist.new_group(backend="nccl") if world > 1 else None
+            seg = pdist.SegmentScan(ctx, rank, world, d, dtype_np, torch_device=dev, group=group)
+
+            def step():
+                seg.pkfs(n_local, P0_d, Fs_d, Qs_d, H_d, noise, ys_d, fms, fPs, sms, sPs, ll_d)
     else:
         from pssgp import distributed as pdist
         seg = pdist.SegmentScan(ctx, rank, world, d, dtype_np, torch_device=dev)
@@ -643,6 +666,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if use_lib_exchange and (world > 1 or args.force_segments) and args.path == "lgssm":
+        ctx.synchronize()
         seg.close()
     if world > 1:
         dist.destroy_process_group()

@@ -434,8 +434,9 @@ static int disc_dev(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, con
         if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)))
             return launch_disc_rc(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
     } else {
-        if (ctx->family == 0 && d > PGPS_MAX_DIM_LANE && d <= rc::kDimMax) {
-            // fp32 at 7 <= d <= 16: the arithmetic is fp64 in every discretisation kernel anyway; widen the inputs,
+        if (((ctx->family == 0 && d > PGPS_MAX_DIM_LANE) || ctx->family == 3) && d >= rc::kDimMin && d <= rc::kDimMax) {
+            // fp32 at 7 <= d <= 16 (or with the row-cooperative family forced): the arithmetic is fp64 in every
+            // discretisation kernel anyway; widen the inputs,
             // run the row-cooperative kernel, narrow the results
             const size_t n = (size_t)N, dd = (size_t)d * d;
             int rc_ = ensure(ctx, ctx->lti[7], (2 * dd + n + 2 * n * dd) * sizeof(double));
