@@ -73,3 +73,40 @@ def test_random_models_sizes_and_chains(seed):
     finally:
         ctx.set_family(0)
         ctx.set_chunk(0)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_models_fp32_row_cooperative(seed):
+    """The fp32 instantiations of the row-cooperative family (own kernels since round 2, forced here also below d = 7):
+    random stable SDEs of state dimension 2..16, ragged lengths against random chain lengths (whole-record LDS staging
+    with 4-, 8- and 16-byte record tails), missing observations -- filter, smoother and log-likelihood against the fp64
+    oracle at the fp32 tolerance of the north star (1e-3 of the largest entry; 3e-3 asserted for the random models)."""
+    from pssgp import _backend as B
+    rng = np.random.default_rng(7000 + seed)
+    ctx = B.get_context()
+    try:
+        for case in range(6):
+            d = int(rng.integers(2, 17))
+            n = int(rng.choice([1, 2, 5, 17, 64, 257, 700, 1500, 2600, 6000]))
+            chunk = int(rng.choice([0, 1, 3, 8, 13, 32, 100]))
+            F, P, H = _random_model(rng, d)
+            t = make_times(n, seed=seed * 100 + case)
+            ssm = _ssm(F, P, H, t, 0.2)
+            y = sample_series(ssm, seed=case, nan_frac=float(rng.choice([0.0, 0.2, 0.6])) if n > 3 else 0.0)
+            ssm32 = tuple(np.asarray(a, np.float32) for a in ssm)
+            ctx.set_family(3)
+            ctx.set_chunk(chunk)
+            sms, sPs, fms, fPs, ll = B.pkfs(ssm32, y.astype(np.float32), return_filtered=True, return_loglikelihood=True)
+            assert sms.dtype == np.float32
+            of, oP, oll = O.kf(ssm, y, True)
+            os_, osP = O.kfs(ssm, y)
+            tag = f"d={d} n={n} chunk={chunk}"
+            tol = 3e-3
+            assert relerr(fms, of) < tol and relerr(fPs, oP) < tol, tag
+            assert relerr(sms, os_) < tol and relerr(sPs, osP) < tol, tag
+            assert abs(float(ll) - oll) <= 1e-3 * abs(oll) + 1e-3, tag
+            s2, sP2 = B.pks(ssm32, of.astype(np.float32), oP.astype(np.float32))
+            assert relerr(s2, os_) < tol and relerr(sP2, osP) < tol, tag
+    finally:
+        ctx.set_family(0)
+        ctx.set_chunk(0)

@@ -67,7 +67,8 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     bad = 0
     for seed in range(first, first + count):
-        for name, fn in (("rc", T.test_random_models_sizes_and_chains), ("large_d", large_d_case)):
+        for name, fn in (("rc", T.test_random_models_sizes_and_chains), ("rc_fp32", T.test_random_models_fp32_row_cooperative),
+                         ("large_d", large_d_case)):
             try:
                 fn(seed)
             except Exception:
