@@ -18,8 +18,8 @@
  *     ABI; outputs are undefined after an error.
  *   - one call in flight per context; contexts are independent (one per GPU / per thread).
  *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels (one lane owns whole d x d operands), fp64
- *     series with 5 <= d <= 16 the row-cooperative ones (fp32 at 5 <= d <= 8 has its own row-cooperative kernels, fp32
- *     at 9..16 is widened to fp64 for them), up to PGPS_MAX_DIM the wave-cooperative ones; pgps_set_family overrides.
+ *     series with 5 <= d <= 16 and fp32 series with 7 <= d <= 16 the row-cooperative ones (built natively in both
+ *     precisions for 2 <= d <= 16), up to PGPS_MAX_DIM the wave-cooperative ones; pgps_set_family overrides.
  *     Every call takes every d <= PGPS_MAX_DIM except the segment calls (pgps_seg_*, pgps_pkfs_seg_*): d <= 16.
  *   - NaN in `ys` marks a missing observation (parallel.py:42,86-95).
  */
@@ -66,9 +66,9 @@ int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
  * 0 = off (three-launch reduce-then-scan), 1 = on; window = tiles per look-back window (1..256, 0 = keep). */
 int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
 /* Kernel family: 0 = automatic (lane-chunk for d <= 4 and for fp32 up to PGPS_MAX_DIM_LANE; row-cooperative for
- * fp64 with 5 <= d <= 16 -- fp32 series at 7 <= d <= 16 are widened to fp64 for it, segments use it above d = 6;
- * wave-cooperative otherwise, d <= 32),
- * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64, 2 <= d <= 16). */
+ * fp64 with 5 <= d <= 16 and fp32 with 7 <= d <= 16, segments use it above d = 6; wave-cooperative otherwise,
+ * d <= 32),
+ * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64 and fp32, 2 <= d <= 16). */
 int pgps_set_family(pgps_ctx* ctx, int family);
 /* (Diagnostic, environment: PGPS_WC_SERIAL3=1 when a context is created makes the wave-cooperative family walk its
  * group totals with one wave instead of the Kogge-Stone scan -- the cross-check of tests/test_gpu_wavecoop.py.) */

@@ -1091,13 +1091,20 @@ __global__ void k_scatter_block(long m, int d, int db, const int* __restrict__ i
 // Sum kernels give block-diagonal F and Pinf (pssgp/kernels/base.py:133-141), so expm(F dt) and Q are block-diagonal
 // too: connected components of the sparsity pattern of |F| + |F^T| + |Pinf|, single states attached to the smallest
 // block.  Returns the components (each sorted) when there are at least two and none is larger than `cap`.
+// An entry counts as a coupling when it exceeds 1e-14 of its matrix's largest entry: a Pinf that came out of a Lyapunov
+// solve carries rounding residue of that size between independent blocks, and dropping it moves the discretised
+// operands by the same relative amount -- five orders below the parity tolerance.
 static bool diagonal_blocks(int d, const double* F, const double* P, int cap, std::vector<std::vector<int>>& blocks) {
     std::vector<int> comp(d);
     for (int i = 0; i < d; ++i) comp[i] = i;
     auto find = [&](int x) { while (comp[x] != x) x = comp[x] = comp[comp[x]]; return x; };
+    double fmax = 0.0, pmax = 0.0;
+    for (int i = 0; i < d * d; ++i) { fmax = std::max(fmax, std::fabs(F[i])); pmax = std::max(pmax, std::fabs(P[i])); }
+    const double ftol = 1e-14 * fmax, ptol = 1e-14 * pmax;
+    auto coupled = [&](int i, int j) { return std::fabs(F[i * d + j]) > ftol || std::fabs(P[i * d + j]) > ptol; };
     for (int i = 0; i < d; ++i)
         for (int j = 0; j < d; ++j)
-            if (i != j && (F[i * d + j] != 0.0 || F[j * d + i] != 0.0 || P[i * d + j] != 0.0 || P[j * d + i] != 0.0)) {
+            if (i != j && (coupled(i, j) || coupled(j, i))) {
                 const int a = find(i), b = find(j);
                 if (a != b) comp[a] = b;
             }

@@ -1,7 +1,7 @@
 """The names the reference's experiment scripts share (pssgp/experiments/common.py:21-71): the model / covariance /
 sampler enumerations and the two factories.  `ModelEnum.GP` (GPflow's dense GPR) has no counterpart on this backend:
-the dense GP exists only as the test oracle; asking for it raises.  Of the samplers only HMC is implemented
-(pssgp/experiments/toy.py::hmc, real_data.py::hmc)."""
+the dense GP exists only as the test oracle; asking for it raises.  All three samplers are implemented
+(experiments/toy.py: hmc, mala_chain, nuts_chain; the real-data drivers pick one by --mcmc)."""
 import enum
 
 from ..kernels import Matern12, Matern32, Matern52, Periodic, RBF, SquaredExponential

@@ -185,21 +185,22 @@ def hmc(gp, n_samples=1000, n_burnin=100, step_size=0.05, n_leapfrogs=10, seed=3
 
 # ---- the reference's other two samplers (experiments/common.py:95-117 picks HMC, MALA or NUTS from tfp.mcmc) ---------
 def mala_chain(logp_and_grad, u0, n_samples, n_burnin, step_size, rng):
-    """Metropolis-adjusted Langevin: proposal u + step_size grad + sqrt(2 step_size) xi (tfp.mcmc's convention for
-    `step_size`), Metropolis-Hastings correction with the asymmetric proposal densities.  Returns (samples, acceptance)."""
+    """Metropolis-adjusted Langevin with tfp.mcmc's meaning of `step_size` (unit volatility): proposal
+    u + step_size / 2 grad + sqrt(step_size) xi, Metropolis-Hastings correction with the asymmetric proposal densities
+    N(u + step_size / 2 grad, step_size I).  Returns (samples, acceptance)."""
     u = np.asarray(u0, np.float64).copy()
     lp, g = logp_and_grad(u)
     out, accepted = [], 0
     for it in range(n_samples + n_burnin):
-        prop = u + step_size * g + math.sqrt(2.0 * step_size) * rng.standard_normal(u.shape)
+        prop = u + 0.5 * step_size * g + math.sqrt(step_size) * rng.standard_normal(u.shape)
         try:
             lpn, gn = logp_and_grad(prop)
             ok = np.isfinite(lpn) and np.all(np.isfinite(gn))
         except Exception:
             ok = False
         if ok:
-            fwd = -np.sum((prop - u - step_size * g) ** 2) / (4.0 * step_size)
-            bwd = -np.sum((u - prop - step_size * gn) ** 2) / (4.0 * step_size)
+            fwd = -np.sum((prop - u - 0.5 * step_size * g) ** 2) / (2.0 * step_size)
+            bwd = -np.sum((u - prop - 0.5 * step_size * gn) ** 2) / (2.0 * step_size)
             if math.log(rng.uniform()) < lpn + bwd - lp - fwd:
                 u, lp, g = prop, lpn, gn
                 accepted += it >= n_burnin

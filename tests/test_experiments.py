@@ -215,7 +215,7 @@ def test_mala_and_nuts_sample_a_gaussian():
     Si = np.linalg.inv(S)
     f = lambda u: (-0.5 * (u - mu) @ Si @ (u - mu), -Si @ (u - mu))
     rng = np.random.RandomState(1)
-    s, acc = mala_chain(f, np.zeros(3), 12000, 1000, 0.15, rng)
+    s, acc = mala_chain(f, np.zeros(3), 12000, 1000, 0.3, rng)
     assert 0.6 < acc <= 1.0 and np.max(np.abs(s.mean(0) - mu)) < 0.12 and np.max(np.abs(np.cov(s.T) - S)) < 0.15
     s, depth = nuts_chain(f, np.zeros(3), 2500, 300, 0.35, rng)
     assert 1.0 <= depth <= 8.0 and np.max(np.abs(s.mean(0) - mu)) < 0.12 and np.max(np.abs(np.cov(s.T) - S)) < 0.2
@@ -228,8 +228,8 @@ def test_run_chain_other_samplers_on_the_gpu_posterior(mcmc):
     from pssgp.experiments.common import MCMC
     t, _, _, _, y = toy.get_data(3, 400, 10)
     gp = toy.get_model("PSSGP", (t, y), 0.5, toy.get_covariance("Matern32", variance=1., lengthscales=1.))
-    theta, diag = toy.run_chain(gp, MCMC(mcmc), n_samples=40, n_burnin=20, step_size=1e-4 if mcmc == "MALA" else 0.05, seed=2)
-    # (MALA's drift is step_size * gradient and the posterior of 400 points is steep away from its mode: a small step)
+    theta, diag = toy.run_chain(gp, MCMC(mcmc), n_samples=40, n_burnin=20, step_size=2e-4 if mcmc == "MALA" else 0.05, seed=2)
+    # (MALA's drift is step_size / 2 * gradient and the posterior of 400 points is steep away from its mode: a small step)
     assert theta.shape == (40, 3) and np.all(np.isfinite(theta)) and np.all(theta > 0)
     assert np.std(theta[:, 0]) > 0          # the chain moves
     assert 0.0 < diag <= 8.0
