@@ -212,6 +212,14 @@ struct GjStep {
 // it to the end of the loop body (shortest live ranges) and expose the whole memory latency: fence it in.
 #define PGPS_RC_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// Waves per SIMD rc_reduce1 / rc_apply1 are compiled for (register budget 512 / waves).  At d = 11 fp64 they need
+// about 275 registers; compiled for two waves they spill 80..200 B per lane inside the step loop and lose 30 % --
+// and a second wave has nothing to hide: rc_smooth1 (158 registers) is no faster with two waves per SIMD than with
+// one, the fp64 DPP multiply-adds already fill the VALU (profiles/r02_experiments.txt).
+#ifndef PGPS_RC_WAVES
+#define PGPS_RC_WAVES 1
+#endif
+
 constexpr unsigned kOob = 0x7ffff000u;         // + any immediate offset: beyond every descriptor's range, no 32-bit wrap
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -537,7 +545,7 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
 }
 
 template <typename Real, int D>
-__global__ __launch_bounds__(64) void rc_reduce1(const RcArgsT<Real> a0) {
+__global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_reduce1(const RcArgsT<Real> a0) {
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     __shared__ __attribute__((aligned(16))) char wslots[2 * (Io<D, Real>::SLOT + 16)];
@@ -784,7 +792,7 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
 
 // STORE: the filtered moments are written (pkf / pkfs); not for the log-likelihood-only and projected-posterior calls
 template <typename Real, int D, bool SMOOTH, bool IMPQS, bool STORE>
-__global__ __launch_bounds__(64) void rc_apply1(const RcArgsT<Real> a0) {
+__global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_apply1(const RcArgsT<Real> a0) {
     static_assert(SMOOTH || !IMPQS, "the implicit-noise instantiation is the smoothing one");
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
