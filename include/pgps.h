@@ -20,7 +20,7 @@
  *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels (one lane owns whole d x d operands), fp64
  *     series with 5 <= d <= 16 and fp32 series with 7 <= d <= 16 the row-cooperative ones (built natively in both
  *     precisions for 2 <= d <= 16), up to PGPS_MAX_DIM the wave-cooperative ones; pgps_set_family overrides.
- *     Every call takes every d <= PGPS_MAX_DIM except the segment calls (pgps_seg_*, pgps_pkfs_seg_*): d <= 16.
+ *     Every call takes every d <= PGPS_MAX_DIM, the segment calls (pgps_seg_*, pgps_pkfs_seg_*) included.
  *   - NaN in `ys` marks a missing observation (parallel.py:42,86-95).
  */
 #ifndef PGPS_H_
@@ -329,7 +329,7 @@ int pgps_seg_smoother_apply_dev_f32(pgps_ctx*, long N, int d, int rank, int nran
  * halo, (3d^2+3d+d(d+1)) scalars per rank) -> filter -> ncclAllGather (smoothing totals + log-likelihood partial) ->
  * smoother, ALL enqueued on the context's stream: no host synchronisation, no framework.  Arguments as
  * pgps_pkfs_dev_* with this rank's arrays; P0 is the prior of the WHOLE series (used by rank 0), ll receives the
- * log-likelihood of the whole series on every rank.  d <= 16 (fp32: 7 <= d <= 16 computes in fp64).  nranks = 1 works
+ * log-likelihood of the whole series on every rank.  d <= PGPS_MAX_DIM, fp64 and fp32 natively.  nranks = 1 works
  * (RCCL copies locally).  pgps_comm_allgather_dev is the bare collective on the context's stream (bytes per rank). */
 #define PGPS_COMM_ID_BYTES 128
 int pgps_comm_get_unique_id(void* id);

@@ -348,6 +348,11 @@ struct WcArgs {
     T* scarry2;             // (ngroup, d + d^2) smoothed (m, P) of the first step after each group
     double* llpart;         // (nchunk,)
     T *ksA, *ksB;           // (ngroup, nfilt) each: Kogge-Stone ping-pong over the group totals (both scans)
+    // one segment of a series sharded over several GPUs (pgps_seg_*): whole series = first and last, no pointers
+    int seg_first, seg_last;
+    const T* carry_in;      // (d + d^2) filtered (m, P) entering the segment            (not seg_first)
+    const T* carry_back;    // (d + d^2) smoothed (m, P) of the next segment's first step (not seg_last)
+    const T *halo_F, *halo_Q;   // (d, d) each: F, Q of the next segment's first step     (not seg_last)
 };
 
 // One step's (F, Q) as register tiles: fetched a step ahead, parked in LDS when needed.
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(64) void wc_reduce1(const WcArgs<T> a) {
         const T y = yn;
         if (k + 1 < k1) { st.fetch(d, a.Fs + (k + 1) * dd, a.Qs + (k + 1) * dd); yn = a.ys[k + 1]; }
         sync();
-        if (k == 0) {
+        if (k == 0 && a.seg_first) {
             mat_g2l<T, DP>(d, a.P0, t1);
             sync();
             first_element<T, DP>(dk, acc, t1, y, h, a.R, v2);
@@ -700,8 +705,13 @@ __global__ __launch_bounds__(64) void wc_carry3(const WcArgs<T> a) {
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* m = pool.take(DP); T* P = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NFL);
     T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRA); T* X = pool.take(MSZ);
-    if (lane_id() < DP) m[lane_id()] = T(0);
-    mat_g2l<T, DP>(d, a.P0, P);
+    if (a.carry_in) {
+        vec_g2l<T, DP>(d, a.carry_in, m);
+        mat_g2l<T, DP>(d, a.carry_in + d, P);
+    } else {
+        if (lane_id() < DP) m[lane_id()] = T(0);
+        mat_g2l<T, DP>(d, a.P0, P);
+    }
     sync();
     symmetrise<T, DP>(P);
     sync();
@@ -739,7 +749,8 @@ __global__ __launch_bounds__(64) void wc_ks_filter(int d, long n, long stride, c
     filt_l2g<T, DP>(d, o, out + i * nf);
 }
 
-// (m, P) entering group g = the inclusive prefix of the groups before it applied to (0, P0); one wave per group
+// (m, P) entering group g = the inclusive prefix of the groups before it applied to (0, P0) -- or to the state entering
+// the segment; one wave per group
 template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_fin_filter(const WcArgs<T> a, const T* incl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -750,8 +761,13 @@ __global__ __launch_bounds__(64) void wc_fin_filter(const WcArgs<T> a, const T* 
     T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRA); T* X = pool.take(MSZ);
     const int g = blockIdx.x;
     if (g >= a.ngroup) return;
-    if (lane_id() < DP) m[lane_id()] = T(0);
-    mat_g2l<T, DP>(d, a.P0, P);
+    if (a.carry_in) {                       // a later segment: the state the segments before it leave behind
+        vec_g2l<T, DP>(d, a.carry_in, m);
+        mat_g2l<T, DP>(d, a.carry_in + d, P);
+    } else {
+        if (lane_id() < DP) m[lane_id()] = T(0);
+        mat_g2l<T, DP>(d, a.P0, P);
+    }
     sync();
     symmetrise<T, DP>(P);
     sync();
@@ -800,6 +816,79 @@ __global__ __launch_bounds__(64) void wc_fin_smoother(const WcArgs<T> a, const T
     const T* rec = sfx + (long)(g + 1) * ns;
     for (int e = lane_id(); e < d + dd; e += 64)
         out[e] = last ? T(0) : (e < d ? rec[2 * dd + e] : rec[dd + (e - d)]);
+}
+
+// The same with a state behind the segment (a series sharded over several GPUs): (sm, sP) of the next segment's first
+// step pushed back through the suffix total that starts at group g + 1; one wave per group.
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_fin_smoother_cb(const WcArgs<T> a, const T* sfx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MSZ = Geo<DP>::MSZ;
+    const int d = a.d, dd = d * d, ns = nsmth(d), dk = (d + 3) & ~3;
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* sm = pool.take(DP); T* sP = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NSL);
+    T* X = pool.take(MSZ); T* Y = pool.take(MSZ); T* v = pool.take(DP);
+    const int g = blockIdx.x;
+    if (g >= a.ngroup) return;
+    vec_g2l<T, DP>(d, a.carry_back, sm);
+    mat_g2l<T, DP>(d, a.carry_back + d, sP);
+    sync();
+    if (g < a.ngroup - 1) {
+        smth_g2l<T, DP>(d, sfx + (long)(g + 1) * ns, cur);
+        sync();
+        sapply<T, DP>(dk, cur, sm, sP, X, v, Y);
+    }
+    T* out = a.scarry2 + (long)g * (d + dd);
+    vec_l2g<T, DP>(d, sm, out);
+    mat_l2g<T, DP>(d, sP, out + d);
+}
+
+// Segment stitching, one wave: the filtered (m, P) entering segment `rank` = the totals of the segments before it
+// (compact records [A | C | J | b | eta], `rank` of them) applied in order to (0, P0) -- segment 0 holds the series'
+// first element, so its total already forgets the start.
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_seg_carry_f(int d, const T* P0, const T* recs, int rank, T* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MSZ = Geo<DP>::MSZ;
+    const int nf = nfilt(d), dk = (d + 3) & ~3;
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* m = pool.take(DP); T* P = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NFL);
+    T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRA); T* X = pool.take(MSZ);
+    if (lane_id() < DP) m[lane_id()] = T(0);
+    mat_g2l<T, DP>(d, P0, P);
+    sync();
+    symmetrise<T, DP>(P);
+    sync();
+    for (int r = 0; r < rank; ++r) {
+        filt_g2l<T, DP>(d, recs + (long)r * nf, cur);
+        sync();
+        apply<T, DP>(d, dk, m, P, cur, M, rhs, X);
+        sync();
+    }
+    vec_l2g<T, DP>(d, m, out);
+    mat_l2g<T, DP>(d, P, out + d);
+}
+
+// ... and the smoothed (sm, sP) of the first step of segment rank + 1 = the smoothing totals (compact [E | L | g]) of the
+// segments behind, applied from the last one backwards to the zero state beyond the end of the series.
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_seg_carry_s(int d, const T* recs, int rank, int nranks, T* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MSZ = Geo<DP>::MSZ;
+    const int ns = nsmth(d), dk = (d + 3) & ~3;
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* sm = pool.take(DP); T* sP = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NSL);
+    T* X = pool.take(MSZ); T* Y = pool.take(MSZ); T* v = pool.take(DP);
+    if (lane_id() < DP) sm[lane_id()] = T(0);
+    slot_zero(MSZ, sP);
+    sync();
+    for (int r = nranks - 1; r > rank; --r) {
+        smth_g2l<T, DP>(d, recs + (long)r * ns, cur);
+        sync();
+        sapply<T, DP>(dk, cur, sm, sP, X, v, Y);
+    }
+    vec_l2g<T, DP>(d, sm, out);
+    mat_l2g<T, DP>(d, sP, out + d);
 }
 
 // smoother gain E = (Pp^-1 F P)^T from Pp and FP (both LDS matrices); M, rhs scratch
@@ -859,9 +948,10 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
     long long expo = 0, count = 0;
     for (long k = k0; k <= k1; ++k) {
         const bool halo = (k == k1);
-        if (halo && (!SMOOTH || k == a.N)) break;
+        if (halo && (!SMOOTH || (k == a.N && a.seg_last))) break;
         st.park(F, Q);
         if (k + 1 < a.N && (k + 1 < k1 || SMOOTH)) st.fetch(d, a.Fs + (k + 1) * dd, a.Qs + (k + 1) * dd);
+        else if (SMOOTH && k + 1 == a.N && !a.seg_last) st.fetch(d, a.halo_F, a.halo_Q);      // the next segment's first step
         if (SMOOTH) {
             if (lane_id() < DP) mprev[lane_id()] = m[lane_id()];
             slot_copy(MSZ, P, Pprev);
@@ -892,7 +982,7 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
         if (halo) break;
         const T y = a.ys[k];
         const bool obs = !(y != y);
-        const bool first = (k == 0);
+        const bool first = (k == 0 && a.seg_first);
         // log-likelihood term from the predicted moments (also for the first step)
         mv<T, DP, false>(dk, Pp, h, u);
         sync();
@@ -929,7 +1019,7 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
         vec_l2g<T, DP>(d, m, a.fms + k * d);
         mat_l2g<T, DP>(d, P, a.fPs + k * dd);
     }
-    if (SMOOTH && k1 == a.N) {
+    if (SMOOTH && k1 == a.N && a.seg_last) {
         // last element of the series: (0, m_N, P_N)
         Smth<T, DP> e(Ee);
         slot_zero(MSZ, e.E);
@@ -1027,13 +1117,15 @@ __global__ __launch_bounds__(64) void wc_smooth1(const WcArgs<T> a) {
     }
     StepTiles<T, DP> st;
     if (k1 < a.N) st.fetch(d, a.Fs + k1 * dd, a.Qs + k1 * dd);
+    else if (!a.seg_last) st.fetch(d, a.halo_F, a.halo_Q);
     for (long k = k1 - 1; k >= k0; --k) {
+        const bool terminal = (k == a.N - 1 && a.seg_last);
         mat_g2l<T, DP>(d, a.fPs + k * dd, P);
         vec_g2l<T, DP>(d, a.fms + k * d, m);
-        if (k < a.N - 1) st.park(F, Q);                 // (F, Q) of step k+1
+        if (!terminal) st.park(F, Q);                   // (F, Q) of step k+1
         if (k > k0) st.fetch(d, a.Fs + k * dd, a.Qs + k * dd);
         sync();
-        if (k == a.N - 1) {
+        if (terminal) {
             if (lane_id() < DP) sm[lane_id()] = m[lane_id()];
             slot_copy(MSZ, P, sP);
             sync();
@@ -1170,11 +1262,101 @@ static __global__ __launch_bounds__(64) void wc_ll_finalize(const double* llpart
 
 }  // namespace wc
 
+// ---- segment records (pgps_seg_*): shared by the row-cooperative and the wave-cooperative drivers ------------
+namespace rc {
+__host__ __device__ inline int sym_index(int d, int i, int j) {
+    return i <= j ? (i * d - (i * (i - 1)) / 2 + (j - i)) : (j * d - (j * (j - 1)) / 2 + (i - j));
+}
+// this segment's filter record [A | b | C sym | J sym | eta | F_0 | Q_0] from the compact total [A | C | J | b | eta]
+template <typename Real>
+static __global__ __launch_bounds__(256) void seg_pack_f(int d, const Real* tot, const Real* Fs, const Real* Qs, Real* rec) {
+    const int dd = d * d, sym = d * (d + 1) / 2;
+    for (int e = threadIdx.x; e < dd; e += 256) {
+        const int i = e / d, j = e % d;
+        rec[e] = tot[e];
+        if (i <= j) {
+            rec[dd + d + sym_index(d, i, j)] = tot[dd + e];
+            rec[dd + d + sym + sym_index(d, i, j)] = tot[2 * dd + e];
+        }
+        rec[dd + 2 * d + 2 * sym + e] = Fs[e];
+        rec[2 * dd + 2 * d + 2 * sym + e] = Qs[e];
+    }
+    for (int e = threadIdx.x; e < d; e += 256) { rec[dd + e] = tot[3 * dd + e]; rec[dd + d + 2 * sym + e] = tot[3 * dd + d + e]; }
+}
+// this segment's smoother record [E | g | L sym | pad | ll partial] from the compact total [E | L | g]
+template <typename Real>
+static __global__ __launch_bounds__(256) void seg_pack_s(int d, const Real* tot, const double* llpart, long nchunk, int pad,
+                                                         Real* rec) {
+    __shared__ double part[4];
+    const int dd = d * d;
+    for (int e = threadIdx.x; e < dd; e += 256) {
+        const int i = e / d, j = e % d;
+        rec[e] = tot[e];
+        if (i <= j) rec[dd + d + sym_index(d, i, j)] = tot[dd + e];
+    }
+    for (int e = threadIdx.x; e < d; e += 256) rec[dd + e] = tot[2 * dd + e];
+    double t = 0.0;
+    for (long c = threadIdx.x; c < nchunk; c += 256) t += llpart[c];
+    t = wc::wave_sum(t);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    // the log-likelihood partial travels as a double whatever the record's type (two floats' worth of room: pad is even)
+    if (threadIdx.x == 0) *reinterpret_cast<double*>(rec + pad) = part[0] + part[1] + part[2] + part[3];
+}
+template <typename Real>
+static __global__ void seg_ll_sum(const Real* gathered_s, int nranks, int reclen, int pad, double* ll) {
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int r = 0; r < nranks; ++r) t += *reinterpret_cast<const double*>(gathered_s + (long)r * reclen + pad);
+        *ll = t;
+    }
+}
+
+// the inverse of the two packers, one workgroup per rank: gathered records -> compact totals (wave-cooperative layouts)
+template <typename Real>
+static __global__ __launch_bounds__(256) void seg_unpack_f(int d, const Real* gathered, int reclen, Real* out) {
+    const int dd = d * d, sym = d * (d + 1) / 2;
+    const Real* rec = gathered + (long)blockIdx.x * reclen;
+    Real* tot = out + (long)blockIdx.x * (3 * dd + 2 * d);
+    for (int e = threadIdx.x; e < dd; e += 256) {
+        const int i = e / d, j = e % d;
+        tot[e] = rec[e];
+        tot[dd + e] = rec[dd + d + sym_index(d, i, j)];
+        tot[2 * dd + e] = rec[dd + d + sym + sym_index(d, i, j)];
+    }
+    for (int e = threadIdx.x; e < d; e += 256) { tot[3 * dd + e] = rec[dd + e]; tot[3 * dd + d + e] = rec[dd + d + 2 * sym + e]; }
+}
+template <typename Real>
+static __global__ __launch_bounds__(256) void seg_unpack_s(int d, const Real* gathered, int reclen, Real* out) {
+    const int dd = d * d;
+    const Real* rec = gathered + (long)blockIdx.x * reclen;
+    Real* tot = out + (long)blockIdx.x * (2 * dd + d);
+    for (int e = threadIdx.x; e < dd; e += 256) {
+        const int i = e / d, j = e % d;
+        tot[e] = rec[e];
+        tot[dd + e] = rec[dd + d + sym_index(d, i, j)];
+    }
+    for (int e = threadIdx.x; e < d; e += 256) tot[2 * dd + e] = rec[dd + e];
+}
+}  // namespace rc
+
 // ---- host side ----------------------------------------------------------------------------------------
 static inline size_t wc_align(size_t x) { return (x + 255) / 256 * 256; }
 
+// one segment of a sharded series (pgps_seg_*): the records exchanged between the ranks and the scratch of the stitching
+template <typename T>
+struct WcSeg {
+    int rank, nranks;
+    T* rec_f; const T* gathered_f;
+    T* rec_s; const T* gathered_s;
+    T *tot_f, *tot_s;           // (nranks, nfilt) / (nranks, nsmth): the gathered totals, unpacked
+    T *carry_in, *carry_back;   // (d + d^2) each
+    T* halo;                    // (2, d, d): F, Q of the next segment's first step, kept for the smoother phase
+    double* ll;
+};
+
 template <typename T, int DP>
-static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode) {
+static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const WcSeg<T>* sg = nullptr) {
     using namespace wc;
     using GE = Geo<DP>;
     const size_t pad = 64;
@@ -1207,9 +1389,93 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode) {
     WC_ATTR((wc_sreduce2<T, DP>), l_sred2);
     WC_ATTR((wc_scarry3<T, DP>), l_scarry3);
     WC_ATTR((wc_smooth1<T, DP>), l_smooth1);
+    WC_ATTR((wc_fin_smoother_cb<T, DP>), l_scarry3);
+    WC_ATTR((wc_seg_carry_f<T, DP>), l_carry3);
+    WC_ATTR((wc_seg_carry_s<T, DP>), l_scarry3);
 #undef WC_ATTR
     attr_done = true;
     const dim3 blk(64), g1((unsigned)a.nchunk), g2((unsigned)a.ngroup);
+    if (sg) {
+        // Three phases with the ranks' records exchanged in between (pssgp/distributed.py); chunk / group totals, their
+        // scans and the in-group prefixes stay in the workspace from one phase to the next.
+        if (ctx->wc_serial3) return PGPS_E_UNSUPPORTED_DIM;     // the diagnostic serial walk keeps no inclusive totals
+        const int d = a.d, dd = d * d, nf = nfilt(d), ns = nsmth(d);
+        const int rf = seg_rec_f_len(d), rs = seg_rec_s_len(d), spad = seg_rec_s_pad(d);
+        const int nfp = dd + d + d * (d + 1) + d;               // packed five-tuple ahead of (F_0, Q_0) in a filter record
+        // Kogge-Stone over the group totals: first -> ksA -> ksB -> ksA ...; where a finished scan lies
+        auto ks_where = [&](T* first) {
+            int steps = 0;
+            for (long st = 1; st < a.ngroup; st <<= 1) ++steps;
+            return steps == 0 ? first : ((steps & 1) ? a.ksA : a.ksB);
+        };
+        if (mode == MODE_SEG_REDUCE) {
+            timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T, DP>, g1, blk, (unsigned)bytes(l_reduce1), a);
+            timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce2<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a);
+            const T* cur = a.agg2;
+            T* nxt = a.ksA;
+            for (long stride = 1; stride < a.ngroup; stride <<= 1) {
+                timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_ks_filter<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a.d,
+                             (long)a.ngroup, stride, cur, nxt);
+                cur = nxt;
+                nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
+            }
+            hipLaunchKernelGGL(rc::seg_pack_f<T>, dim3(1), dim3(256), 0, ctx->stream, d, cur + (long)(a.ngroup - 1) * nf, a.Fs,
+                               a.Qs, sg->rec_f);
+            HIPCHK(ctx, hipGetLastError());
+            return PGPS_OK;
+        }
+        if (mode == MODE_SEG_FILTER) {
+            const T* incl = ks_where(a.agg2);
+            if (!a.seg_first) {
+                hipLaunchKernelGGL(rc::seg_unpack_f<T>, dim3((unsigned)sg->rank), dim3(256), 0, ctx->stream, d, sg->gathered_f, rf,
+                                   sg->tot_f);
+                hipLaunchKernelGGL((wc_seg_carry_f<T, DP>), dim3(1), blk, (unsigned)bytes(l_carry3), ctx->stream, d, a.P0,
+                                   (const T*)sg->tot_f, sg->rank, sg->carry_in);
+                a.carry_in = sg->carry_in;
+            }
+            if (!a.seg_last) {
+                HIPCHK(ctx, hipMemcpyAsync(sg->halo, sg->gathered_f + (long)(sg->rank + 1) * rf + nfp, 2 * (size_t)dd * sizeof(T),
+                                           hipMemcpyDeviceToDevice, ctx->stream));
+                a.halo_F = sg->halo;
+                a.halo_Q = sg->halo + dd;
+            }
+            timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_fin_filter<T, DP>, g2, blk, (unsigned)bytes(l_carry3), a, incl);
+            timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, DP, true>, g1, blk, (unsigned)bytes(l_apply1), a);
+            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_sreduce2<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a);
+            const T* cur = a.sagg2;
+            T* nxt = a.ksA;
+            for (long stride = 1; stride < a.ngroup; stride <<= 1) {
+                timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_ks_smoother<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a.d,
+                             (long)a.ngroup, stride, cur, nxt);
+                cur = nxt;
+                nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
+            }
+            // the suffix that starts at group 0 is the whole segment
+            hipLaunchKernelGGL(rc::seg_pack_s<T>, dim3(1), dim3(256), 0, ctx->stream, d, cur, (const double*)a.llpart,
+                               (long)a.nchunk, spad, sg->rec_s);
+            HIPCHK(ctx, hipGetLastError());
+            return PGPS_OK;
+        }
+        // MODE_SEG_SMOOTHER
+        const T* sfx = ks_where(a.sagg2);
+        if (!a.seg_last) {
+            hipLaunchKernelGGL(rc::seg_unpack_s<T>, dim3((unsigned)sg->nranks), dim3(256), 0, ctx->stream, d, sg->gathered_s, rs,
+                               sg->tot_s);
+            hipLaunchKernelGGL((wc_seg_carry_s<T, DP>), dim3(1), blk, (unsigned)bytes(l_scarry3), ctx->stream, d,
+                               (const T*)sg->tot_s, sg->rank, sg->nranks, sg->carry_back);
+            a.carry_back = sg->carry_back;
+            a.halo_F = sg->halo;
+            a.halo_Q = sg->halo + dd;
+            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_fin_smoother_cb<T, DP>, g2, blk, (unsigned)bytes(l_scarry3), a, sfx);
+        } else {
+            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_fin_smoother<T>, g2, blk, 0u, a, sfx);
+        }
+        timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_smooth1<T, DP>, g1, blk, (unsigned)bytes(l_smooth1), a);
+        if (sg->ll)
+            hipLaunchKernelGGL(rc::seg_ll_sum<T>, dim3(1), dim3(64), 0, ctx->stream, sg->gathered_s, sg->nranks, rs, spad, sg->ll);
+        HIPCHK(ctx, hipGetLastError());
+        return PGPS_OK;
+    }
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T, DP>, g1, blk, (unsigned)bytes(l_reduce1), a);
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce2<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a);
     // level 3: Kogge-Stone over the group totals, ping-pong agg2 -> ksA -> ksB -> ...; serial wc_carry3 / wc_scarry3
@@ -1261,8 +1527,8 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode) {
 template <typename T>
 int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     using namespace wc;
-    if (mode == MODE_PKS || mode == MODE_SEG_REDUCE || mode == MODE_SEG_FILTER || mode == MODE_SEG_SMOOTHER)
-        return PGPS_E_UNSUPPORTED_DIM;      // stand-alone pks / segments: lane-chunk family (d <= 6) only
+    if (mode == MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;      // stand-alone pks: the other two families (d <= 16)
+    const bool seg = mode == MODE_SEG_REDUCE || mode == MODE_SEG_FILTER || mode == MODE_SEG_SMOOTHER;
     if (d < 1 || d > 32) return PGPS_E_UNSUPPORTED_DIM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     WcArgs<T> a{};
@@ -1277,7 +1543,9 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     a.kgroup = (int)(kg < 8 ? 8 : (kg > kGroupMax ? kGroupMax : kg));
     a.ngroup = (int)((a.nchunk + a.kgroup - 1) / a.kgroup);
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
-    a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs; a.ll = sa.ll;
+    a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs; a.ll = seg ? nullptr : sa.ll;
+    a.seg_first = seg ? (sa.rank == 0) : 1;
+    a.seg_last = seg ? (sa.rank == sa.nranks - 1) : 1;
     const size_t dd = (size_t)d * d, nf = nfilt(d), ns = nsmth(d), nc = (size_t)a.nchunk, ng = (size_t)a.ngroup;
     size_t off = 0;
     const size_t o_agg1 = off;   off = wc_align(off + nc * nf * sizeof(T));
@@ -1291,6 +1559,13 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     const size_t o_ll = off;     off = wc_align(off + nc * sizeof(double));
     const size_t o_ksA = off;    off = wc_align(off + ng * nf * sizeof(T));
     const size_t o_ksB = off;    off = wc_align(off + ng * nf * sizeof(T));
+    // segments: the same layout in all three phases (the workspace must not move between them)
+    const size_t nr = seg ? (size_t)sa.nranks : 0;
+    const size_t o_totf = off;   off = wc_align(off + nr * nf * sizeof(T));
+    const size_t o_tots = off;   off = wc_align(off + nr * ns * sizeof(T));
+    const size_t o_cin = off;    if (seg) off = wc_align(off + (d + dd) * sizeof(T));
+    const size_t o_cback = off;  if (seg) off = wc_align(off + (d + dd) * sizeof(T));
+    const size_t o_halo = off;   if (seg) off = wc_align(off + 2 * dd * sizeof(T));
     int rc = ensure(ctx, ctx->ws, off);
     if (rc) return rc;
     char* base = (char*)ctx->ws.p;
@@ -1298,11 +1573,20 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     a.carry2 = (T*)(base + o_carry2); a.sagg1 = (T*)(base + o_sagg1); a.lsuf1 = (T*)(base + o_lsuf1);
     a.sagg2 = (T*)(base + o_sagg2); a.scarry2 = (T*)(base + o_sc2); a.llpart = (double*)(base + o_ll);
     a.ksA = (T*)(base + o_ksA); a.ksB = (T*)(base + o_ksB);
-    if (d <= 8) return launch_scan_wc_dp<T, 8>(ctx, a, mode);
-    if (d <= 12) return launch_scan_wc_dp<T, 12>(ctx, a, mode);
-    if (d <= 16) return launch_scan_wc_dp<T, 16>(ctx, a, mode);
-    if (d <= 24) return launch_scan_wc_dp<T, 24>(ctx, a, mode);
-    return launch_scan_wc_dp<T, 32>(ctx, a, mode);
+    WcSeg<T> sgv{};
+    if (seg) {
+        sgv.rank = sa.rank; sgv.nranks = sa.nranks;
+        sgv.rec_f = sa.rec_f; sgv.gathered_f = sa.gathered_f; sgv.rec_s = sa.rec_s; sgv.gathered_s = sa.gathered_s;
+        sgv.tot_f = (T*)(base + o_totf); sgv.tot_s = (T*)(base + o_tots);
+        sgv.carry_in = (T*)(base + o_cin); sgv.carry_back = (T*)(base + o_cback); sgv.halo = (T*)(base + o_halo);
+        sgv.ll = sa.ll;
+    }
+    const WcSeg<T>* sg = seg ? &sgv : nullptr;
+    if (d <= 8) return launch_scan_wc_dp<T, 8>(ctx, a, mode, sg);
+    if (d <= 12) return launch_scan_wc_dp<T, 12>(ctx, a, mode, sg);
+    if (d <= 16) return launch_scan_wc_dp<T, 16>(ctx, a, mode, sg);
+    if (d <= 24) return launch_scan_wc_dp<T, 24>(ctx, a, mode, sg);
+    return launch_scan_wc_dp<T, 32>(ctx, a, mode, sg);
 }
 
 template <typename T, int DP>
@@ -1396,54 +1680,6 @@ static int seg_carry(pgps_ctx* ctx, int d, int which, const Real* gathered, int 
 #undef PGPS_RC_CASE
     }
     return PGPS_E_UNSUPPORTED_DIM;
-}
-
-__host__ __device__ inline int sym_index(int d, int i, int j) {
-    return i <= j ? (i * d - (i * (i - 1)) / 2 + (j - i)) : (j * d - (j * (j - 1)) / 2 + (i - j));
-}
-// this segment's filter record [A | b | C sym | J sym | eta | F_0 | Q_0] from the compact total [A | C | J | b | eta]
-template <typename Real>
-static __global__ __launch_bounds__(256) void seg_pack_f(int d, const Real* tot, const Real* Fs, const Real* Qs, Real* rec) {
-    const int dd = d * d, sym = d * (d + 1) / 2;
-    for (int e = threadIdx.x; e < dd; e += 256) {
-        const int i = e / d, j = e % d;
-        rec[e] = tot[e];
-        if (i <= j) {
-            rec[dd + d + sym_index(d, i, j)] = tot[dd + e];
-            rec[dd + d + sym + sym_index(d, i, j)] = tot[2 * dd + e];
-        }
-        rec[dd + 2 * d + 2 * sym + e] = Fs[e];
-        rec[2 * dd + 2 * d + 2 * sym + e] = Qs[e];
-    }
-    for (int e = threadIdx.x; e < d; e += 256) { rec[dd + e] = tot[3 * dd + e]; rec[dd + d + 2 * sym + e] = tot[3 * dd + d + e]; }
-}
-// this segment's smoother record [E | g | L sym | pad | ll partial] from the compact total [E | L | g]
-template <typename Real>
-static __global__ __launch_bounds__(256) void seg_pack_s(int d, const Real* tot, const double* llpart, long nchunk, int pad,
-                                                         Real* rec) {
-    __shared__ double part[4];
-    const int dd = d * d;
-    for (int e = threadIdx.x; e < dd; e += 256) {
-        const int i = e / d, j = e % d;
-        rec[e] = tot[e];
-        if (i <= j) rec[dd + d + sym_index(d, i, j)] = tot[dd + e];
-    }
-    for (int e = threadIdx.x; e < d; e += 256) rec[dd + e] = tot[2 * dd + e];
-    double t = 0.0;
-    for (long c = threadIdx.x; c < nchunk; c += 256) t += llpart[c];
-    t = wc::wave_sum(t);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
-    __syncthreads();
-    // the log-likelihood partial travels as a double whatever the record's type (two floats' worth of room: pad is even)
-    if (threadIdx.x == 0) *reinterpret_cast<double*>(rec + pad) = part[0] + part[1] + part[2] + part[3];
-}
-template <typename Real>
-static __global__ void seg_ll_sum(const Real* gathered_s, int nranks, int reclen, int pad, double* ll) {
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int r = 0; r < nranks; ++r) t += *reinterpret_cast<const double*>(gathered_s + (long)r * reclen + pad);
-        *ll = t;
-    }
 }
 
 template <typename Real>

@@ -163,6 +163,9 @@ def _seg_kernel(name):
         "m32+m52": lambda: Matern32(1., 1.) + Matern52(1., 0.7),                                     # d = 5: lane-chunk
         "rbf8": lambda: RBF(variance=1., lengthscales=0.7, order=8, balancing_iter=10),              # d = 8: row-cooperative
         "c5": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.),
+        # above d = 16: the wave-cooperative family (the reference's CO2 kernel, d = 18; Periodic order 10, d = 22)
+        "co2": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern32(0.5, 5.) + Matern32(1., 2.),
+        "periodic10": lambda: Periodic(SquaredExponential(1., 0.8), period=1.5, order=10),
     }[name]()
 
 
@@ -172,7 +175,10 @@ def _seg_kernel(name):
     (4, np.float32, "m32+m52", 0),
     # the row-cooperative family's segment protocol: forced at d = 5, automatic above d = 6
     (3, np.float64, "m32+m52", 3), (1, np.float64, "rbf8", 0), (2, np.float64, "rbf8", 0), (8, np.float64, "rbf8", 0),
-    (3, np.float64, "c5", 0), (5, np.float64, "c5", 0)])
+    (3, np.float64, "c5", 0), (5, np.float64, "c5", 0),
+    # the wave-cooperative family's: automatic above d = 16, forced (family 2) below
+    (1, np.float64, "co2", 0), (2, np.float64, "co2", 0), (5, np.float64, "co2", 0), (3, np.float64, "periodic10", 0),
+    (3, np.float32, "co2", 0), (3, np.float64, "rbf8", 2), (4, np.float64, "m32+m52", 2)])
 def test_segments_on_one_gpu(world, dtype, kname, family):
     from pssgp import _backend as B
     from pssgp.distributed import record_lengths, split_segments
@@ -392,7 +398,8 @@ def test_config_c4_scale_eight_segments_on_one_gpu():
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,kname", [(np.float64, None), (np.float64, "m32+m52"), (np.float32, "m32+m52"),
-                                         (np.float64, "rbf8"), (np.float32, "rbf8"), (np.float64, "c5")])
+                                         (np.float64, "rbf8"), (np.float32, "rbf8"), (np.float64, "c5"),
+                                         (np.float64, "co2")])
 def test_rccl_communicator_in_library_world_1(dtype, kname, tmp_path):
     """pgps_comm_init + pgps_pkfs_seg_dev_* with a REAL RCCL communicator of one rank (all this box has): the five
     launches and the two ncclAllGathers of a pass go out on the context's stream with no host step in between, no
@@ -434,7 +441,7 @@ def test_rccl_communicator_in_library_world_1(dtype, kname, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kname", [None, "rbf8"])
+@pytest.mark.parametrize("kname", [None, "rbf8", "co2"])
 def test_segment_phases_out_of_order_are_refused(kname):
     """The three phases keep state in the context's scratch (for d > 6 the smoothing elements themselves): a phase
     that does not directly follow its predecessor on the context gets PGPS_E_INVALID, not stale scratch."""
