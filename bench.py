@@ -48,6 +48,8 @@ for p in (ROOT, os.path.join(ROOT, "parallel-gps_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+# vector (non-MFMA) FMA peaks, SURVEY.md 8(d): the path has no dense contraction, the matrix cores never apply
+VECTOR_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
 
 
 def parse():
@@ -211,6 +213,17 @@ SLOT_BYTES = {"k_filter_reduce": lambda d, w: (2 * d * d + 1) * w,
               "k_smoother_reduce": lambda d, w: (3 * d * d + d) * w,
               "k_smoother_apply": lambda d, w: (4 * d * d + 2 * d) * w}
 SLOT_INDEX = {"k_filter_reduce": 0, "k_filter_apply": 1, "k_smoother_reduce": 2, "k_smoother_apply": 3}
+
+
+def vector_fp(d, suf, n_local, ms_per_pass, alg_bytes_step):
+    flops_step = 64 * d ** 3 + 40 * d ** 2
+    peak = VECTOR_PEAK_TFLOPS[suf]
+    achieved = flops_step * n_local / (ms_per_pass * 1e-3) / 1e12
+    lb_hbm = alg_bytes_step * n_local / (HBM_PEAK_GBPS * 1e9) * 1e3
+    lb_fp = flops_step * n_local / (peak * 1e12) * 1e3
+    return {"flops_per_step": flops_step, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "lower_bound_ms": max(lb_hbm, lb_fp), "lower_bound_by": "hbm" if lb_hbm >= lb_fp else "vector_fp",
+            "frac_of_lower_bound": max(lb_hbm, lb_fp) / ms_per_pass}
 
 
 def committed_traffic(key, slot):
@@ -498,7 +511,11 @@ def main():
                      # the whole pass against its algorithmic bytes B_alg = (7d^2+3d+1)w per step, per GPU,
                      # from the GPU-event time of the timed region
                      "whole_path_GBps": whole_gbps, "whole_path_frac": whole_gbps / HBM_PEAK_GBPS,
-                     "algorithmic_bytes_per_step": alg_bytes_step},
+                     "algorithmic_bytes_per_step": alg_bytes_step,
+                     # from d = 6 the path sits near the vector-FMA ridge, so the same pass is also
+                     # priced against the vector peak with the work-efficient-scan estimate 64 d^3 + 40 d^2 flop per
+                     # step; lower_bound_ms = max(bytes / HBM peak, flops / vector peak) for this rank's steps
+                     "vector_fp": vector_fp(d, suf, n_local, gpu_ms / args.steps, alg_bytes_step)},
         "whole_path_effective_GBps": alg_bytes_step * n_total * args.steps / elapsed / 1e9,
         "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in breakdown.items() if v[1]},
         "kernel_ms_per_pass": {k: v[0] / n_break for k, v in breakdown.items() if v[1]},
