@@ -213,9 +213,9 @@ struct GjStep {
 #define PGPS_RC_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // Waves per SIMD rc_reduce1 / rc_apply1 are compiled for (register budget 512 / waves).  At d = 11 fp64 they need
-// about 275 registers; compiled for two waves they spill 80..200 B per lane inside the step loop and lose 30 % --
-// and a second wave has nothing to hide: rc_smooth1 (158 registers) is no faster with two waves per SIMD than with
-// one, the fp64 DPP multiply-adds already fill the VALU (profiles/r02_experiments.txt).
+// about 275 registers; compiled for two waves they spill 80..200 B per lane inside the step loop and lose 30 %.
+// (Their VALU is busy 53..56 % of the time on one wave per SIMD, so a second wave would pay -- once ~25 registers of
+// live state are gone; rc_smooth1 fits two waves and gains nothing, it is HBM-bound: profiles/r02_experiments.txt.)
 #ifndef PGPS_RC_WAVES
 #define PGPS_RC_WAVES 1
 #endif
