@@ -66,7 +66,8 @@ def parse():
                     help="lib: RCCL communicator owned by the libpgps context, one call per pass (default); torch: the "
                          "three library phases with torch.distributed collectives in between (--dist-backend)")
     ap.add_argument("--kernel", default="matern32",
-                    choices=["matern32", "matern52", "rbf6", "matern12", "c5", "rbf15", "periodic10"])
+                    choices=["matern32", "matern52", "matern12", "c5", "periodic10"] + [f"rbf{n}" for n in range(2, 33)],
+                    help="rbfN = RBF of order N (state dimension N)")
     ap.add_argument("--family", type=int, default=0, help="0 auto, 1 lane-chunk, 2 wave-cooperative kernels")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
@@ -120,13 +121,13 @@ def self_launch(args):
 
 def make_kernel(name):
     from pssgp.kernels import Matern12, Matern32, Matern52, RBF, Periodic, SquaredExponential
+    if name.startswith("rbf"):
+        return RBF(1.0, 1.0, order=int(name[3:]), balancing_iter=10)
     return {"matern12": lambda: Matern12(1.0, 1.0), "matern32": lambda: Matern32(1.0, 1.0),
             "matern52": lambda: Matern52(1.0, 1.0),
-            "rbf6": lambda: RBF(1.0, 1.0, order=6, balancing_iter=10),
             # BASELINE config c5: quasi-periodic (Periodic * Matern32) + Matern52, d = 11
             "c5": lambda: Periodic(SquaredExponential(1.0, 1.0), period=1.0, order=1) * Matern32(1.0, 1.0)
             + Matern52(1.0, 1.0),
-            "rbf15": lambda: RBF(1.0, 1.0, order=15, balancing_iter=10),
             "periodic10": lambda: Periodic(SquaredExponential(1.0, 1.0), period=1.0, order=10)}[name]()
 
 

@@ -247,11 +247,15 @@ struct Io {
     unsigned oc, orw, ov, ro8;          // byte offsets of (0, lane), (lane, 0), vector element `lane`; of the row's step
     unsigned foc, forw, fov;            // the same for the buffer accesses: out of range for lanes >= D
     unsigned span_m, span_v;            // bytes from row 0's record to the end of row 3's: matrices, vectors
+    unsigned ros, srl, span_s;          // symmetric records (below): byte offset of the row's step, sym_row(lane), span
     bool lv;
     int lane;
     __device__ __forceinline__ void init(int lane_, int row, int Lw) {
         lane = lane_;
         lv = lane < D;
+        ros = (unsigned)row * (unsigned)Lw * (unsigned)RECS;
+        srl = (unsigned)(lane * D - lane * (lane - 1) / 2 - lane);
+        span_s = (3u * (unsigned)Lw + 1u) * (unsigned)RECS;
         const unsigned ro = (unsigned)row * (unsigned)Lw * (unsigned)(D * D);
         ro8 = ro * W;
         oc = lv ? (ro + (unsigned)lane) * W : 0u;
@@ -315,6 +319,50 @@ struct Io {
         else if (lv && pred) *reinterpret_cast<Real*>(reinterpret_cast<char*>(base) + ov) = x;
     }
 
+    // ---- symmetric records: the smoother's L waits in scratch between rc_apply1 / rc_selem1 and rc_smooth1, and the
+    // smoother pass is HBM-bound on (E, L, g) in, (sm, sP) out -- so L travels as its upper triangle, row-major
+    // (element (i, j), j >= i, at sym_row(i) + j), NS = d (d + 1) / 2 scalars in records RECS bytes apart (padded to
+    // whole 16-byte pieces).  Lane j writes the part of its column above the diagonal; it reads the part below as
+    // row j.  d = 11 fp64: 528 instead of 968 bytes per step and direction (c5: rc_smooth1 0.65 -> 0.57 ms).
+    static constexpr int NS = D * (D + 1) / 2;
+    static constexpr int RECS = (NS * (int)sizeof(Real) + 15) / 16 * 16;
+    static constexpr int sym_row(int i) { return i * D - i * (i - 1) / 2 - i; }
+    static __device__ __forceinline__ const Real* sym_at(const Real* base, long k) {
+        return reinterpret_cast<const Real*>(reinterpret_cast<const char*>(base) + k * RECS);
+    }
+    static __device__ __forceinline__ Real* sym_at(Real* base, long k) {
+        return reinterpret_cast<Real*>(reinterpret_cast<char*>(base) + k * RECS);
+    }
+    // scalar offset of element (i, lane) of the lane's column inside a record
+    __device__ __forceinline__ unsigned sym_off(int i) const {
+        return i <= lane ? (unsigned)(sym_row(i) + lane) : srl + (unsigned)i;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void st_sym(Real* rec, bool pred, const Real* X) const {
+        if constexpr (FAST) {
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(rec, span_s);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                buf_st(r, (lv && lane >= i) ? ros + (unsigned)(sym_row(i) + lane) * W : kOob, X[i]);
+        } else if (lv && pred) {
+            char* p = reinterpret_cast<char*>(rec) + ros + (unsigned)lane * W;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                if (lane >= i) *reinterpret_cast<Real*>(p + sym_row(i) * (int)W) = X[i];
+        }
+    }
+    // X <- the record's matrix, column layout; rows that are not `real` get zeros
+    __device__ __forceinline__ void ld_sym(const Real* rec, bool real, Real* X) const {
+        if (lv && real) {
+            const char* p = reinterpret_cast<const char*>(rec) + ros;
+#pragma unroll
+            for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const Real*>(p + sym_off(i) * W);
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) X[i] = Real(0.0);
+        }
+    }
+
     // ---- WIDE path of the FAST bodies: whole records as 16-byte pieces, staged through wave-private LDS ------------
     // The per-register accesses above move 4 rows x D scalars (96 .. 512 bytes) per memory instruction, and the level-1
     // kernels issue 45 .. 70 of them per step: measured, their time is the memory pipeline's per-instruction cost
@@ -342,6 +390,11 @@ struct Io {
     unsigned wg[NVW], wgs[NVW], wtail;  // global byte offsets of this lane's pieces: loads / stores (out of range when
                                         // there is no such piece; stores: also for the tail piece) / the 8-byte tail
     unsigned lc, lr, ltail;             // LDS byte offsets of (0, lane) column layout, (lane, 0) row layout; tail
+    // symmetric records on the same road: NPS pieces per row and step, no tails (RECS is whole pieces)
+    static constexpr int NPS = RECS / 16;
+    static constexpr int NVS = (4 * NPS + 63) / 64;
+    unsigned wsym[NVS];                 // global byte offsets of this lane's pieces (out of range when there is none)
+    unsigned lsrow, zoff;               // LDS byte offset of the row's record in a slot; of the slot's zeros
     int tid;
     __device__ __forceinline__ void init_wide(int row, int Lw, unsigned zero_off) {
         tid = threadIdx.x & 63;
@@ -353,6 +406,13 @@ struct Io {
             wg[v] = ok ? (unsigned)r * pitch + (unsigned)idx * 16u : kOob;
             wgs[v] = (ok && idx < NPF) ? (unsigned)r * pitch + (unsigned)idx * 16u : kOob;
         }
+#pragma unroll
+        for (int v = 0; v < NVS; ++v) {
+            const int q = v * 64 + tid, r = q / NPS, idx = q % NPS;
+            wsym[v] = q < 4 * NPS ? (unsigned)r * (unsigned)Lw * (unsigned)RECS + (unsigned)idx * 16u : kOob;
+        }
+        lsrow = (unsigned)row * (unsigned)RECS;
+        zoff = zero_off;
         wtail = (TAIL && tid < 4) ? (unsigned)tid * pitch + (unsigned)NPF * 16u : kOob;
         ltail = (unsigned)(tid & 3) * (unsigned)RECPAD + (unsigned)NPF * 16u;
         // lanes >= D read the zeros at zero_off (relative to the slot) in both layouts: no select behind the LDS read
@@ -407,6 +467,43 @@ struct Io {
         lds_put(slot, X);
         sync();
         wide_drain(base, slot);
+    }
+    // the same for symmetric records (slots are sized for full records: these fit)
+    __device__ __forceinline__ void wide_load_sym(const Real* rec, V4* r) const {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(rec, span_s);
+#pragma unroll
+        for (int v = 0; v < NVS; ++v) r[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wsym[v], 0, 0);
+    }
+    __device__ __forceinline__ void wide_commit_sym(char* slot, const V4* r) const {
+#pragma unroll
+        for (int v = 0; v < NVS; ++v) *reinterpret_cast<V4*>(slot + (v * 64 + tid) * 16) = r[v];
+    }
+    __device__ __forceinline__ void lds_get_sym(const char* slot, Real* X) const {
+        const char* p = slot + (lv ? lsrow : zoff);
+#pragma unroll
+        for (int i = 0; i < D; ++i) X[i] = *reinterpret_cast<const Real*>(p + (lv ? sym_off(i) * W : 0u));
+    }
+    __device__ __forceinline__ void lds_put_sym(char* slot, const Real* X) const {
+        if (lv) {
+            char* p = slot + lsrow + (unsigned)lane * W;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                if (lane >= i) *reinterpret_cast<Real*>(p + sym_row(i) * (int)W) = X[i];
+        }
+    }
+    __device__ __forceinline__ void wide_drain_sym(Real* rec, const char* slot) const {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(rec, span_s);
+#pragma unroll
+        for (int v = 0; v < NVS; ++v) {
+            const V4 x = *reinterpret_cast<const V4*>(slot + (v * 64 + tid) * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(x, rs, (int)wsym[v], 0, 0);
+        }
+    }
+    __device__ __forceinline__ void wide_store_sym(Real* rec, char* slot, const Real* X) const {
+        sync();
+        lds_put_sym(slot, X);
+        sync();
+        wide_drain_sym(rec, slot);
     }
 };
 
@@ -706,7 +803,9 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
             {
                 const bool st = FAST || (k - 1 < k1);
                 put(slotE, a.Es, ku - 1, st, En);
-                put(slotL, a.Lws, ku - 1, st, Ln);
+                if constexpr (FAST && BATCH) io.lds_put_sym(slotL, Ln);
+                else if constexpr (FAST) io.wide_store_sym(IOT::sym_at(a.Lws, ku - 1), slotL, Ln);
+                else io.template st_sym<false>(IOT::sym_at(a.Lws, ku - 1), st, Ln);
                 io.template st_vec<FAST>(a.gs + (ku - 1) * D, st, gn);
             }
             // total <- total (x) element:  E = Ea En, g = Ea gn + ga, L = Ea Ln Ea^T + La
@@ -765,7 +864,7 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
         }
         if constexpr (FAST && BATCH) {          // the step's matrix results leave together
             sync();
-            if constexpr (SMOOTH && !FIRST) { io.wide_drain(a.Es + (ku - 1) * dd, slotE); io.wide_drain(a.Lws + (ku - 1) * dd, slotL); }
+            if constexpr (SMOOTH && !FIRST) { io.wide_drain(a.Es + (ku - 1) * dd, slotE); io.wide_drain_sym(IOT::sym_at(a.Lws, ku - 1), slotL); }
             if constexpr (!LAST && STORE) io.wide_drain(a.fPs + ku * dd, slotP);
         }
     };
@@ -868,7 +967,7 @@ __device__ __forceinline__ void selem1_body(const RcArgsT<Real>& a, Real* patch,
         {
             const bool st = FAST || k < k1;
             io.template st_mat<FAST>(a.Es + ku * dd, st, En);
-            io.template st_mat<FAST>(a.Lws + ku * dd, st, Ln);
+            io.template st_sym<FAST>(Io<D, Real>::sym_at(a.Lws, ku), st, Ln);
             io.template st_vec<FAST>(a.gs + ku * D, st, gn);
         }
         Real E2[D], Er[D];
@@ -940,13 +1039,13 @@ __device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch
         const bool real = k < k1;
         io.template mat_slow<false>(a.Es + kc * dd, real, Real(1.0), Ec);
         io.template mat_slow<true>(a.Es + kc * dd, real, Real(1.0), Er);
-        io.template mat_slow<false>(a.Lws + kc * dd, real, Real(0.0), L);
+        io.ld_sym(Io<D, Real>::sym_at(a.Lws, kc), real, L);
         g = io.vec(a.gs + kc * D, real);
     };
     // FAST: the stored elements as 16-byte pieces through LDS (Io, WIDE path), a whole step ahead; E's row layout
     // comes out of the same slot
     using IOT = Io<D, Real>;
-    typename IOT::V4 pE[IOT::NVW], pL[IOT::NVW];
+    typename IOT::V4 pE[IOT::NVW], pL[IOT::NVS];
     Real ng = Real(0.0);
     int nq = -1;
     char* slotE = wslots;
@@ -954,14 +1053,14 @@ __device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch
     char* slotO = wslots + 2 * (IOT::SLOT + 16);
     auto prefetch = [&](int s) {                // (s = -1 at the end: the step before the chunk, >= 0 for a FAST wave)
         io.wide_load(a.Es + (kw + s) * dd, pE);
-        io.wide_load(a.Lws + (kw + s) * dd, pL);
+        io.wide_load_sym(IOT::sym_at(a.Lws, kw + s), pL);
         io.vec_fast(a.gs + (kw + s) * D, ng);
         if (PROJ) nq = a.qslot[k0 + s];
     };
     auto take = [&](int s) {
         sync();
         io.wide_commit(slotE, pE);
-        io.wide_commit(slotL, pL);
+        io.wide_commit_sym(slotL, pL);
         g = ng; q = nq;
         sync();
         PGPS_RC_PIN();
@@ -969,7 +1068,7 @@ __device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch
         PGPS_RC_PIN();
         io.template lds_get<false>(slotE, Ec);
         io.template lds_get<true>(slotE, Er);
-        io.template lds_get<false>(slotL, L);
+        io.lds_get_sym(slotL, L);
     };
     if constexpr (FAST) { io.init_wide(row, a.Lw, (unsigned)IOT::SLOT); prefetch(a.Lw - 1); }
     else load(a.Lw - 1);
