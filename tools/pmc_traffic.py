@@ -43,8 +43,9 @@ def main():
         slots[slot]["kernels"].append({"name": short, "dispatches": n, "FETCH_SIZE_KiB_mean": sum(ctr["FETCH_SIZE"]) / n,
                                        "WRITE_SIZE_KiB_mean": sum(ctr["WRITE_SIZE"]) / len(ctr["WRITE_SIZE"])})
         # single-launch kernels fix the number of passes that were profiled
+        # (the most frequent one: warm-up / fused-path variants of the same kernel run fewer times)
         if any(p in kname for p in ("rc_apply1", "k_filter_apply", "k_filter_single")):
-            passes = n
+            passes = max(passes or 0, n)
         slots[slot]["FETCH_SIZE_KiB"] += sum(ctr["FETCH_SIZE"])
         slots[slot]["WRITE_SIZE_KiB"] += sum(ctr["WRITE_SIZE"])
     assert passes, "no filter-apply dispatches found"
