@@ -110,3 +110,44 @@ def test_random_models_fp32_row_cooperative(seed):
     finally:
         ctx.set_family(0)
         ctx.set_chunk(0)
+
+
+def random_segments_case(seed):
+    """One random sharded series: state dimension 1..24 (all three kernel families: lane-chunk up to 6, row-cooperative
+    up to 16, wave-cooperative above -- or forced), 1..6 ranks with ragged boundaries (segments down to a single step),
+    fp64 or fp32, through the three pgps_seg_* phases against the unsegmented oracle."""
+    from tests.test_segments import run_segments_on_one_gpu
+    rng = np.random.default_rng(9000 + seed)
+    d = int(rng.choice([1, 2, 3, 5, 6, 7, 9, 12, 16, 17, 20, 24]))
+    dtype = np.float32 if rng.random() < 0.25 else np.float64
+    family = 0
+    if rng.random() < 0.3:
+        family = int(rng.choice([f for f in (1, 2, 3) if (f != 1 or d <= 6) and (f != 3 or 2 <= d <= 16)]))
+    world = int(rng.integers(1, 7))
+    n = int(rng.choice([world, world + 3, 40, 333, 1200, 2500]))
+    n = max(n, world)
+    cuts = np.sort(rng.choice(np.arange(1, n), size=world - 1, replace=False)) if world > 1 else np.array([], int)
+    edges = [0] + [int(c) for c in cuts] + [n]
+    bounds = list(zip(edges[:-1], edges[1:]))
+    if d == 1:
+        F, P, H = np.array([[-1.3]]), np.array([[0.8]]), np.array([[1.0]])
+    else:
+        F, P, H = _random_model(rng, d)
+    t = make_times(n, seed=seed)
+    ssm = _ssm(F, P, H, t, 0.2)
+    y = sample_series(ssm, seed=seed, nan_frac=float(rng.choice([0.0, 0.3])) if n > 3 else 0.0)
+    tag = f"seed={seed} d={d} n={n} world={world} bounds={bounds} dtype={np.dtype(dtype).name} family={family}"
+    got, lls, _, _ = run_segments_on_one_gpu(ssm, y, bounds, dtype, family)
+    of, oP, oll = O.kf(ssm, y, True)
+    os_, osP = O.kfs(ssm, y)
+    tol = 1e-7 if dtype == np.float64 else 5e-3
+    assert relerr(got["fms"], of) < tol and relerr(got["fPs"], oP) < tol, tag
+    assert relerr(got["sms"], os_) < tol and relerr(got["sPs"], osP) < tol, tag
+    for v in lls:
+        assert abs(v - oll) <= (1e-8 if dtype == np.float64 else 2e-3) * abs(oll) + (1e-10 if dtype == np.float64 else 1e-2), (tag, v, oll)
+    return tag
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_segments(seed):
+    random_segments_case(seed)

@@ -169,26 +169,15 @@ def _seg_kernel(name):
     }[name]()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("world,dtype,kname,family", [
-    (1, np.float64, "m32+m52", 0), (2, np.float64, "m32+m52", 0), (3, np.float64, "m32+m52", 0), (8, np.float64, "m32+m52", 0),
-    (4, np.float32, "m32+m52", 0),
-    # the row-cooperative family's segment protocol: forced at d = 5, automatic above d = 6
-    (3, np.float64, "m32+m52", 3), (1, np.float64, "rbf8", 0), (2, np.float64, "rbf8", 0), (8, np.float64, "rbf8", 0),
-    (3, np.float64, "c5", 0), (5, np.float64, "c5", 0),
-    # the wave-cooperative family's: automatic above d = 16, forced (family 2) below
-    (1, np.float64, "co2", 0), (2, np.float64, "co2", 0), (5, np.float64, "co2", 0), (3, np.float64, "periodic10", 0),
-    (3, np.float32, "co2", 0), (3, np.float64, "rbf8", 2), (4, np.float64, "m32+m52", 2)])
-def test_segments_on_one_gpu(world, dtype, kname, family):
+def run_segments_on_one_gpu(ssm, y, bounds, dtype, family):
+    """R logical ranks on one device, one context each, the all-gathers by hand.  Returns the concatenated outputs, every
+    rank's log-likelihood and the gathered records."""
     from pssgp import _backend as B
-    from pssgp.distributed import record_lengths, split_segments
-    ssm, y = _problem(n=5000, seed=9, kernel=_seg_kernel(kname))
+    from pssgp.distributed import record_lengths
     d = ssm[1].shape[1]
-    fms, fPs, ll = O.kf(ssm, y, True)
-    sms, sPs = O.kfs(ssm, y)
+    world = len(bounds)
     suf, real = B._suffix(dtype)
     rf, rs, pad = record_lengths(d)
-    bounds = split_segments(y.size, world)
     ranks = []
     for r, (lo, hi) in enumerate(bounds):
         ctx = B.Context(0)
@@ -205,10 +194,50 @@ def test_segments_on_one_gpu(world, dtype, kname, family):
                           ll=_Dev(ctx, shape=(2,), dtype=np.float64)))
     Rv = real(float(ssm[4].reshape(())))
     L, I = ctypes.c_long, ctypes.c_int
-    for r, k in enumerate(ranks):
-        k["ctx"].call(f"pgps_seg_filter_reduce_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p,
-                      k["Qs"].p, k["H"].p, Rv, k["ys"].p, k["rec_f"].p)
-    gf = np.stack([k["rec_f"].get() for k in ranks])
+    try:
+        for r, k in enumerate(ranks):
+            k["ctx"].call(f"pgps_seg_filter_reduce_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p,
+                          k["Qs"].p, k["H"].p, Rv, k["ys"].p, k["rec_f"].p)
+        gf = np.stack([k["rec_f"].get() for k in ranks])
+        for r, k in enumerate(ranks):
+            k["gf"].put(gf)
+            k["ctx"].call(f"pgps_seg_filter_apply_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p,
+                          k["Qs"].p, k["H"].p, Rv, k["ys"].p, k["gf"].p, k["fms"].p, k["fPs"].p, k["rec_s"].p)
+        gs = np.stack([k["rec_s"].get() for k in ranks])
+        for r, k in enumerate(ranks):
+            k["gs"].put(gs)
+            k["ctx"].call(f"pgps_seg_smoother_apply_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["Fs"].p, k["Qs"].p,
+                          k["fms"].p, k["fPs"].p, k["gs"].p, k["sms"].p, k["sPs"].p, k["ll"].p)
+        got = {n: np.concatenate([k[n].get() for k in ranks]) for n in ("fms", "fPs", "sms", "sPs")}
+        lls = [float(k["ll"].get()[0]) for k in ranks]
+    finally:
+        for k in ranks:
+            k["ctx"].synchronize()
+            for v in k.values():
+                if isinstance(v, _Dev):
+                    v.free()
+            k["ctx"].close()
+    return got, lls, gf, gs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dtype,kname,family", [
+    (1, np.float64, "m32+m52", 0), (2, np.float64, "m32+m52", 0), (3, np.float64, "m32+m52", 0), (8, np.float64, "m32+m52", 0),
+    (4, np.float32, "m32+m52", 0),
+    # the row-cooperative family's segment protocol: forced at d = 5, automatic above d = 6
+    (3, np.float64, "m32+m52", 3), (1, np.float64, "rbf8", 0), (2, np.float64, "rbf8", 0), (8, np.float64, "rbf8", 0),
+    (3, np.float64, "c5", 0), (5, np.float64, "c5", 0),
+    # the wave-cooperative family's: automatic above d = 16, forced (family 2) below
+    (1, np.float64, "co2", 0), (2, np.float64, "co2", 0), (5, np.float64, "co2", 0), (3, np.float64, "periodic10", 0),
+    (3, np.float32, "co2", 0), (3, np.float64, "rbf8", 2), (4, np.float64, "m32+m52", 2)])
+def test_segments_on_one_gpu(world, dtype, kname, family):
+    from pssgp.distributed import split_segments
+    ssm, y = _problem(n=5000, seed=9, kernel=_seg_kernel(kname))
+    d = ssm[1].shape[1]
+    fms, fPs, ll = O.kf(ssm, y, True)
+    sms, sPs = O.kfs(ssm, y)
+    bounds = split_segments(y.size, world)
+    got, lls, gf, gs = run_segments_on_one_gpu(ssm, y, bounds, dtype, family)
     # the records themselves: compare with the numpy stand-ins field by field
     segs = [OracleSegment(r, world, _slice(ssm, lo, hi), y[lo:hi]) for r, (lo, hi) in enumerate(bounds)]
     gf_o = np.stack([s.phase_reduce() for s in segs])
@@ -221,26 +250,10 @@ def test_segments_on_one_gpu(world, dtype, kname, family):
             # A of a long segment underflows towards 0 (the filter forgets): absolute scale 1
             assert np.max(np.abs(A - Ao)) < tol * max(1.0, np.max(np.abs(Ao)))
             assert relerr(J, Jo) < tol and relerr(eta, etao) < tol
-    for r, k in enumerate(ranks):
-        k["gf"].put(gf)
-        k["ctx"].call(f"pgps_seg_filter_apply_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["P0"].p, k["Fs"].p,
-                      k["Qs"].p, k["H"].p, Rv, k["ys"].p, k["gf"].p, k["fms"].p, k["fPs"].p, k["rec_s"].p)
-    gs = np.stack([k["rec_s"].get() for k in ranks])
-    for r, k in enumerate(ranks):
-        k["gs"].put(gs)
-        k["ctx"].call(f"pgps_seg_smoother_apply_dev_{suf}", L(k["n"]), I(d), I(r), I(world), k["Fs"].p, k["Qs"].p,
-                      k["fms"].p, k["fPs"].p, k["gs"].p, k["sms"].p, k["sPs"].p, k["ll"].p)
-    got = {n: np.concatenate([k[n].get() for k in ranks]) for n in ("fms", "fPs", "sms", "sPs")}
     assert relerr(got["fms"], fms) < tol and relerr(got["fPs"], fPs) < tol
     assert relerr(got["sms"], sms) < tol and relerr(got["sPs"], sPs) < tol
-    for k in ranks:
-        assert abs(k["ll"].get()[0] - ll) < (1e-10 if dtype == np.float64 else 1e-4) * abs(ll)
-    for k in ranks:
-        k["ctx"].synchronize()
-        for v in k.values():
-            if isinstance(v, _Dev):
-                v.free()
-        k["ctx"].close()
+    for v in lls:
+        assert abs(v - ll) < (1e-10 if dtype == np.float64 else 1e-4) * abs(ll)
 
 
 @pytest.mark.gpu

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off extended fuzz campaign on the GPU box (not part of the test-suite): tests/test_gpu_fuzz.py with many more
-seeds, plus random models of state dimension 17..32 (dense and block-diagonal) through the general-LTI entry points.
+seeds, plus random models of state dimension 17..32 (dense and block-diagonal) through the general-LTI entry points
+and random sharded series (1..6 ranks, ragged boundaries, every kernel family) through the segment protocol.
 Usage: python tools/fuzz_campaign.py [first_seed] [n_seeds]"""
 import os
 import sys
@@ -68,7 +69,7 @@ def main():
     bad = 0
     for seed in range(first, first + count):
         for name, fn in (("rc", T.test_random_models_sizes_and_chains), ("rc_fp32", T.test_random_models_fp32_row_cooperative),
-                         ("large_d", large_d_case)):
+                         ("large_d", large_d_case), ("segments", T.random_segments_case)):
             try:
                 fn(seed)
             except Exception:
