@@ -70,6 +70,8 @@ def parse():
                     help="rbfN = RBF of order N (state dimension N)")
     ap.add_argument("--family", type=int, default=0, help="0 auto, 1 lane-chunk, 2 wave-cooperative kernels")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--block", type=int, default=0, choices=[0, 128, 256],
+                    help="lanes per workgroup of the lane-chunk kernels: 0 = library default (pgps_set_block)")
     ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
     ap.add_argument("--stage", type=int, default=-1, help="LDS staging: -1 auto, 0 off, 2 / 4 steps per sub-tile")
     ap.add_argument("--path", default="lgssm", choices=["lgssm", "fused", "fused-ll"],
@@ -158,21 +160,24 @@ def sample_prior_observations(P0, Fs, Qs, H, R, rng):
     return b @ h + np.sqrt(R) * rng.standard_normal(n)
 
 
-def dominant_symbol(slot, d, suf, family, world):
+def dominant_symbol(slot, d, suf, family, segments, n_local):
     """The device function(s) behind a timing slot (slots are named after the lane-chunk kernels): mirrors
-    dispatch_scan in csrc/pgps_core.hip."""
-    rc_names = {"k_filter_reduce": "pgps::rc::rc_reduce1<{d}> + rc_ks_filter<{d}> levels", "k_filter_apply": "pgps::rc::rc_apply1<{d}, ...>",
-                "k_smoother_reduce": "pgps::rc::rc_ks_smoother<{d}> levels", "k_smoother_apply": "pgps::rc::rc_smooth1<{d}, false>"}
+    dispatch_scan in csrc/pgps_core.hip.  `segments`: the multi-GPU protocol (pgps_seg_*) is what runs."""
+    rc_names = {"k_filter_reduce": "pgps::rc::rc_reduce1<{t}, {d}> + rc_ks_filter<{t}, {d}> levels",
+                "k_filter_apply": "pgps::rc::rc_apply1<{t}, {d}, ...>",
+                "k_smoother_reduce": "pgps::rc::rc_ks_smoother<{t}, {d}> levels",
+                "k_smoother_apply": "pgps::rc::rc_smooth1<{t}, {d}, false>"}
     wc_names = {"k_filter_reduce": "pgps::wc::wc_reduce1/2 + wc_ks_filter levels", "k_filter_apply": "pgps::wc::wc_apply1",
                 "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels", "k_smoother_apply": "pgps::wc::wc_smooth1"}
-    rc = suf == "f64" and 2 <= d <= 16 and (family == 3 or (family == 0 and (d >= 5 if world == 1 else d > 6)))
-    if rc:
-        return rc_names[slot].format(d=d)
-    if family == 2 or (family == 0 and d > 6):
-        if suf == "f32" and family == 0 and d <= 16:
-            return rc_names[slot].format(d=d) + " (fp32 arrays widened to fp64)"
+    t = "double" if suf == "f64" else "float"
+    rc_auto = (d > 6) if (segments or suf == "f32") else (d >= 5)
+    if 2 <= d <= 16 and (family == 3 or (family == 0 and rc_auto)):
+        return rc_names[slot].format(t=t, d=d)
+    if family == 2 or (family in (0, 3) and d > 6):
         return wc_names[slot]
-    return f"pgps::{slot}<{'double' if suf == 'f64' else 'float'}, {d}, ...>"
+    # lane-chunk kernels: whole-series calls run the 128-lane build (suffix _n) except d <= 2 from 2^23 steps
+    narrow = not segments and not (d <= 2 and n_local >= (1 << 23))
+    return f"pgps::{slot}{'_n' if narrow else ''}<{t}, {d}, ...>"
 
 
 def workload_name(args, d, suf, n_total, n_local, world):
@@ -304,6 +309,7 @@ def main():
         ctx.set_chunk(args.chunk)
     ctx.set_stage(args.stage)
     ctx.set_family(args.family)
+    ctx.set_block(args.block)
     ctx.set_single_pass(args.single_pass, 0)
 
     def dev_from(a):
@@ -504,7 +510,7 @@ def main():
                    f"{world} contiguous time segments, 2 all-gathers of segment totals per pass ("
                    + ("RCCL ncclAllGather issued by libpgps on the context's stream" if use_lib_exchange
                       else f"torch.distributed {args.dist_backend}") + ")"},
-        "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": dominant_symbol(dominant, d, suf, args.family, world),
+        "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": dominant_symbol(dominant, d, suf, args.family, world > 1 or args.force_segments, n_local),
                      "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src,

@@ -157,6 +157,11 @@ extern "C" int pgps_set_family(pgps_ctx* ctx, int family) {
     ctx->family = family;
     return PGPS_OK;
 }
+extern "C" int pgps_set_block(pgps_ctx* ctx, int lanes) {
+    if (!ctx || (lanes != 0 && lanes != kBlockNarrow && lanes != 256)) return PGPS_E_INVALID;
+    ctx->block = lanes;
+    return PGPS_OK;
+}
 
 extern "C" int pgps_set_stage(pgps_ctx* ctx, int g) {
     if (!ctx || !(g == -1 || g == 0 || g == 2 || g == 4)) return PGPS_E_INVALID;
@@ -363,6 +368,22 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
     }
     if (ctx->family == 3) return PGPS_E_UNSUPPORTED_DIM;
     if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_scan_wc<T>(ctx, a, d, mode);
+    // Lane-chunk family: whole-series calls run the build with 128-lane workgroups (pgps_inst.hip, PGPS_NARROW) --
+    // except the longest d <= 2 series, where 256 lanes are ahead again (2^24 steps: 1.25 against 1.28 ms; 2^22: 0.303
+    // against 0.292) -- the segment protocol the 256-lane one (a rank's 2^21 steps of c4 time the same on both).
+    const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
+    const bool narrow = whole && ctx->block != 256 && (ctx->block == kBlockNarrow || !(d <= 2 && a.N >= (1L << 23)));
+    if (narrow) {
+        switch (d) {
+            case 1: return launch_scan_narrow<T, 1>(ctx, a, mode);
+            case 2: return launch_scan_narrow<T, 2>(ctx, a, mode);
+            case 3: return launch_scan_narrow<T, 3>(ctx, a, mode);
+            case 4: return launch_scan_narrow<T, 4>(ctx, a, mode);
+            case 5: return launch_scan_narrow<T, 5>(ctx, a, mode);
+            case 6: return launch_scan_narrow<T, 6>(ctx, a, mode);
+            default: return PGPS_E_UNSUPPORTED_DIM;
+        }
+    }
     switch (d) {
         case 1: return launch_scan<T, 1>(ctx, a, mode);
         case 2: return launch_scan<T, 2>(ctx, a, mode);

@@ -2,9 +2,26 @@
 // pgps_kernels.hip.h / pgps_discretise.hip.h instantiated for PGPS_INST_T, PGPS_INST_D, and the
 // launch functions the C ABI dispatches to.  Split this way because the fully unrolled algebra
 // for d >= 5 takes minutes to compile; the Makefile builds the units in parallel.
+//
+// With -DPGPS_NARROW -DPGPS_BLOCK=128 the unit holds a second build of the array-path scan only, with 128-lane
+// workgroups (half the lanes per workgroup = half the scan tree per step at the same number of workgroups: c2 86.7 ->
+// 82.6 us, RBF order 6 fp32 0.66 -> 0.59 ms, 2^14 .. 2^16 steps 32 -> 26 us; the fused kernels prefer 256 lanes).  Its
+// kernels and its launch function carry their own names so that both builds link into one library.
+#ifdef PGPS_NARROW
+#define k_filter_reduce k_filter_reduce_n
+#define k_filter_apply k_filter_apply_n
+#define k_filter_single k_filter_single_n
+#define k_smoother_reduce k_smoother_reduce_n
+#define k_smoother_apply k_smoother_apply_n
+#define k_seg_filter_total k_seg_filter_total_n
+#define k_seg_smoother_total k_seg_smoother_total_n
+#define launch_scan launch_scan_narrow
+#include "pgps_kernels.hip.h"
+#else
 #include "pgps_discretise.hip.h"
 #include "pgps_fused.hip.h"
 #include "pgps_kernels.hip.h"
+#endif
 
 #ifndef PGPS_INST_T
 #error "compile with -DPGPS_INST_T=<float|double> -DPGPS_INST_D=<d>"
@@ -49,16 +66,57 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     return PGPS_OK;
 }
 
+#ifdef PGPS_NARROW
+static_assert(kBlock == kBlockNarrow, "the narrow build is compiled with -DPGPS_BLOCK=128");
+// Steps per lane and workgroups of the 128-lane build.  Up to d = 3 one workgroup per CU where the series allows it (256
+// workgroups, up to 32 steps per lane: measured at d = 2 from 2^17 to 2^20 steps and at d = 3), from d = 4 sixteen
+// steps per lane (RBF order 4 / 6 at 2^20: 16 and 32 steps per lane 0.40 / 0.40 and 0.59 / 0.62 ms).
+static void geometry_narrow(const pgps_ctx* ctx, long N, int* Lc, int* nblocks, int d) {
+    int c = ctx->chunk;
+    if (c <= 0) {
+        long v;
+        if (d <= 3) {
+            v = (N + (long)kBlock * 256 - 1) / ((long)kBlock * 256);
+            v = v < 4 ? 4 : (v > 32 ? 32 : v);
+            const long max_blocks = 4096;
+            if (N > (long)kBlock * v * max_blocks) v = (N + (long)kBlock * max_blocks - 1) / ((long)kBlock * max_blocks);
+        } else {
+            v = 16;
+            const long max_blocks = 2048;
+            if (N > (long)kBlock * v * max_blocks) v = (N + (long)kBlock * max_blocks - 1) / ((long)kBlock * max_blocks);
+            while (v > 4 && (long)kBlock * v * 256 > N) v /= 2;
+        }
+        if (N < (long)kBlock * 4) v = (N + kBlock - 1) / kBlock;
+        if (v < 1) v = 1;
+        if (v > 4) v = (v + 3) / 4 * 4;
+        c = (int)v;
+    }
+    long nb = (N + (long)kBlock * c - 1) / ((long)kBlock * c);
+    *Lc = c;
+    *nblocks = (int)(nb < 1 ? 1 : nb);
+}
+#endif
+
 template <typename T, int D, int G, bool NT>
 static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
+#ifdef PGPS_NARROW
+    geometry_narrow(ctx, a.N, &a.Lc, &a.nblocks, D);
+#else
     geometry(ctx, a.N, &a.Lc, &a.nblocks, D);
+#endif
     a.nlanes = (long)a.nblocks * kBlock;
     a.nt = NT ? 1 : 0;
     int rc = carve_workspace<T, D>(ctx, a);
     if (rc) return rc;
     const dim3 grid(a.nblocks), block(kBlock);
     hipStream_t s = ctx->stream;
+    // Whole series: nothing reads the stitching operands, but they must point at memory -- the compiler turns the small
+    // `k + 1 < N ? Fs[k + 1] : halo_FQ` choices of d <= 2 into loads of both sides and a select (k_smoother_reduce<T, 2>
+    // faulted on a null halo_FQ in the stand-alone smoother).
+    a.carry_in = a.seg_ws;
+    a.halo_FQ = a.seg_ws + (D + D * D);
+    a.carry_back = a.seg_ws + (D + D * D) + 2 * D * D;
     if (mode == MODE_SEG_REDUCE || mode == MODE_SEG_FILTER || mode == MODE_SEG_SMOOTHER) {
         // one segment of a series sharded over GPUs: carry_in / halo_FQ / carry_back live in seg_ws
         a.seg_first = (a.rank == 0);
@@ -158,6 +216,9 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     return launch_scan_nt<T, D, 0>(ctx, a, mode);
 }
 
+#ifdef PGPS_NARROW
+template int launch_scan<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, ScanArgs<PGPS_INST_T>, Mode);
+#else
 template <typename T, int D>
 int launch_disc(pgps_ctx* ctx, long N, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -260,5 +321,6 @@ template int launch_gp<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, GpArgs<PGPS_INST_T>,
 template int launch_scan<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, ScanArgs<PGPS_INST_T>, Mode);
 template int launch_disc<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, long, const PGPS_INST_T*, const PGPS_INST_T*,
                                                    const PGPS_INST_T*, PGPS_INST_T, PGPS_INST_T*, PGPS_INST_T*);
+#endif      // PGPS_NARROW
 
 }  // namespace pgps

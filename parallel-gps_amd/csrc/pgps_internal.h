@@ -24,6 +24,7 @@ struct pgps_ctx {
     int stage_g = -1;                   // LDS staging: -1 = auto, 0 = off, 2 / 4 = steps per sub-tile
     int single_pass = -1;               // single-pass filter kernel: -1 = auto, 0 = off, 1 = on
     int lookback_window = 256;          // tiles per look-back window (<= 256; small values are for tests)
+    int block = 0;                      // lane-chunk workgroups: 0 = auto, 128 / 256 lanes (pgps_set_block)
     int family = 0;                     // 0 = auto (lane-chunk d <= 6; row-cooperative fp64 d <= 16; else wave-cooperative), 1 = lane, 2 = wave, 3 = row
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
@@ -211,6 +212,11 @@ enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS, MODE_SEG_REDUCE, MODE_SEG_FILTER, MOD
 // defined in pgps_inst.hip, one explicit instantiation per compiled (T, D)
 template <typename T, int D>
 int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
+// the same scan built a second time with 128-lane workgroups (pgps_inst.hip with -DPGPS_NARROW -DPGPS_BLOCK=128):
+// whole-series modes only
+template <typename T, int D>
+int launch_scan_narrow(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
+constexpr int kBlockNarrow = 128;
 // wave-cooperative family (pgps_wc.hip): runtime state dimension, 1 <= d <= 32
 template <typename T>
 int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);

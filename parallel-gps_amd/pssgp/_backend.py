@@ -48,6 +48,7 @@ def _declare(lib):
     lib.pgps_set_chunk.argtypes = [P, c_int]
     lib.pgps_set_stage.argtypes = [P, c_int]
     lib.pgps_set_family.argtypes = [P, c_int]
+    lib.pgps_set_block.argtypes = [P, c_int]
     lib.pgps_set_single_pass.argtypes = [P, c_int, c_int]
     lib.pgps_get_chunk.argtypes = [P, c_long, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_malloc.argtypes = [P, ctypes.c_size_t, ctypes.POINTER(P)]
@@ -153,6 +154,10 @@ class Context:
     def set_family(self, family):
         """0 auto, 1 lane-chunk kernels (d <= 6), 2 wave-cooperative kernels (any d <= 32)."""
         check(self, self.lib.pgps_set_family(self.handle, int(family)), "pgps_set_family")
+
+    def set_block(self, lanes):
+        """Lanes per workgroup of the lane-chunk kernels: 0 = automatic, 128, 256 (pgps_set_block)."""
+        check(self, self.lib.pgps_set_block(self.handle, int(lanes)), "pgps_set_block")
 
     def get_chunk(self, n_steps):
         lc, nb = c_int(0), c_int(0)

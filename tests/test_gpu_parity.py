@@ -82,6 +82,41 @@ def test_chunk_size_invariance(chunk):
         ctx.set_chunk(0)
 
 
+@pytest.mark.parametrize("lanes", [128, 256])
+@pytest.mark.parametrize("dtype,kname,n,chunk", [(np.float64, "m32", 70001, 0), (np.float64, "m32", 1025, 3), (np.float32, "m32", 9000, 0),
+                                                 (np.float64, "m52", 33000, 0), (np.float64, "rbf6", 5000, 0),
+                                                 (np.float32, "rbf6", 12000, 8), (np.float64, "m12", 257, 0)])
+def test_both_workgroup_sizes(lanes, dtype, kname, n, chunk):
+    """libpgps carries the lane-chunk scan twice, with 128- and 256-lane workgroups (pgps_set_block; the automatic choice
+    is 128 for whole-series calls): each build on its own against the oracle, ragged sizes and forced chunks included;
+    stand-alone filter and smoother too."""
+    from pssgp.kernels import Matern12, Matern32, Matern52, RBF
+    B = _gpu()
+    ctx = B.get_context()
+    k = {"m12": lambda: Matern12(1., 1.), "m32": lambda: Matern32(1., 1.), "m52": lambda: Matern52(1., 0.7),
+         "rbf6": lambda: RBF(1., 0.8, order=6, balancing_iter=10)}[kname]()
+    t = make_times(n, seed=n % 97)
+    ssm = O.get_ssm(k.get_sde(), t, 0.1)
+    y = sample_series(ssm, seed=3, nan_frac=0.1)
+    tol = TOL64 if dtype == np.float64 else TOL32
+    try:
+        ctx.set_family(1)
+        ctx.set_block(lanes)
+        ctx.set_chunk(chunk)
+        _check_all(_gpu_all(ssm, y, dtype), _oracle_all(ssm, y), tol)
+        if dtype == np.float64:
+            of, oP, _ = O.kf(ssm, y, True)
+            s2, sP2 = B.pks(ssm, of, oP)
+            os_, osP = O.kfs(ssm, y)
+            assert relerr(s2, os_) < 1e-9 and relerr(sP2, osP) < 1e-9
+    finally:
+        ctx.set_chunk(0)
+        ctx.set_block(0)
+        ctx.set_family(0)
+    with pytest.raises(B.PgpsError):
+        ctx.set_block(64)
+
+
 @pytest.mark.parametrize("stage", [0, 2, 4])
 @pytest.mark.parametrize("chunk", [4, 8, 12])
 @pytest.mark.parametrize("dtype,kname", [(np.float64, "m32"), (np.float64, "m12"), (np.float32, "m32"),
