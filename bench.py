@@ -175,8 +175,8 @@ def dominant_symbol(slot, d, suf, family, segments, n_local):
         return rc_names[slot].format(t=t, d=d)
     if family == 2 or (family in (0, 3) and d > 6):
         return wc_names[slot]
-    # lane-chunk kernels: whole-series calls run the 128-lane build (suffix _n) except d <= 2 from 2^23 steps
-    narrow = not segments and not (d <= 2 and n_local >= (1 << 23))
+    # lane-chunk kernels: whole-series calls run the 128-lane build (suffix _n) except d <= 3 from 2^22 steps
+    narrow = not segments and not (d <= 3 and n_local >= (1 << 22))
     return f"pgps::{slot}{'_n' if narrow else ''}<{t}, {d}, ...>"
 
 

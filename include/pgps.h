@@ -71,7 +71,7 @@ int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
  * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64 and fp32, 2 <= d <= 16). */
 int pgps_set_family(pgps_ctx* ctx, int family);
 /* Lanes per workgroup of the lane-chunk kernels (d <= PGPS_MAX_DIM_LANE): 0 = automatic (128 for whole-series calls --
- * half the scan tree per step at the same number of workgroups -- except d <= 2 from 2^23 steps; 256 for the segment
+ * half the scan tree per step at the same number of workgroups -- except d <= 3 from 2^22 steps; 256 for the segment
  * calls), 128, 256.  The library carries both builds; the fused (pgps_gp_*) kernels always use 256.
  * pgps_get_chunk reports the geometry of the 256-lane build. */
 int pgps_set_block(pgps_ctx* ctx, int lanes);

@@ -369,10 +369,12 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
     if (ctx->family == 3) return PGPS_E_UNSUPPORTED_DIM;
     if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_scan_wc<T>(ctx, a, d, mode);
     // Lane-chunk family: whole-series calls run the build with 128-lane workgroups (pgps_inst.hip, PGPS_NARROW) --
-    // except the longest d <= 2 series, where 256 lanes are ahead again (2^24 steps: 1.25 against 1.28 ms; 2^22: 0.303
-    // against 0.292) -- the segment protocol the 256-lane one (a rank's 2^21 steps of c4 time the same on both).
+    // except the long series of the LDS-staged dimensions: from 2^22 steps there are two waves per SIMD to cover each
+    // other's loads, and the narrow build's prefetch registers cost it that (d = 2, 2^22 steps: 0.303 ms against 0.307 for
+    // 256 lanes; 2^24: 1.28 against 1.25) -- the segment protocol the 256-lane one (a rank's 2^21 steps of c4: 0.151 /
+    // 0.152 ms without the prefetch).
     const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
-    const bool narrow = whole && ctx->block != 256 && (ctx->block == kBlockNarrow || !(d <= 2 && a.N >= (1L << 23)));
+    const bool narrow = whole && ctx->block != 256 && (ctx->block == kBlockNarrow || !(d <= 3 && a.N >= (1L << 22)));
     if (narrow) {
         switch (d) {
             case 1: return launch_scan_narrow<T, 1>(ctx, a, mode);

@@ -754,16 +754,29 @@ struct FilterApplyStaged {
         char* gM = reinterpret_cast<char*>(a.fms + wbase * D);
         const int S = a.Lc / G;
         const long k0 = wbase + (long)lane * a.Lc;
-        for (int sb = 0; sb < S; ++sb) {
-            wave_lds_sync();
+        // The 128-lane build runs one workgroup of two waves per CU at 2^20 steps: no second wave covers the loads, and
+        // registers do not decide its occupancy -- so there the next sub-tile is requested as soon as this one's pieces
+        // have been committed (kPrefetch).  The 256-lane build (long series, two waves per SIMD) keeps the lean loop.
+#ifdef PGPS_NARROW
+        constexpr bool kPrefetch = true;
+#else
+        constexpr bool kPrefetch = false;
+#endif
+        auto issue = [&](int sb) {
             stage_issue<GF>(gF + (long)sb * GF::SEG, pitchF, rF);
             stage_issue<GF>(gQ + (long)sb * GF::SEG, pitchF, rQ);
             y_issue<T, G>(gY + sb * G, yn);
+        };
+        if (kPrefetch) issue(0);
+        for (int sb = 0; sb < S; ++sb) {
+            wave_lds_sync();
+            if (!kPrefetch) issue(sb);
             stage_commit<GF>(lF, rF);
             stage_commit<GF>(lQ, rQ);
             T yv[G];
 #pragma unroll
             for (int i = 0; i < G; ++i) yv[i] = yn[i];
+            if (kPrefetch && sb + 1 < S) issue(sb + 1);
             wave_lds_sync();
             if (SMOOTH && sb == 0 && lane < kWave - 1) {
                 // record 0 of the next lane = this lane's halo step
