@@ -1262,17 +1262,30 @@ struct SmootherApplyStaged {
     using GF = typename CFG::GF;
     using GM = typename CFG::GM;
     static constexpr int MAT = D * D;
-    V4 rF[GF::NV], rQ[GF::NV], rP[GF::NV], rM[GM::NV];
+    // The 128-lane build keeps TWO sub-tiles in flight per wave (one workgroup of two waves per CU at 2^20 steps: the
+    // bytes in flight, not the registers, bound its streaming rate); the 256-lane build one.
+#ifdef PGPS_NARROW
+    static constexpr int kDepth = 2;
+#else
+    static constexpr int kDepth = 1;
+#endif
+    struct Regs { V4 rF[GF::NV], rQ[GF::NV], rP[GF::NV], rM[GM::NV]; };
+    Regs r0, r1;
     T Fc[MAT], Qc[MAT];                 // transition into the step after the one being processed
+
+    __device__ __forceinline__ void issue(const ScanArgs<T>& a, long wbase, int sb, Regs& r) {
+        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchM = (long)a.Lc * D * sizeof(T);
+        stage_issue<GF>(reinterpret_cast<const char*>(a.Fs + wbase * MAT) + (long)sb * GF::SEG, pitchF, r.rF);
+        stage_issue<GF>(reinterpret_cast<const char*>(a.Qs + wbase * MAT) + (long)sb * GF::SEG, pitchF, r.rQ);
+        stage_issue<GF>(reinterpret_cast<const char*>(a.fPs + wbase * MAT) + (long)sb * GF::SEG, pitchF, r.rP);
+        stage_issue<GM>(reinterpret_cast<const char*>(a.fms + wbase * D) + (long)sb * GM::SEG, pitchM, r.rM);
+    }
 
     __device__ __forceinline__ void prefetch(const ScanArgs<T>& a, long wbase) {
         const int lane = threadIdx.x & (kWave - 1);
-        const long pitchF = (long)a.Lc * MAT * sizeof(T), pitchM = (long)a.Lc * D * sizeof(T);
         const int S = a.Lc / G;
-        stage_issue<GF>(reinterpret_cast<const char*>(a.Fs + wbase * MAT) + (long)(S - 1) * GF::SEG, pitchF, rF);
-        stage_issue<GF>(reinterpret_cast<const char*>(a.Qs + wbase * MAT) + (long)(S - 1) * GF::SEG, pitchF, rQ);
-        stage_issue<GF>(reinterpret_cast<const char*>(a.fPs + wbase * MAT) + (long)(S - 1) * GF::SEG, pitchF, rP);
-        stage_issue<GM>(reinterpret_cast<const char*>(a.fms + wbase * D) + (long)(S - 1) * GM::SEG, pitchM, rM);
+        issue(a, wbase, S - 1, r0);
+        if (kDepth == 2 && S >= 2) issue(a, wbase, S - 2, r1);
         smoother_halo<T, D>(a, wbase + (long)(lane + 1) * a.Lc, Fc, Qc);
     }
 
@@ -1292,18 +1305,14 @@ struct SmootherApplyStaged {
         const int S = a.Lc / G;
         const long k1 = wbase + (long)(lane + 1) * a.Lc;
         const bool end_of_series = (k1 == a.N) && a.seg_last;
-        for (int sb = S - 1; sb >= 0; --sb) {
+        (void)gF; (void)gQ; (void)gP; (void)gM;
+        auto step = [&](int sb, Regs& r) {
             wave_lds_sync();
-            stage_commit<GF>(lF, rF);
-            stage_commit<GF>(lQ, rQ);
-            stage_commit<GF>(lP, rP);
-            stage_commit<GM>(lM, rM);
-            if (sb > 0) {
-                stage_issue<GF>(gF + (long)(sb - 1) * GF::SEG, pitchF, rF);
-                stage_issue<GF>(gQ + (long)(sb - 1) * GF::SEG, pitchF, rQ);
-                stage_issue<GF>(gP + (long)(sb - 1) * GF::SEG, pitchF, rP);
-                stage_issue<GM>(gM + (long)(sb - 1) * GM::SEG, pitchM, rM);
-            }
+            stage_commit<GF>(lF, r.rF);
+            stage_commit<GF>(lQ, r.rQ);
+            stage_commit<GF>(lP, r.rP);
+            stage_commit<GM>(lM, r.rM);
+            if (sb - kDepth >= 0) issue(a, wbase, sb - kDepth, r);
             wave_lds_sync();
 #pragma unroll
             for (int i = G - 1; i >= 0; --i) {
@@ -1321,6 +1330,13 @@ struct SmootherApplyStaged {
             wave_lds_sync();
             stage_drain<GM, NT>(oM + (long)sb * GM::SEG, pitchM, lM);
             stage_drain<GF, NT>(oP + (long)sb * GF::SEG, pitchF, lP);
+        };
+        if constexpr (kDepth == 2) {
+            int sb = S - 1;
+            for (; sb >= 1; sb -= 2) { step(sb, r0); step(sb - 1, r1); }
+            if (sb == 0) step(0, r0);
+        } else {
+            for (int sb = S - 1; sb >= 0; --sb) step(sb, r0);
         }
     }
 };
