@@ -176,7 +176,7 @@ def dominant_symbol(slot, d, suf, family, segments, n_local):
     if family == 2 or (family in (0, 3) and d > 6):
         return wc_names[slot]
     # lane-chunk kernels: whole-series calls run the 128-lane build (suffix _n) except d <= 3 from 2^22 steps
-    narrow = not segments and not (d <= 3 and n_local >= (1 << 22))
+    narrow = not (d <= 3 and n_local >= (1 << 22))
     return f"pgps::{slot}{'_n' if narrow else ''}<{t}, {d}, ...>"
 
 

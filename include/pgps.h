@@ -70,10 +70,10 @@ int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
  * d <= 32),
  * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64 and fp32, 2 <= d <= 16). */
 int pgps_set_family(pgps_ctx* ctx, int family);
-/* Lanes per workgroup of the lane-chunk kernels (d <= PGPS_MAX_DIM_LANE): 0 = automatic (128 for whole-series calls --
- * half the scan tree per step at the same number of workgroups -- except d <= 3 from 2^22 steps; 256 for the segment
- * calls), 128, 256.  The library carries both builds; the fused (pgps_gp_*) kernels always use 256.
- * pgps_get_chunk reports the geometry of the 256-lane build. */
+/* Lanes per workgroup of the lane-chunk kernels (d <= PGPS_MAX_DIM_LANE): 0 = automatic (128 -- half the scan tree per
+ * step at the same number of workgroups -- except d <= 3 from 2^22 steps of this call / this rank's segment), 128, 256.
+ * The library carries both builds; the fused (pgps_gp_*) kernels always use 256.  Do not change it between the phases
+ * of a segment pass (refused).  pgps_get_chunk reports the geometry of the 256-lane build. */
 int pgps_set_block(pgps_ctx* ctx, int lanes);
 /* (Diagnostic, environment: PGPS_WC_SERIAL3=1 when a context is created makes the wave-cooperative family walk its
  * group totals with one wave instead of the Kogge-Stone scan -- the cross-check of tests/test_gpu_wavecoop.py.) */

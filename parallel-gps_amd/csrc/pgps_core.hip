@@ -371,10 +371,9 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
     // Lane-chunk family: whole-series calls run the build with 128-lane workgroups (pgps_inst.hip, PGPS_NARROW) --
     // except the long series of the LDS-staged dimensions: from 2^22 steps there are two waves per SIMD to cover each
     // other's loads, and the narrow build's prefetch registers cost it that (d = 2, 2^22 steps: 0.303 ms against 0.307 for
-    // 256 lanes; 2^24: 1.28 against 1.25) -- the segment protocol the 256-lane one (a rank's 2^21 steps of c4: 0.151 /
-    // 0.152 ms without the prefetch).
-    const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
-    const bool narrow = whole && ctx->block != 256 && (ctx->block == kBlockNarrow || !(d <= 3 && a.N >= (1L << 22)));
+    // 256 lanes; 2^24: 1.28 against 1.25).  The three phases of the segment protocol follow the same rule (it depends on
+    // this rank's N and d only, so they agree with each other: a rank's 2^21 steps of c4 0.152 -> 0.147 ms).
+    const bool narrow = ctx->block != 256 && (ctx->block == kBlockNarrow || !(d <= 3 && a.N >= (1L << 22)));
     if (narrow) {
         switch (d) {
             case 1: return launch_scan_narrow<T, 1>(ctx, a, mode);
@@ -673,12 +672,12 @@ static int seg_common(pgps_ctx* ctx, long N, int d, int rank, int nranks, ScanAr
 // scratch it reads (chain totals, their scans, stored smoothing elements) is whatever the last call left in `ws`.
 static bool seg_follows(const pgps_ctx* ctx, int phase, long N, int d, int rank, int nranks) {
     const auto& t = ctx->seg_tag;
-    return t.phase == phase - 1 && t.N == N && t.d == d && t.rank == rank && t.nranks == nranks && t.chunk == ctx->chunk &&
+    return t.phase == phase - 1 && t.N == N && t.d == d && t.rank == rank && t.nranks == nranks && t.chunk == ctx->chunk && t.block == ctx->block &&
            t.epoch == ctx->ws_epoch;
 }
 static void seg_mark(pgps_ctx* ctx, int phase, long N, int d, int rank, int nranks) {
     ctx->seg_tag.phase = phase; ctx->seg_tag.N = N; ctx->seg_tag.d = d; ctx->seg_tag.rank = rank;
-    ctx->seg_tag.nranks = nranks; ctx->seg_tag.chunk = ctx->chunk; ctx->seg_tag.epoch = ctx->ws_epoch;
+    ctx->seg_tag.nranks = nranks; ctx->seg_tag.chunk = ctx->chunk; ctx->seg_tag.block = ctx->block; ctx->seg_tag.epoch = ctx->ws_epoch;
 }
 
 template <typename T>

@@ -39,7 +39,7 @@ struct pgps_ctx {
     DevBuf comm_buf;                    // [rec_f | rec_s | gathered_f | gathered_s] of pgps_pkfs_seg_dev_*
     // the three-phase segment protocol keeps state in `ws` between its calls: what the last phase left, and the
     // workspace epoch (bumped by every call that carves `ws`) it left it at
-    struct SegTag { int phase = 0; long N = 0; int d = 0, rank = 0, nranks = 0, chunk = 0; unsigned long epoch = 0; } seg_tag;
+    struct SegTag { int phase = 0; long N = 0; int d = 0, rank = 0, nranks = 0, chunk = 0, block = 0; unsigned long epoch = 0; } seg_tag;
     unsigned long ws_epoch = 0;
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
     int prof_every = 1;                 // time every n-th launch of an enabled slot
@@ -212,8 +212,7 @@ enum Mode { MODE_PKF, MODE_PKS, MODE_PKFS, MODE_SEG_REDUCE, MODE_SEG_FILTER, MOD
 // defined in pgps_inst.hip, one explicit instantiation per compiled (T, D)
 template <typename T, int D>
 int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
-// the same scan built a second time with 128-lane workgroups (pgps_inst.hip with -DPGPS_NARROW -DPGPS_BLOCK=128):
-// whole-series modes only
+// the same scan built a second time with 128-lane workgroups (pgps_inst.hip with -DPGPS_NARROW -DPGPS_BLOCK=128)
 template <typename T, int D>
 int launch_scan_narrow(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
 constexpr int kBlockNarrow = 128;
