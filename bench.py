@@ -532,6 +532,10 @@ def main():
         "gpu_event_ms_per_step": gpu_ms / args.steps,
         "log_likelihood": ll_val,
         "chunk": ctx.get_chunk(n_local),
+        # lane-chunk kernels (d <= 6): lanes per workgroup, steps per lane, workgroups of the pass that was timed
+        "lane_geometry": (list(ctx.get_geometry(n_local, d)) if d <= 6 and args.family in (0, 1)
+                          and "rc::" not in dominant_symbol(dominant, d, suf, args.family, world > 1 or args.force_segments, n_local)
+                          else None),
     }
 
     # ---- the same workload through the fused entry point (ts, ys resident; Fs / Qs never read) ------------

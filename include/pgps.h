@@ -75,6 +75,9 @@ int pgps_set_family(pgps_ctx* ctx, int family);
  * The library carries both builds; the fused (pgps_gp_*) kernels always use 256.  Do not change it between the phases
  * of a segment pass (refused).  pgps_get_chunk reports the geometry of the 256-lane build. */
 int pgps_set_block(pgps_ctx* ctx, int lanes);
+/* What a lane-chunk call (or one rank's segment) of N steps at state dimension d <= PGPS_MAX_DIM_LANE runs with: lanes per
+ * workgroup (128 / 256), steps per lane, workgroups -- after pgps_set_block / pgps_set_chunk. */
+int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* steps_per_lane, int* workgroups);
 /* (Diagnostic, environment: PGPS_WC_SERIAL3=1 when a context is created makes the wave-cooperative family walk its
  * group totals with one wave instead of the Kogge-Stone scan -- the cross-check of tests/test_gpu_wavecoop.py.) */
 /* LDS staging of the lane-chunk kernels: -1 = automatic, 0 = off (direct global accesses),

@@ -331,7 +331,48 @@ void geometry(const pgps_ctx* ctx, long N, int* Lc, int* nblocks, int d) {
     *Lc = c;
     *nblocks = (int)nb;
 }
+// Steps per lane and workgroups of the 128-lane build.  Up to d = 3 one workgroup per CU where the series allows it (256
+// workgroups, up to 32 steps per lane: measured at d = 2 from 2^17 to 2^20 steps and at d = 3), from d = 4 sixteen
+// steps per lane (RBF order 4 / 6 at 2^20: 16 and 32 steps per lane 0.40 / 0.40 and 0.59 / 0.62 ms).
+void geometry_narrow(const pgps_ctx* ctx, long N, int* Lc, int* nblocks, int d) {
+    int c = ctx->chunk;
+    if (c <= 0) {
+        long v;
+        if (d <= 3) {
+            v = (N + (long)kBlockNarrow * 256 - 1) / ((long)kBlockNarrow * 256);
+            v = v < 4 ? 4 : (v > 32 ? 32 : v);
+            const long max_blocks = 4096;
+            if (N > (long)kBlockNarrow * v * max_blocks) v = (N + (long)kBlockNarrow * max_blocks - 1) / ((long)kBlockNarrow * max_blocks);
+        } else {
+            v = 16;
+            const long max_blocks = 2048;
+            if (N > (long)kBlockNarrow * v * max_blocks) v = (N + (long)kBlockNarrow * max_blocks - 1) / ((long)kBlockNarrow * max_blocks);
+            while (v > 4 && (long)kBlockNarrow * v * 256 > N) v /= 2;
+        }
+        if (N < (long)kBlockNarrow * 4) v = (N + kBlockNarrow - 1) / kBlockNarrow;
+        if (v < 1) v = 1;
+        if (v > 4) v = (v + 3) / 4 * 4;
+        c = (int)v;
+    }
+    long nb = (N + (long)kBlockNarrow * c - 1) / ((long)kBlockNarrow * c);
+    *Lc = c;
+    *nblocks = (int)(nb < 1 ? 1 : nb);
+}
 }  // namespace pgps
+
+namespace pgps {
+// which of the two builds of the lane-chunk scan a call (or a rank's segment) of N steps at state dimension d takes
+static bool lane_narrow(const pgps_ctx* ctx, int d, long N) {
+    return ctx->block != 256 && (ctx->block == kBlockNarrow || !(d <= 3 && N >= (1L << 22)));
+}
+}  // namespace pgps
+
+extern "C" int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* Lc, int* nb) {
+    if (!ctx || N < 1 || d < 1 || d > PGPS_MAX_DIM_LANE || !lanes || !Lc || !nb) return PGPS_E_INVALID;
+    if (lane_narrow(ctx, d, N)) { *lanes = kBlockNarrow; geometry_narrow(ctx, N, Lc, nb, d); }
+    else { *lanes = kBlock; geometry(ctx, N, Lc, nb, d); }
+    return PGPS_OK;
+}
 
 extern "C" int pgps_get_chunk(pgps_ctx* ctx, long N, int* Lc, int* nb) {
     if (!ctx || N < 1 || !Lc || !nb) return PGPS_E_INVALID;
@@ -373,7 +414,7 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
     // other's loads, and the narrow build's prefetch registers cost it that (d = 2, 2^22 steps: 0.303 ms against 0.307 for
     // 256 lanes; 2^24: 1.28 against 1.25).  The three phases of the segment protocol follow the same rule (it depends on
     // this rank's N and d only, so they agree with each other: a rank's 2^21 steps of c4 0.152 -> 0.147 ms).
-    const bool narrow = ctx->block != 256 && (ctx->block == kBlockNarrow || !(d <= 3 && a.N >= (1L << 22)));
+    const bool narrow = lane_narrow(ctx, d, a.N);
     if (narrow) {
         switch (d) {
             case 1: return launch_scan_narrow<T, 1>(ctx, a, mode);

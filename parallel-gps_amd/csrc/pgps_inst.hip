@@ -68,33 +68,6 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
 
 #ifdef PGPS_NARROW
 static_assert(kBlock == kBlockNarrow, "the narrow build is compiled with -DPGPS_BLOCK=128");
-// Steps per lane and workgroups of the 128-lane build.  Up to d = 3 one workgroup per CU where the series allows it (256
-// workgroups, up to 32 steps per lane: measured at d = 2 from 2^17 to 2^20 steps and at d = 3), from d = 4 sixteen
-// steps per lane (RBF order 4 / 6 at 2^20: 16 and 32 steps per lane 0.40 / 0.40 and 0.59 / 0.62 ms).
-static void geometry_narrow(const pgps_ctx* ctx, long N, int* Lc, int* nblocks, int d) {
-    int c = ctx->chunk;
-    if (c <= 0) {
-        long v;
-        if (d <= 3) {
-            v = (N + (long)kBlock * 256 - 1) / ((long)kBlock * 256);
-            v = v < 4 ? 4 : (v > 32 ? 32 : v);
-            const long max_blocks = 4096;
-            if (N > (long)kBlock * v * max_blocks) v = (N + (long)kBlock * max_blocks - 1) / ((long)kBlock * max_blocks);
-        } else {
-            v = 16;
-            const long max_blocks = 2048;
-            if (N > (long)kBlock * v * max_blocks) v = (N + (long)kBlock * max_blocks - 1) / ((long)kBlock * max_blocks);
-            while (v > 4 && (long)kBlock * v * 256 > N) v /= 2;
-        }
-        if (N < (long)kBlock * 4) v = (N + kBlock - 1) / kBlock;
-        if (v < 1) v = 1;
-        if (v > 4) v = (v + 3) / 4 * 4;
-        c = (int)v;
-    }
-    long nb = (N + (long)kBlock * c - 1) / ((long)kBlock * c);
-    *Lc = c;
-    *nblocks = (int)(nb < 1 ? 1 : nb);
-}
 #endif
 
 template <typename T, int D, int G, bool NT>

@@ -216,6 +216,7 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
 template <typename T, int D>
 int launch_scan_narrow(pgps_ctx* ctx, ScanArgs<T> a, Mode mode);
 constexpr int kBlockNarrow = 128;
+void geometry_narrow(const pgps_ctx* ctx, long N, int* Lc, int* nblocks, int d);      // pgps_core.hip
 // wave-cooperative family (pgps_wc.hip): runtime state dimension, 1 <= d <= 32
 template <typename T>
 int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> a, int d, Mode mode);

@@ -49,6 +49,7 @@ def _declare(lib):
     lib.pgps_set_stage.argtypes = [P, c_int]
     lib.pgps_set_family.argtypes = [P, c_int]
     lib.pgps_set_block.argtypes = [P, c_int]
+    lib.pgps_get_geometry.argtypes = [P, c_long, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_set_single_pass.argtypes = [P, c_int, c_int]
     lib.pgps_get_chunk.argtypes = [P, c_long, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_malloc.argtypes = [P, ctypes.c_size_t, ctypes.POINTER(P)]
@@ -158,6 +159,13 @@ class Context:
     def set_block(self, lanes):
         """Lanes per workgroup of the lane-chunk kernels: 0 = automatic, 128, 256 (pgps_set_block)."""
         check(self, self.lib.pgps_set_block(self.handle, int(lanes)), "pgps_set_block")
+
+    def get_geometry(self, n, d):
+        """(lanes per workgroup, steps per lane, workgroups) of a lane-chunk call of n steps at state dimension d <= 6."""
+        lanes, lc, nb = c_int(0), c_int(0), c_int(0)
+        check(self, self.lib.pgps_get_geometry(self.handle, c_long(int(n)), c_int(int(d)), ctypes.byref(lanes),
+                                               ctypes.byref(lc), ctypes.byref(nb)), "pgps_get_geometry")
+        return lanes.value, lc.value, nb.value
 
     def get_chunk(self, n_steps):
         lc, nb = c_int(0), c_int(0)

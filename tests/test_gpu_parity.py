@@ -115,6 +115,11 @@ def test_both_workgroup_sizes(lanes, dtype, kname, n, chunk):
         ctx.set_family(0)
     with pytest.raises(B.PgpsError):
         ctx.set_block(64)
+    # what the automatic choice is, as the library reports it: c2 = 256 workgroups of 128 lanes x 32 steps; long staged
+    # series and nothing else on 256 lanes
+    assert ctx.get_geometry(1 << 20, 2) == (128, 32, 256) and ctx.get_geometry(1 << 19, 2) == (128, 16, 256)
+    assert ctx.get_geometry(1 << 24, 2)[0] == 256 and ctx.get_geometry(1 << 22, 3)[0] == 256
+    assert ctx.get_geometry(1 << 20, 6) == (128, 16, 512) and ctx.get_geometry(1 << 22, 6)[0] == 128
 
 
 @pytest.mark.parametrize("stage", [0, 2, 4])
