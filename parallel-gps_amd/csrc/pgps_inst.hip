@@ -185,6 +185,9 @@ int launch_scan(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         // 144-byte lane segments: 2 steps of 72-byte fp64 records or 4 steps of 36-byte fp32 ones
         constexpr int g3 = (sizeof(T) == 8) ? 2 : 4;
         if (ctx->stage_g != 0) return launch_scan_nt<T, D, g3>(ctx, a, mode);
+    } else if constexpr (D == 4 || (D == 6 && sizeof(T) == 4)) {
+        // one step per sub-tile: 64- / 128-byte (d = 4) and 144-byte (d = 6 fp32) records
+        if (ctx->stage_g != 0) return launch_scan_nt<T, D, 1>(ctx, a, mode);
     }
     return launch_scan_nt<T, D, 0>(ctx, a, mode);
 }

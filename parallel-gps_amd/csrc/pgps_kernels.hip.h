@@ -451,20 +451,26 @@ __device__ __forceinline__ void stage_put(char* lds, int i, const T* in) {
 template <typename T, int G>
 __device__ __forceinline__ void y_issue(const T* __restrict__ p, T* out) { load_rec<T, G>(p, out); }
 
-// staging is used when a record is small: d <= 2, and d = 3 with 144-byte lane segments
-// (fp64 G = 2, fp32 G = 4); G = steps per lane per sub-tile
+// staging is used when a lane's sub-tile fits the LDS budget: d <= 2, d = 3 with 144-byte lane segments (fp64 G = 2,
+// fp32 G = 4), and -- one step per sub-tile -- d = 4 (64- / 128-byte records) and d = 6 in fp32 (144-byte records:
+// config c3, where the direct accesses cost 40 % of k_filter_apply: 0.237 ms, 0.184 without its loads, 0.187 without
+// its stores); G = steps per lane per sub-tile
 template <typename T, int D, int G>
 struct StageCfg {
-    static constexpr bool on = (G > 0) && (D <= 2 || (D == 3 && G * (int)sizeof(T) == 16));
+    static constexpr int W = (int)sizeof(T);
+    static constexpr bool on = (G > 0) && (D <= 2 || (D == 3 && G * W == 16) || (D == 4 && G == 1) || (D == 6 && W == 4 && G == 1));
     static constexpr int GG = on ? G : 4;
-    using GF = StageGeom<D * D * (int)sizeof(T), GG>;     // F, Q, P records
-    using GM = StageGeom<D * (int)sizeof(T), GG>;         // m records
-    using GY = StageGeom<(int)sizeof(T), GG>;             // y records
+    // the means travel through LDS too when a lane's G of them are whole 16-byte pieces; otherwise (d = 6 fp32: 24
+    // bytes) they are read and written directly -- 24 of the 456 bytes a step moves
+    static constexpr bool stage_m = (D * W * GG) % 16 == 0;
+    using GF = StageGeom<D * D * W, GG>;                                        // F, Q, P records
+    using GM = StageGeom<stage_m ? D * W : 16, stage_m ? GG : 1>;               // m records (placeholder when direct)
+    using GY = StageGeom<W, GG>;                                                // y records
     // filter kernels: F (in; filtered P out) and Q (in; filtered m out, written compactly into the lane's own
     // segment once Q_i has been read: m_i ends before Q_{i+1} begins) -- 2 x 9 KiB per wave at d = 2 fp64
     static constexpr int F1_BYTES = on ? 2 * GF::BYTES : 16;
     static constexpr int F3_BYTES = on ? 2 * GF::BYTES : 16;
-    static constexpr int S3_BYTES = on ? 3 * GF::BYTES + GM::BYTES : 16;
+    static constexpr int S3_BYTES = on ? 3 * GF::BYTES + (stage_m ? GM::BYTES : 0) : 16;
 };
 
 // Fold spine entries [lo, hi) in time order over the whole workgroup; result in every lane.
@@ -793,11 +799,12 @@ struct FilterApplyStaged {
                 filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, yv[i], h, s, ll, sagg);
                 T Pf[MAT];
                 full_from_sym<T, D>(s.P, Pf);
-                stage_put<GM, T, D, GF::STRIDE>(lQ, i, s.m);    // Q_k is dead too: m_k goes where Q_0..Q_k were
+                if constexpr (CFG::stage_m) stage_put<GM, T, D, GF::STRIDE>(lQ, i, s.m);    // Q_k is dead too: m_k goes where Q_0..Q_k were
+                else store_rec<T, D>(a.fms + k * D, s.m);
                 stage_put<GF, T, MAT>(lF, i, Pf);       // F_k is dead after its predict
             }
             wave_lds_sync();
-            stage_drain<GM, NT, GF::STRIDE>(gM + (long)sb * GM::SEG, pitchM, lQ);
+            if constexpr (CFG::stage_m) stage_drain<GM, NT, GF::STRIDE>(gM + (long)sb * GM::SEG, pitchM, lQ);
             stage_drain<GF, NT>(gP + (long)sb * GF::SEG, pitchF, lF);
         }
         if (SMOOTH) filter_tail_apply<T, D>(have_next, Fh, Qh, s, sagg);
@@ -1264,12 +1271,13 @@ struct SmootherApplyStaged {
     static constexpr int MAT = D * D;
     // The 128-lane build keeps TWO sub-tiles in flight per wave (one workgroup of two waves per CU at 2^20 steps: the
     // bytes in flight, not the registers, bound its streaming rate); the 256-lane build one.
+    // (from d = 4 a second set of piece registers would spill: one)
 #ifdef PGPS_NARROW
-    static constexpr int kDepth = 2;
+    static constexpr int kDepth = D <= 3 ? 2 : 1;
 #else
     static constexpr int kDepth = 1;
 #endif
-    struct Regs { V4 rF[GF::NV], rQ[GF::NV], rP[GF::NV], rM[GM::NV]; };
+    struct Regs { V4 rF[GF::NV], rQ[GF::NV], rP[GF::NV], rM[GM::NV]; T mv[G][D]; };
     Regs r0, r1;
     T Fc[MAT], Qc[MAT];                 // transition into the step after the one being processed
 
@@ -1278,7 +1286,13 @@ struct SmootherApplyStaged {
         stage_issue<GF>(reinterpret_cast<const char*>(a.Fs + wbase * MAT) + (long)sb * GF::SEG, pitchF, r.rF);
         stage_issue<GF>(reinterpret_cast<const char*>(a.Qs + wbase * MAT) + (long)sb * GF::SEG, pitchF, r.rQ);
         stage_issue<GF>(reinterpret_cast<const char*>(a.fPs + wbase * MAT) + (long)sb * GF::SEG, pitchF, r.rP);
-        stage_issue<GM>(reinterpret_cast<const char*>(a.fms + wbase * D) + (long)sb * GM::SEG, pitchM, r.rM);
+        if constexpr (CFG::stage_m) {
+            stage_issue<GM>(reinterpret_cast<const char*>(a.fms + wbase * D) + (long)sb * GM::SEG, pitchM, r.rM);
+        } else {
+            const long kb = wbase + (long)(threadIdx.x & (kWave - 1)) * a.Lc + (long)sb * G;
+#pragma unroll
+            for (int i = 0; i < G; ++i) load_rec<T, D>(a.fms + (kb + i) * D, r.mv[i]);
+        }
     }
 
     __device__ __forceinline__ void prefetch(const ScanArgs<T>& a, long wbase) {
@@ -1311,24 +1325,38 @@ struct SmootherApplyStaged {
             stage_commit<GF>(lF, r.rF);
             stage_commit<GF>(lQ, r.rQ);
             stage_commit<GF>(lP, r.rP);
-            stage_commit<GM>(lM, r.rM);
+            T mvv[G][D];
+            if constexpr (CFG::stage_m) {
+                stage_commit<GM>(lM, r.rM);
+            } else {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) mvv[i][j] = r.mv[i][j];
+            }
             if (sb - kDepth >= 0) issue(a, wbase, sb - kDepth, r);
             wave_lds_sync();
 #pragma unroll
             for (int i = G - 1; i >= 0; --i) {
                 T mk[D], Pk[MAT];
-                stage_get<GM, T, D>(lM, i, mk);
+                if constexpr (CFG::stage_m) {
+                    stage_get<GM, T, D>(lM, i, mk);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) mk[j] = mvv[i][j];
+                }
                 stage_get<GF, T, MAT>(lP, i, Pk);
                 smoother_apply_step<T, D>(Fc, Qc, mk, Pk, end_of_series && sb == S - 1 && i == G - 1, s);
                 stage_get<GF, T, MAT>(lF, i, Fc);       // transition into this step: used by step k-1
                 stage_get<GF, T, MAT>(lQ, i, Qc);
                 T Pf[MAT];
                 full_from_sym<T, D>(s.P, Pf);
-                stage_put<GM, T, D>(lM, i, s.m);
+                if constexpr (CFG::stage_m) stage_put<GM, T, D>(lM, i, s.m);
+                else store_rec<T, D>(a.sms + (k1 - a.Lc + (long)sb * G + i) * D, s.m);
                 stage_put<GF, T, MAT>(lP, i, Pf);
             }
             wave_lds_sync();
-            stage_drain<GM, NT>(oM + (long)sb * GM::SEG, pitchM, lM);
+            if constexpr (CFG::stage_m) stage_drain<GM, NT>(oM + (long)sb * GM::SEG, pitchM, lM);
             stage_drain<GF, NT>(oP + (long)sb * GF::SEG, pitchF, lP);
         };
         if constexpr (kDepth == 2) {
