@@ -96,7 +96,9 @@ def solve_lyap_vec(F, L, Q):
         if np.all(np.isfinite(P)) and np.max(np.abs(res)) <= 1e-12 * max(1.0, float(np.max(np.abs(C))),
                                                                           float(np.max(np.abs(F))) * float(np.max(np.abs(P)))):
             return 0.5 * (P + P.T)
+    # I (x) F + F (x) I, written as two broadcast products (the same entries in the same order of addition as np.kron's,
+    # at a quarter of its cost for these d <= 8 matrices: every hyper-parameter setting of a chain pays for this)
     eye = np.eye(dim)
-    big = np.kron(eye, F) + np.kron(F, eye)
+    big = (eye[:, None, :, None] * F[None, :, None, :] + F[:, None, :, None] * eye[None, :, None, :]).reshape(dim * dim, dim * dim)
     P = np.linalg.solve(big, C.reshape(-1)).reshape(dim, dim)
     return -0.5 * (P + P.T)

@@ -199,8 +199,18 @@ class StateSpaceGP:
 
         base = block()
         blocks = [tuple(base)]
+        zeros = [np.zeros_like(np.asarray(v, np.float64)) for v in base]
         for owner, name in self.trainable_parameters():
             x0 = getattr(owner, name)
+            # two of the three derivatives are known in closed form -- and get_sde() (balancing sweep + Lyapunov solve)
+            # is what a small-N gradient call costs on the host: the observation noise enters through R alone, and a
+            # single Matern kernel's variance through Pinf alone, linearly (balance_ss leaves F, H independent of q)
+            if owner is self and name == "noise_variance":
+                blocks.append(tuple(zeros[:4]) + (np.float64(1.0),))
+                continue
+            if owner is self.kernel and name == "variance" and x0 != 0.0:
+                blocks.append((zeros[0], zeros[1], base[2] / x0, zeros[3], np.float64(0.0)))
+                continue
 
             def central(h):
                 setattr(owner, name, x0 + h)
@@ -341,12 +351,25 @@ class StateSpaceGP:
         ts, Y = self.data
         stream = None                   # state dimensions 17..32: asynchronous single evaluations, see below
         try:
+            memo = {}                   # kernel parameters -> its SDE: settings that differ in the noise only share it
+            from .kernels import Matern12, Matern32, Matern52, RBF
+            leaf_variance = isinstance(self.kernel, (Matern12, Matern32, Matern52, RBF)) and params[0] == (self.kernel, "variance")
             for row in thetas:
                 for (o, n), v in zip(params, row):
                     setattr(o, n, float(v))
-                sde = self.kernel.get_sde()
-                form = _backend.nilpotent_form(sde.F)
-                F, P0, H = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64), np.asarray(sde.H, np.float64).reshape(-1)
+                key = tuple(float(v) for v in row[:-1])
+                if key not in memo and leaf_variance and key[0] != 0.0:
+                    # a single Matern / RBF kernel: F, H do not depend on its variance and Pinf is linear in it
+                    # (balance_ss normalises L and H, q carries the scale) -- one SDE per lengthscale
+                    for other, (fo, Fo, Po, Ho) in list(memo.items()):
+                        if other[1:] == key[1:] and other[0] != 0.0:
+                            memo[key] = (fo, Fo, Po * (key[0] / other[0]), Ho)
+                            break
+                if key not in memo:
+                    sde = self.kernel.get_sde()
+                    memo[key] = (_backend.nilpotent_form(sde.F), np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64),
+                                 np.asarray(sde.H, np.float64).reshape(-1))
+                form, F, P0, H = memo[key]
                 if form is not None:
                     models.append((form, P0, H, self.noise_variance))
                 d = F.shape[0]
