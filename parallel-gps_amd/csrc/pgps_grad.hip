@@ -69,11 +69,34 @@ int launch_grad(pgps_ctx* ctx, long N, int d, int np, const double* model, const
     if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
     if (d == 1) return launch_grad_d<kNP, 1>(ctx, make_model<kNP>(d, np, 0, model, N, ts, t0, ys, out_dev));
     if (d == 2) return launch_grad_d<kNP, 2>(ctx, make_model<kNP>(d, np, 0, model, N, ts, t0, ys, out_dev));
+    // d = 3: one direction per model, the np models side by side in the same three launches (grid.y): at the
+    // reference's series lengths one workgroup's scan tree on duals is the whole cost (64 us), not its length
+    using T = Dual<1>;
     double* scratch = out_dev + 1 + np;
+    GradPack<1> pack{};
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int p = 0; p < 3; ++p) pack.m[p] = make_model<1>(d, np, p < np ? p : 0, model, N, ts, t0, ys, scratch + 2 * (p < np ? p : 0));
+    GradModel<1>& m0 = pack.m[0];
+    geometry(ctx, m0.N, &m0.Lc, &m0.nblocks);
+    m0.nlanes = (long)m0.nblocks * kBlock;
+    const size_t nb = (size_t)m0.nblocks, nl = (size_t)m0.nlanes;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t s_spine = up(nb * Dim<3>::NFILT * sizeof(T)), s_lpre = up(nl * Dim<3>::NFILT * sizeof(T)), s_ll = up(nb * sizeof(T));
+    const size_t per = s_spine + s_lpre + s_ll;
+    int rc = ensure(ctx, ctx->ws, per * (size_t)np);
+    if (rc) return rc;
+    char* base = (char*)ctx->ws.p;
     for (int p = 0; p < np; ++p) {
-        int rc = launch_grad_d<1, 3>(ctx, make_model<1>(d, np, p, model, N, ts, t0, ys, scratch + 2 * p));
-        if (rc) return rc;
+        GradModel<1>& m = pack.m[p];
+        m.Lc = m0.Lc; m.nblocks = m0.nblocks; m.nlanes = m0.nlanes;
+        m.spine = (T*)(base + per * p);
+        m.lpre = (T*)(base + per * p + s_spine);
+        m.llpart = (T*)(base + per * p + s_spine + s_lpre);
     }
+    const dim3 grid(m0.nblocks, np), block(kBlock);
+    timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_grad_reduce_pack<1, 3>, grid, block, 0, pack);
+    timed_launch(ctx, PGPS_K_FILTER_APPLY, k_grad_apply_pack<1, 3>, grid, block, 0, pack);
+    timed_launch(ctx, PGPS_K_LL_FINALIZE, k_grad_finalize_pack<1>, dim3(1, np), block, 0, pack);
     k_grad_compact<<<1, 64, 0, ctx->stream>>>(scratch, np, out_dev);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;

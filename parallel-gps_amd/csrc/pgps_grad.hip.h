@@ -61,8 +61,12 @@ __device__ __forceinline__ void grad_prior(const GradModel<NP>& m, Dual<NP>* h, 
         for (int j = i; j < D; ++j) P0[symi<D>(i, j)] = Dual<NP>(0.5) * (m.Pinf[i * D + j] + m.Pinf[j * D + i]);
 }
 
+// d = 3 differentiates one direction per model (registers): the directions run side by side, blockIdx.y picks the model
+template <int NP>
+struct GradPack { GradModel<NP> m[3]; };
+
 template <int NP, int D>
-__global__ __launch_bounds__(kBlock) void k_grad_reduce(const GradModel<NP> m) {
+__device__ __forceinline__ void grad_reduce_body(const GradModel<NP>& m) {
     using T = Dual<NP>;
     constexpr int MAT = D * D, SYM = Dim<D>::SYM;
     using FE = FiltElem<T, D>;
@@ -95,9 +99,13 @@ __global__ __launch_bounds__(kBlock) void k_grad_reduce(const GradModel<NP> m) {
     ws_store(m.lpre, m.nlanes, gt, excl);
     if (threadIdx.x == 0) rec_store(m.spine + (long)blockIdx.x * Dim<D>::NFILT, total);
 }
+template <int NP, int D>
+__global__ __launch_bounds__(kBlock) void k_grad_reduce(const GradModel<NP> m) { grad_reduce_body<NP, D>(m); }
+template <int NP, int D>
+__global__ __launch_bounds__(kBlock) void k_grad_reduce_pack(const GradPack<NP> p) { grad_reduce_body<NP, D>(p.m[blockIdx.y]); }
 
 template <int NP, int D>
-__global__ __launch_bounds__(kBlock) void k_grad_apply(const GradModel<NP> m) {
+__device__ __forceinline__ void grad_apply_body(const GradModel<NP>& m) {
     using T = Dual<NP>;
     constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT;
     using FE = FiltElem<T, D>;
@@ -142,9 +150,13 @@ __global__ __launch_bounds__(kBlock) void k_grad_apply(const GradModel<NP> m) {
     for (int i = 0; i < NP; ++i) tot.d[i] = block_sum_double(v.d[i], lds_ll);
     if (threadIdx.x == 0) m.llpart[blockIdx.x] = tot;
 }
+template <int NP, int D>
+__global__ __launch_bounds__(kBlock) void k_grad_apply(const GradModel<NP> m) { grad_apply_body<NP, D>(m); }
+template <int NP, int D>
+__global__ __launch_bounds__(kBlock) void k_grad_apply_pack(const GradPack<NP> p) { grad_apply_body<NP, D>(p.m[blockIdx.y]); }
 
 template <int NP>
-__global__ __launch_bounds__(kBlock) void k_grad_finalize(const Dual<NP>* llpart, int nblocks, double* out) {
+__device__ __forceinline__ void grad_finalize_body(const Dual<NP>* llpart, int nblocks, double* out) {
     __shared__ double lds_ll[kWaves];
     for (int c = 0; c <= NP; ++c) {
         double v = 0.0;
@@ -152,6 +164,15 @@ __global__ __launch_bounds__(kBlock) void k_grad_finalize(const Dual<NP>* llpart
         const double t = block_sum_double(v, lds_ll);
         if (threadIdx.x == 0) out[c] = t;
     }
+}
+template <int NP>
+__global__ __launch_bounds__(kBlock) void k_grad_finalize(const Dual<NP>* llpart, int nblocks, double* out) {
+    grad_finalize_body<NP>(llpart, nblocks, out);
+}
+template <int NP>
+__global__ __launch_bounds__(kBlock) void k_grad_finalize_pack(const GradPack<NP> p) {
+    const GradModel<NP>& m = p.m[blockIdx.y];
+    grad_finalize_body<NP>(m.llpart, m.nblocks, m.out);
 }
 
 // d = 3: np single-direction passes left (ll, d ll / d theta_p) pairs; gather them as [ll, grad...]
