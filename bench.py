@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--block", type=int, default=0, choices=[0, 128, 256],
                     help="lanes per workgroup of the lane-chunk kernels: 0 = library default (pgps_set_block)")
+    ap.add_argument("--dma", type=int, default=-1, choices=[-1, 0, 1],
+                    help="LDS-DMA ring in the Kalman pass (d = 2 fp64): -1 = library default, 0 off, 1 on (pgps_set_dma)")
     ap.add_argument("--chunk", type=int, default=0, help="steps per lane (0 = library default)")
     ap.add_argument("--stage", type=int, default=-1, help="LDS staging: -1 auto, 0 off, 2 / 4 steps per sub-tile")
     ap.add_argument("--path", default="lgssm", choices=["lgssm", "fused", "fused-ll"],
@@ -234,6 +236,86 @@ def vector_fp(d, suf, n_local, ms_per_pass, alg_bytes_step):
             "frac_of_lower_bound": max(lb_hbm, lb_fp) / ms_per_pass}
 
 
+def timed_rounds(fn, stream, sync, reps=20, rounds=5, warm=5):
+    """GPU-event time per call of `fn`: `rounds` rounds of `reps` back-to-back calls after `warm` untimed ones; median,
+    min and max over the rounds (one mean of 20 cannot tell a slow box from a noisy one)."""
+    import torch
+    for _ in range(warm):
+        fn()
+    sync()
+    per = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        sync()
+        per.append(e0.elapsed_time(e1) / reps)
+    per.sort()
+    return {"ms_per_step": per[len(per) // 2], "ms_min": per[0], "ms_max": per[-1], "rounds": rounds, "reps_per_round": reps}
+
+
+def one_gpu_reference(ctx, sde, d, suf, dtype_np, dtype_t, dev, stream, ts_all, n_total, noise):
+    """ms per pass of the whole n_total-step series on this one GPU (the N = 1 point of the strong-scaling curve, same
+    workload as the N > 1 line).  The observations are plain normal draws: the kernels' time does not depend on them."""
+    import torch
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    real = ctypes.c_double if suf == "f64" else ctypes.c_float
+    dev_from = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    F_d, P0_d = dev_from(np.asarray(sde.F, dtype_np)), dev_from(np.asarray(sde.P0, dtype_np))
+    H_d = dev_from(np.asarray(sde.H, dtype_np).reshape(-1))
+    ts_d = dev_from(ts_all.astype(dtype_np))
+    Fs = torch.empty((n_total, d, d), dtype=dtype_t, device=dev)
+    Qs = torch.empty((n_total, d, d), dtype=dtype_t, device=dev)
+    ctx.call(f"pgps_discretise_dev_{suf}", ctypes.c_long(n_total), ctypes.c_int(d), P(F_d), P(P0_d), P(ts_d), real(0.0),
+             P(Fs), P(Qs))
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    ys = torch.randn(n_total, dtype=dtype_t, device=dev, generator=g) * float(np.sqrt(sde.P0[0, 0] + noise))
+    fms, sms = (torch.empty((n_total, d), dtype=dtype_t, device=dev) for _ in range(2))
+    fPs, sPs = (torch.empty((n_total, d, d), dtype=dtype_t, device=dev) for _ in range(2))
+    ll = torch.zeros((2,), dtype=torch.float64, device=dev)
+
+    def step():
+        ctx.call(f"pgps_pkfs_dev_{suf}", ctypes.c_long(n_total), ctypes.c_int(d), P(P0_d), P(Fs), P(Qs), P(H_d), real(noise),
+                 P(ys), P(fms), P(fPs), P(sms), P(sPs), P(ll))
+
+    r = timed_rounds(step, stream, lambda: torch.cuda.synchronize(dev), reps=5, rounds=3, warm=3)
+    del Fs, Qs, ys, fms, sms, fPs, sPs
+    torch.cuda.empty_cache()
+    return r["ms_per_step"]
+
+
+def allgather_latency(ctx, d, dtype_t, dev, stream, world, n=100):
+    """Median GPU-event time (microseconds) of an isolated ncclAllGather of each of the two segment records over the
+    context's communicator: [filter record, smoother record]."""
+    import torch
+    from pssgp.distributed import record_lengths
+    rf, rs, _ = record_lengths(d)
+    out = []
+    for reclen in (rf, rs):
+        send = torch.zeros(reclen, dtype=dtype_t, device=dev)
+        recv = torch.zeros((world, reclen), dtype=dtype_t, device=dev)
+        nbytes = send.numel() * send.element_size()
+        call = lambda: ctx.call("pgps_comm_allgather_dev", ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr()),
+                                ctypes.c_size_t(nbytes))
+        for _ in range(10):
+            call()
+        torch.cuda.synchronize(dev)
+        ts_ = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            call()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ts_.append(e0.elapsed_time(e1) * 1e3)
+        ts_.sort()
+        out.append(ts_[len(ts_) // 2])
+    return out
+
+
 def committed_traffic(key, slot):
     """HBM-side bytes per launch of `slot` for workload `key` from the newest committed PMC summary that has it
     (profiles/r*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 * FETCH + WRITE)."""
@@ -310,6 +392,7 @@ def main():
     ctx.set_stage(args.stage)
     ctx.set_family(args.family)
     ctx.set_block(args.block)
+    ctx.set_dma(args.dma)
     ctx.set_single_pass(args.single_pass, 0)
 
     def dev_from(a):
@@ -340,6 +423,14 @@ def main():
     sPs = torch.empty((n_local, d, d), dtype=dtype_t, device=dev)
     ll_d = torch.zeros((2,), dtype=torch.float64, device=dev)
 
+    rccl_info, exchange_fallback, one_gpu_ms = None, False, None
+    if world > 1 and args.scaling == "strong" and args.path == "lgssm":
+        # the reference of the strong-scaling factor: the SAME series length on ONE GPU (rank 0), outside the timed
+        # region, before any communicator exists; the other ranks wait at the barrier
+        if rank == 0:
+            one_gpu_ms = one_gpu_reference(ctx, sde, d, suf, dtype_np, dtype_t, dev, stream, ts_all, n_total, noise)
+        dist.barrier()
+
     if args.path != "lgssm":
         form = _backend.nilpotent_form(sde.F)
         if form is None or world != 1:
@@ -363,45 +454,73 @@ def main():
     elif use_lib_exchange:
         # the product's multi-GPU path: the context owns the RCCL communicator, one library call per pass
         from pssgp import distributed as pdist
+        import faulthandler
 
-        def bcast(uid):
-            if world == 1:
-                return uid
+        # ncclCommInitRank is collective: a rank that cannot take part must say so BEFORE anyone enters it, or the others
+        # wait for it for ever.  So: (1) rank 0 makes the id, or fails, and broadcasts the outcome over gloo; (2) every
+        # rank reports over gloo whether it is ready; (3) only then the collective init, under a watchdog that ends
+        # the process (non-zero: the launcher then ends the job) if a peer never joins.
+        uid = None
+        if rank == 0:
+            try:
+                uid = _backend.Context.comm_unique_id()
+            except Exception as e:                  # noqa: BLE001
+                print(f"[bench rank 0] pgps_comm_get_unique_id failed ({e!r})", file=sys.stderr)
+        if world > 1:
             box = [uid]
             dist.broadcast_object_list(box, src=0)
-            return box[0]
-
-        lib_ok = 1
-        try:
-            seg = pdist.ShardedScan(ctx, pdist.share_unique_id(rank, broadcast=bcast), rank, world, d, dtype_np)
-        except Exception as e:                      # noqa: BLE001 -- reported, and decided together below
-            lib_ok = 0
-            print(f"[bench rank {rank}] RCCL communicator inside libpgps failed ({e!r}); "
-                  "falling back to --exchange torch", file=sys.stderr)
+            uid = box[0]
+        ready = int(uid is not None and len(uid) == _backend.COMM_ID_BYTES)
+        if world > 1:
+            flag = torch.tensor([ready], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ready = int(flag.item())
+        lib_ok = 0
+        if ready:
+            faulthandler.dump_traceback_later(int(os.environ.get("PGPS_COMM_INIT_TIMEOUT", "180")), exit=True)
+            try:
+                seg = pdist.ShardedScan(ctx, uid, rank, world, d, dtype_np)
+                lib_ok = 1
+            except Exception as e:                  # noqa: BLE001 -- reported, and decided together below
+                print(f"[bench rank {rank}] RCCL communicator inside libpgps failed ({e!r})", file=sys.stderr)
+            finally:
+                faulthandler.cancel_dump_traceback_later()
         if world > 1:                               # every rank takes the same path
             flag = torch.tensor([lib_ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             lib_ok = int(flag.item())
         if lib_ok:
             ptrs = [t.data_ptr() for t in (P0_d, Fs_d, Qs_d, H_d)] + [noise] + [t.data_ptr() for t in (ys_d, fms, fPs, sms, sPs, ll_d)]
+            n_rccl, r_rccl = ctx.comm_count()       # what RCCL itself says (ncclCommCount / ncclCommUserRank)
+            if (n_rccl, r_rccl) != (world, rank):
+                raise SystemExit(f"RCCL communicator reports {n_rccl} ranks / rank {r_rccl}, expected {world} / {rank}")
+            rccl_info = {"in_library": True, "ranks": n_rccl, "allgather_us": allgather_latency(ctx, d, dtype_t, dev, stream, world)}
 
             def step():
                 seg.pkfs(n_local, *ptrs)
         else:
-            # the framework-hosted variant: the three library phases with torch.distributed's RCCL collectives in between
+            # the framework-hosted variant (tools/torch_segment_scan.py): the three library phases with torch.distributed's
+            # RCCL collectives in between -- a FALLBACK, flagged as such in the JSON line
+            print(f"[bench rank {rank}] falling back to --exchange torch", file=sys.stderr)
+            from tools.torch_segment_scan import SegmentScan
             use_lib_exchange = False
+            exchange_fallback = True
             try:
                 ctx.comm_destroy()
             except Exception:                       # noqa: BLE001
                 pass
             group = dist.new_group(backend="nccl") if world > 1 else None
-            seg = pdist.SegmentScan(ctx, rank, world, d, dtype_np, torch_device=dev, group=group)
+            seg = SegmentScan(ctx, rank, world, d, dtype_np, torch_device=dev, group=group)
+            rccl_info = {"in_library": False, "ranks": world if world > 1 else 1, "allgather_us": None,
+                         "via": "torch.distributed nccl (fallback)"}
 
             def step():
                 seg.pkfs(n_local, P0_d, Fs_d, Qs_d, H_d, noise, ys_d, fms, fPs, sms, sPs, ll_d)
     else:
-        from pssgp import distributed as pdist
-        seg = pdist.SegmentScan(ctx, rank, world, d, dtype_np, torch_device=dev)
+        from tools.torch_segment_scan import SegmentScan
+        seg = SegmentScan(ctx, rank, world, d, dtype_np, torch_device=dev)
+        rccl_info = {"in_library": False, "ranks": world if args.dist_backend == "nccl" else 0, "allgather_us": None,
+                     "via": f"torch.distributed {args.dist_backend} (--exchange torch)"}
 
         def step():
             seg.pkfs(n_local, P0_d, Fs_d, Qs_d, H_d, noise, ys_d, fms, fPs, sms, sPs, ll_d)
@@ -433,7 +552,8 @@ def main():
     dominant = max(per_pass, key=per_pass.get) if per_pass else "k_smoother_apply"
     empty_pair_ms = ctx.profile_calibrate()
     ctx.profile_read(reset=True)
-    ctx.profile_sample(max(1, args.event_every))
+    # a short timed region (the driver's --steps 20) samples EVERY launch of the dominant kernel
+    ctx.profile_sample(1 if args.steps <= 32 else max(1, args.event_every))
     dom_slot = SLOT_INDEX[dominant]
     ctx.profile_enable((1 << dom_slot) if args.event_every > 0 else 0)   # time the dominant slot's launches
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -499,7 +619,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": args.scaling if world > 1 else "weak",
+        "scaling": args.scaling if world > 1 else None,     # one GPU: neither weak nor strong
         "vs_baseline": None,
         "dtype": suf,
         "data": "synthetic",
@@ -538,6 +658,16 @@ def main():
                           else None),
     }
 
+    if world > 1 or args.force_segments:
+        out["rccl"] = rccl_info
+        out["exchange_fallback"] = bool(exchange_fallback)
+    if one_gpu_ms is not None:
+        n_ms = elapsed / args.steps * 1e3
+        out["strong_scaling"] = {"one_gpu_ms": one_gpu_ms, "n_gpu_ms": n_ms, "speedup": one_gpu_ms / n_ms,
+                                 "efficiency": one_gpu_ms / n_ms / world,
+                                 "series": f"the same 2^{args.log2n} steps in one pgps_pkfs_dev_{suf} call on rank 0's GPU, "
+                                           "median of 3 rounds of 5 passes, before the communicator is built"}
+
     # ---- the same workload through the fused entry point (ts, ys resident; Fs / Qs never read) ------------
     if rank == 0 and world == 1 and args.path == "lgssm" and not args.main_only and _backend.nilpotent_form(sde.F) is not None:
         lam, N1, N2 = _backend.nilpotent_form(sde.F)
@@ -553,19 +683,15 @@ def main():
                      P(sPs) if full else null, P(ll_d))
 
         fused = {}
+        sync = lambda: torch.cuda.synchronize(dev)
+        rounds, reps = (5, 20) if args.steps >= 20 else (2, max(1, args.steps))
         for name, full in (("filter+smooth+log-lik", True), ("log-lik only", False)):
-            for _ in range(10):
-                gp_step(full)
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(min(args.steps, 100)):
-                gp_step(full)
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            ms = e0.elapsed_time(e1) / min(args.steps, 100)
-            fused[name] = {"ms_per_step": ms, "timesteps_per_s": n_local / ms * 1e3,
-                           "log_likelihood": float(ll_d[0].item())}
+            r_ = timed_rounds(lambda: gp_step(full), stream, sync, reps=reps, rounds=rounds)
+            r_.update({"timesteps_per_s": n_local / r_["ms_per_step"] * 1e3, "log_likelihood": float(ll_d[0].item())})
+            fused[name] = r_
+        # geometry of the fused kernels (always the 256-lane build: csrc/pgps_inst.hip launch_gp)
+        g_lc, g_nb = ctx.get_chunk(n_local)
+        fused["geometry"] = {"lanes_per_workgroup": 256, "steps_per_lane": g_lc, "workgroups": g_nb}
         if d <= 2 and dtype_np == np.float64:
             from pssgp.model import StateSpaceGP
             gm = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), kern, noise_variance=noise, parallel=True)
@@ -576,19 +702,10 @@ def main():
                 ctx.call("pgps_gp_ll_grad_dev_f64", ctypes.c_long(n_local), ctypes.c_int(d), ctypes.c_int(npar),
                          HP(gmodel), P(ts_d), ctypes.c_double(t_prev), P(ys_d), P(g_d))
 
-            for _ in range(5):
-                grad_step()
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(min(args.steps, 50)):
-                grad_step()
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            ms = e0.elapsed_time(e1) / min(args.steps, 50)
-            fused["log-lik + gradient (3 hyper-parameters, forward-mode duals)"] = {
-                "ms_per_step": ms, "timesteps_per_s": n_local / ms * 1e3,
-                "log_likelihood": float(g_d[0].item()), "gradient": [float(v) for v in g_d[1:1 + npar].tolist()]}
+            r_ = timed_rounds(grad_step, stream, sync, reps=reps, rounds=rounds)
+            r_.update({"timesteps_per_s": n_local / r_["ms_per_step"] * 1e3, "log_likelihood": float(g_d[0].item()),
+                       "gradient": [float(v) for v in g_d[1:1 + npar].tolist()]})
+            fused["log-lik + gradient (3 hyper-parameters, forward-mode duals)"] = r_
         # predict_f on the device: N training steps + N/4 query times (merge + filter + smoother + projection)
         kq = max(1, n_local // 4)
         tq_d = (torch.rand(kq, dtype=torch.float64, device=dev) * float(ts_d[-1].item())).sort().values.to(dtype_t)
@@ -600,18 +717,9 @@ def main():
                      ctypes.c_double(lam), HP(N1), HP(N2), HP(Pinf_h), HP(H_h), ctypes.c_double(noise), P(ts_d), P(ys_d),
                      ctypes.c_double(t_prev), P(tq_d), P(pm_d), P(pv_d), P(ll_d))
 
-        for _ in range(5):
-            predict_step()
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(min(args.steps, 50)):
-            predict_step()
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / min(args.steps, 50)
-        fused[f"predict_f on device (N train + N/4 = {kq} queries)"] = {
-            "ms_per_step": ms, "merged_timesteps_per_s": (n_local + kq) / ms * 1e3}
+        r_ = timed_rounds(predict_step, stream, sync, reps=reps, rounds=rounds)
+        r_["merged_timesteps_per_s"] = (n_local + kq) / r_["ms_per_step"] * 1e3
+        fused[f"predict_f on device (N train + N/4 = {kq} queries)"] = r_
         fused["note"] = ("pgps_gp_dev: discretisation fused into the scan kernels, inputs are (ts, ys) only; "
                          "GPU-event time, not part of `value`")
         out["fused_path"] = fused
@@ -638,20 +746,12 @@ def main():
                      P(pm_d), P(pv_d), P(ll_d))
 
         lti = {}
+        sync = lambda: torch.cuda.synchronize(dev)
         for name, fn, steps in (("log-lik only (discretise + filter)", lti_ll_step, n_local),
                                 (f"predict_f on device (N train + N/4 = {kq} queries)", lti_predict_step, n_local + kq)):
-            for _ in range(2):
-                fn()
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = min(args.steps, 10)
-            e0.record(stream)
-            for _ in range(reps):
-                fn()
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            ms = e0.elapsed_time(e1) / reps
-            lti[name] = {"ms_per_step": ms, "timesteps_per_s": steps / ms * 1e3, "log_likelihood": float(ll_d[0].item())}
+            r_ = timed_rounds(fn, stream, sync, reps=min(max(1, args.steps), 10), rounds=5 if args.steps >= 10 else 2, warm=2)
+            r_.update({"timesteps_per_s": steps / r_["ms_per_step"] * 1e3, "log_likelihood": float(ll_d[0].item())})
+            lti[name] = r_
         lti["note"] = ("pgps_lti_*_dev_f64: discretisation, scan and projection on the device, inputs are (ts, ys[, tq]) "
                        "only; GPU-event time, not part of `value`")
         out["lti_path"] = lti

@@ -75,6 +75,11 @@ int pgps_set_family(pgps_ctx* ctx, int family);
  * The library carries both builds; the fused (pgps_gp_*) kernels always use 256.  Do not change it between the phases
  * of a segment pass (refused).  pgps_get_chunk reports the geometry of the 256-lane build. */
 int pgps_set_block(pgps_ctx* ctx, int lanes);
+/* Kalman pass of the 128-lane lane-chunk kernels at d = 2, fp64 (16 or 32 steps per lane): inputs through a ring of
+ * LDS-DMA slots (buffer_load ... lds) requested before the workgroup folds the spine, instead of register staging.
+ * -1 = automatic (= off: measured slower at 2^20 steps, profiles/r03_experiments.txt), 0 = off, 1 = on (the ring takes
+ * 128 KiB of LDS: one workgroup per CU). */
+int pgps_set_dma(pgps_ctx* ctx, int mode);
 /* What a lane-chunk call (or one rank's segment) of N steps at state dimension d <= PGPS_MAX_DIM_LANE runs with: lanes per
  * workgroup (128 / 256), steps per lane, workgroups -- after pgps_set_block / pgps_set_chunk. */
 int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* steps_per_lane, int* workgroups);
@@ -344,6 +349,7 @@ int pgps_comm_get_unique_id(void* id);
 int pgps_comm_init(pgps_ctx* ctx, const void* id, int rank, int nranks);
 int pgps_comm_destroy(pgps_ctx* ctx);
 int pgps_comm_info(pgps_ctx* ctx, int* rank, int* nranks);      /* nranks = 0: no communicator */
+int pgps_comm_count(pgps_ctx* ctx, int* nranks, int* rank);     /* as RCCL reports them (ncclCommCount / ncclCommUserRank); rank may be NULL */
 int pgps_comm_allgather_dev(pgps_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
 int pgps_pkfs_seg_dev_f64(pgps_ctx*, long N, int d, const double* P0, const double* Fs, const double* Qs, const double* H,
                           double R, const double* ys, double* fms, double* fPs, double* sms, double* sPs, double* ll);

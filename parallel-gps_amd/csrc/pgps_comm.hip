@@ -64,6 +64,20 @@ extern "C" int pgps_comm_info(pgps_ctx* ctx, int* rank, int* nranks) {
     return PGPS_OK;
 }
 
+// what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank): 0 ranks = no communicator
+extern "C" int pgps_comm_count(pgps_ctx* ctx, int* nranks, int* rank) {
+    if (!ctx || !nranks) return PGPS_E_INVALID;
+    *nranks = 0;
+    if (rank) *rank = 0;
+    if (!ctx->comm) return PGPS_OK;
+    int n = 0, r = 0;
+    NCCLCHK(ctx, ncclCommCount((ncclComm_t)ctx->comm, &n));
+    NCCLCHK(ctx, ncclCommUserRank((ncclComm_t)ctx->comm, &r));
+    *nranks = n;
+    if (rank) *rank = r;
+    return PGPS_OK;
+}
+
 namespace pgps {
 int comm_allgather(pgps_ctx* ctx, const void* send, void* recv, size_t bytes) {
     if (!ctx->comm) return PGPS_E_INVALID;

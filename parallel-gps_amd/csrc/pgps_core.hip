@@ -163,6 +163,12 @@ extern "C" int pgps_set_block(pgps_ctx* ctx, int lanes) {
     return PGPS_OK;
 }
 
+extern "C" int pgps_set_dma(pgps_ctx* ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 1) return PGPS_E_INVALID;
+    ctx->dma = mode;
+    return PGPS_OK;
+}
+
 extern "C" int pgps_set_stage(pgps_ctx* ctx, int g) {
     if (!ctx || !(g == -1 || g == 0 || g == 2 || g == 4)) return PGPS_E_INVALID;
     ctx->stage_g = g;
@@ -714,11 +720,12 @@ static int seg_common(pgps_ctx* ctx, long N, int d, int rank, int nranks, ScanAr
 static bool seg_follows(const pgps_ctx* ctx, int phase, long N, int d, int rank, int nranks) {
     const auto& t = ctx->seg_tag;
     return t.phase == phase - 1 && t.N == N && t.d == d && t.rank == rank && t.nranks == nranks && t.chunk == ctx->chunk && t.block == ctx->block &&
-           t.epoch == ctx->ws_epoch;
+           t.family == ctx->family && t.stage_g == ctx->stage_g && t.dma == ctx->dma && t.epoch == ctx->ws_epoch;
 }
 static void seg_mark(pgps_ctx* ctx, int phase, long N, int d, int rank, int nranks) {
     ctx->seg_tag.phase = phase; ctx->seg_tag.N = N; ctx->seg_tag.d = d; ctx->seg_tag.rank = rank;
-    ctx->seg_tag.nranks = nranks; ctx->seg_tag.chunk = ctx->chunk; ctx->seg_tag.block = ctx->block; ctx->seg_tag.epoch = ctx->ws_epoch;
+    ctx->seg_tag.nranks = nranks; ctx->seg_tag.chunk = ctx->chunk; ctx->seg_tag.block = ctx->block; ctx->seg_tag.family = ctx->family;
+    ctx->seg_tag.stage_g = ctx->stage_g; ctx->seg_tag.dma = ctx->dma; ctx->seg_tag.epoch = ctx->ws_epoch;
 }
 
 template <typename T>

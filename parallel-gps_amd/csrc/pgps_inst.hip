@@ -23,6 +23,8 @@
 #include "pgps_kernels.hip.h"
 #endif
 
+#include <type_traits>
+
 #ifndef PGPS_INST_T
 #error "compile with -DPGPS_INST_T=<float|double> -DPGPS_INST_D=<d>"
 #endif
@@ -90,6 +92,28 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     a.carry_in = a.seg_ws;
     a.halo_FQ = a.seg_ws + (D + D * D);
     a.carry_back = a.seg_ws + (D + D * D) + 2 * D * D;
+    // the Kalman pass with its inputs through an LDS-DMA ring (FilterApplyDma): 128-lane build, d = 2, fp64, 4-step
+    // sub-tiles, 16 or 32 steps per lane.  A measured experiment, off unless asked for (pgps_set_dma(ctx, 1)): the ring
+    // fills while the spine is folded, but issuing its 64 pieces costs the prologue what the loop then saves -- the
+    // streaming loops are bound by the CU's memory path (10 - 14 B/clk), not by latency (profiles/r03_experiments.txt)
+    bool dma = false;
+#ifdef PGPS_NARROW
+    if constexpr (sizeof(T) == 8 && D == 2 && G == 4)
+        dma = ctx->dma > 0 && (a.Lc == 16 || a.Lc == 32);
+#endif
+    auto launch_apply = [&](auto smooth_tag) {
+        constexpr bool SMOOTH = decltype(smooth_tag)::value;
+#ifdef PGPS_NARROW
+        if constexpr (sizeof(T) == 8 && D == 2 && G == 4) {
+            if (dma) {
+                timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, SMOOTH, G, NT, true>, grid, block, 0, a);
+                return;
+            }
+        }
+#endif
+        timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, SMOOTH, G, NT>, grid, block, 0, a);
+    };
+    (void)dma;
     if (mode == MODE_SEG_REDUCE || mode == MODE_SEG_FILTER || mode == MODE_SEG_SMOOTHER) {
         // one segment of a series sharded over GPUs: carry_in / halo_FQ / carry_back live in seg_ws
         a.seg_first = (a.rank == 0);
@@ -105,7 +129,7 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
             // halo step of this segment = first step of the next rank, straight out of its record
             if (!a.seg_last)
                 a.halo_FQ = a.gathered_f + (long)(a.rank + 1) * seg_rec_f_len(D) + Dim<D>::NFILT;
-            timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, true, G, NT>, grid, block, 0, a);
+            launch_apply(std::true_type{});
             hipLaunchKernelGGL((k_seg_smoother_total<T, D>), dim3(1), block, 0, s, a, pad);
         } else timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_smoother_apply<T, D, G, NT>, grid, block, 0, a);
         HIPCHK(ctx, hipGetLastError());
@@ -138,8 +162,8 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     }
     if (mode == MODE_PKF || mode == MODE_PKFS) {
         timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_filter_reduce<T, D, G>, grid, block, 0, a);
-        if (mode == MODE_PKFS) timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, true, G, NT>, grid, block, 0, a); else {
-            timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, false, G, NT>, grid, block, 0, a);
+        if (mode == MODE_PKFS) launch_apply(std::true_type{}); else {
+            launch_apply(std::false_type{});
             if (a.ll) {
                 timed_launch(ctx, PGPS_K_LL_FINALIZE, k_ll_finalize, dim3(1), block, 0, (const double*)a.llpart, a.nblocks,
                              a.ll);

@@ -25,6 +25,7 @@ struct pgps_ctx {
     int single_pass = -1;               // single-pass filter kernel: -1 = auto, 0 = off, 1 = on
     int lookback_window = 256;          // tiles per look-back window (<= 256; small values are for tests)
     int block = 0;                      // lane-chunk workgroups: 0 = auto, 128 / 256 lanes (pgps_set_block)
+    int dma = -1;                       // LDS-DMA ring in the Kalman pass (d = 2 fp64, 128-lane build): -1 = auto, 0 = off, 1 = on
     int family = 0;                     // 0 = auto (lane-chunk d <= 6; row-cooperative fp64 d <= 16; else wave-cooperative), 1 = lane, 2 = wave, 3 = row
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
@@ -39,7 +40,7 @@ struct pgps_ctx {
     DevBuf comm_buf;                    // [rec_f | rec_s | gathered_f | gathered_s] of pgps_pkfs_seg_dev_*
     // the three-phase segment protocol keeps state in `ws` between its calls: what the last phase left, and the
     // workspace epoch (bumped by every call that carves `ws`) it left it at
-    struct SegTag { int phase = 0; long N = 0; int d = 0, rank = 0, nranks = 0, chunk = 0, block = 0; unsigned long epoch = 0; } seg_tag;
+    struct SegTag { int phase = 0; long N = 0; int d = 0, rank = 0, nranks = 0, chunk = 0, block = 0, family = 0, stage_g = 0, dma = 0; unsigned long epoch = 0; } seg_tag;
     unsigned long ws_epoch = 0;
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
     int prof_every = 1;                 // time every n-th launch of an enabled slot

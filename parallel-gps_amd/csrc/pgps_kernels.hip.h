@@ -207,6 +207,8 @@ __device__ __forceinline__ float wshfl_up(float x, int s) { return __shfl_up(x, 
 __device__ __forceinline__ double wshfl_up(double x, int s) { return __shfl_up(x, s, kWave); }
 __device__ __forceinline__ float wshfl_down(float x, int s) { return __shfl_down(x, s, kWave); }
 __device__ __forceinline__ double wshfl_down(double x, int s) { return __shfl_down(x, s, kWave); }
+__device__ __forceinline__ float wshfl_idx(float x, int l) { return __shfl(x, l, kWave); }
+__device__ __forceinline__ double wshfl_idx(double x, int l) { return __shfl(x, l, kWave); }
 
 template <typename E>
 __device__ __forceinline__ E shfl_up_elem(const E& e, int s) {
@@ -229,6 +231,116 @@ __device__ __forceinline__ E shfl_down_elem(const E& e, int s) {
     E r;
     unpack(v, r);
     return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave scans on DPP.  The shuffles above are ds_bpermute_b32 -- an LDS-pipeline instruction per dword and level;
+// the cross-lane moves of a scan are regular, so they go out as v_mov_b32_dpp instead (a VALU move with a lane
+// pattern, no LDS traffic): row_shr / row_shl : 1, 2, 4, 8 scan the four 16-lane rows, row_bcast:15 (rows 1, 3 take
+// lane 15 / 47) and row_bcast:31 (rows 2, 3 take lane 31) carry the row totals forwards; wave_shr:1 / wave_shl:1 turn
+// the inclusive result into the exclusive one.  There is no backward counterpart of row_bcast, so the suffix scan
+// takes the two cross-row levels through two rounds of indexed shuffles (first lane of the next row / of the row after).
+// Operands stay contiguous ranges of lanes at every step, so associativity is all the operator needs.
+// Plain float / double elements only: dual-number elements (pgps_grad.hip.h) keep the shuffle tree.
+// -DPGPS_DPP_SCAN=0 builds the shuffle trees everywhere (A/B: profiles/r03_experiments.txt).
+// ---------------------------------------------------------------------------------------------
+#ifndef PGPS_DPP_SCAN
+#define PGPS_DPP_SCAN 1
+#endif
+template <typename S> struct DppScalar { static constexpr bool ok = false; };
+template <> struct DppScalar<float> { static constexpr bool ok = PGPS_DPP_SCAN != 0; };
+template <> struct DppScalar<double> { static constexpr bool ok = PGPS_DPP_SCAN != 0; };
+
+constexpr int kDppRowShr = 0x110, kDppRowShl = 0x100, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138,
+              kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov(float x) {
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK, typename E>
+__device__ __forceinline__ E dpp_elem(const E& e) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+    pack(e, v);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) v[i] = dpp_mov<CTRL, ROWMASK>(v[i]);
+    E r;
+    unpack(v, r);
+    return r;
+}
+template <typename E>
+__device__ __forceinline__ E shfl_idx_elem(const E& e, int l) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+    pack(e, v);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) v[i] = wshfl_idx(v[i], l);
+    E r;
+    unpack(v, r);
+    return r;
+}
+
+// inclusive scan over the 64 lanes of a wave (lane order = time order), in place
+template <typename E, bool FORWARD>
+__device__ __forceinline__ void wave_scan_inclusive(E& incl, int lane) {
+    using TR = ElemTraits<E>;
+    if constexpr (DppScalar<typename TR::Scalar>::ok) {
+        const int r = lane & 15;
+        auto step = [&](const E& other, bool act) {
+            if (act) {
+                E t;
+                if (FORWARD) TR::combine(other, incl, t); else TR::combine(incl, other, t);
+                incl = t;
+            }
+        };
+        if constexpr (FORWARD) {
+            step(dpp_elem<kDppRowShr + 1, 0xf>(incl), r >= 1);
+            step(dpp_elem<kDppRowShr + 2, 0xf>(incl), r >= 2);
+            step(dpp_elem<kDppRowShr + 4, 0xf>(incl), r >= 4);
+            step(dpp_elem<kDppRowShr + 8, 0xf>(incl), r >= 8);
+            step(dpp_elem<kDppBcast15, 0xa>(incl), (lane & 16) != 0);
+            step(dpp_elem<kDppBcast31, 0xc>(incl), lane >= 32);
+        } else {
+            step(dpp_elem<kDppRowShl + 1, 0xf>(incl), r + 1 < 16);
+            step(dpp_elem<kDppRowShl + 2, 0xf>(incl), r + 2 < 16);
+            step(dpp_elem<kDppRowShl + 4, 0xf>(incl), r + 4 < 16);
+            step(dpp_elem<kDppRowShl + 8, 0xf>(incl), r + 8 < 16);
+            const int row = lane >> 4;
+            step(shfl_idx_elem(incl, ((row + 1) & 3) * 16), row < 3);      // total of the next row
+            step(shfl_idx_elem(incl, ((row + 2) & 3) * 16), row < 2);      // rows 2.. (row 0) / row 3 (row 1)
+        }
+    } else {
+#pragma unroll
+        for (int s = 1; s < kWave; s <<= 1) {
+            E other = FORWARD ? shfl_up_elem(incl, s) : shfl_down_elem(incl, s);
+            const bool act = FORWARD ? (lane >= s) : (lane + s < kWave);
+            if (act) {
+                E t;
+                if (FORWARD) TR::combine(other, incl, t); else TR::combine(incl, other, t);
+                incl = t;
+            }
+        }
+    }
+}
+// the neighbour's value: lane - 1 (FORWARD) or lane + 1; the first / last lane gets something it must not use
+template <typename E, bool FORWARD>
+__device__ __forceinline__ E wave_shift1(const E& e) {
+    using TR = ElemTraits<E>;
+    if constexpr (DppScalar<typename TR::Scalar>::ok) {
+        if constexpr (FORWARD) return dpp_elem<kDppWaveShr1, 0xf>(e);
+        else return dpp_elem<kDppWaveShl1, 0xf>(e);
+    } else {
+        return FORWARD ? shfl_up_elem(e, 1) : shfl_down_elem(e, 1);
+    }
 }
 
 // strided (field-major) workspace I/O: value f of lane-slot t lives at ws[f * stride + t]
@@ -278,17 +390,8 @@ __device__ __forceinline__ void block_scan_exclusive(const E& mine, E& excl, E& 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     E incl = mine;
-#pragma unroll
-    for (int s = 1; s < kWave; s <<= 1) {
-        E other = FORWARD ? shfl_up_elem(incl, s) : shfl_down_elem(incl, s);
-        const bool act = FORWARD ? (lane >= s) : (lane + s < kWave);
-        if (act) {
-            E r;
-            if (FORWARD) TR::combine(other, incl, r); else TR::combine(incl, other, r);
-            incl = r;
-        }
-    }
-    E wex = FORWARD ? shfl_up_elem(incl, 1) : shfl_down_elem(incl, 1);
+    wave_scan_inclusive<E, FORWARD>(incl, lane);
+    E wex = wave_shift1<E, FORWARD>(incl);
     if (FORWARD ? (lane == 0) : (lane == kWave - 1)) TR::identity(wex);
     // wavefront totals to LDS
     if (FORWARD ? (lane == kWave - 1) : (lane == 0)) {
@@ -331,12 +434,19 @@ __device__ __forceinline__ void block_reduce_ordered(const E& mine, E& total, ty
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     E acc = mine;
+    int src_lane = 0;
+    if constexpr (DppScalar<typename TR::Scalar>::ok) {
+        // the forward DPP scan leaves the wave's total in its last lane
+        wave_scan_inclusive<E, true>(acc, lane);
+        src_lane = kWave - 1;
+    } else {
 #pragma unroll
-    for (int s = 1; s < kWave; s <<= 1) {
-        E other = shfl_down_elem(acc, s);
-        if ((lane & (2 * s - 1)) == 0) { E r; TR::combine(acc, other, r); acc = r; }
+        for (int s = 1; s < kWave; s <<= 1) {
+            E other = shfl_down_elem(acc, s);
+            if ((lane & (2 * s - 1)) == 0) { E r; TR::combine(acc, other, r); acc = r; }
+        }
     }
-    if (lane == 0) {
+    if (lane == src_lane) {
         typename TR::Scalar v[TR::N];
         pack(acc, v);
 #pragma unroll
@@ -484,6 +594,17 @@ __device__ __forceinline__ void fold_spine_partial(const typename ElemTraits<E>:
     TR::identity(acc);
     const int b0 = lo + (int)threadIdx.x * per;
     const int b1 = min(hi, b0 + per);
+    if (per <= 2) {
+        // the common geometries (<= 2 entries per lane): both records are requested before either is used, so the
+        // fold pays one round trip to memory instead of two
+        E e0, e1;
+        const bool h0 = b0 < b1, h1 = b0 + 1 < b1;
+        if (h0) rec_load(spine + (long)b0 * TR::N, e0);
+        if (h1) rec_load(spine + (long)(b0 + 1) * TR::N, e1);
+        if (h1) TR::combine(e0, e1, acc);
+        else if (h0) acc = e0;
+        return;
+    }
     bool have = false;
     for (int b = b0; b < b1; ++b) {
         E e;
@@ -811,16 +932,241 @@ struct FilterApplyStaged {
     }
 };
 
-template <typename T, int D, bool SMOOTH, int G, bool NT>
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA ring for the Kalman pass at d = 2, fp64 (configs c2 / c4; 128-lane build only).
+//
+// Phase stamps of the register-staged kernels at 2^20 steps (profiles/r03_stamps_before.txt): the streaming loops move
+// their bytes at 5.7 - 7.3 TB/s -- the memory system's ceiling -- but 17 us of the 81 us pass are prologues and epilogues
+// in which every CU folds a spine or scans its lanes while the memory pipes idle.  This variant puts input traffic into
+// those phases: F and Q of a wave's sub-tiles travel by `buffer_load_dwordx4 ... lds` (no registers, no ds_write pass)
+// into a ring of K slots, requested BEFORE the workgroup folds the spine, so the ring fills while the fold computes and
+// the first K sub-tiles of the Kalman pass run at arithmetic speed; y arrives the same way, once per chunk.
+//
+// A DMA piece is lane-linear on its LDS side (lane p of the wave-instruction writes bytes [16p, 16p+16) of the KiB at
+// M0), so the bank-conflict-free image is made on the SOURCE side: piece (owner o, physical position pp) is fetched from
+// the owner's LOGICAL piece pp ^ f(o), f(o) = (o & 7) ^ ((o >> 3) & 1).  With that f both the owners' ds_read_b128 of
+// their records (four 16-lane groups, 64 banks) and their ds_write_b128 of the results (eight 8-lane groups, 32 banks)
+// are conflict-free (checked exhaustively; tools/micro/dma_ring.hip verifies the addressing on the device).
+//
+// The DMAs are inline asm: hipcc neither counts them in its s_waitcnt bookkeeping nor knows that they write LDS, so
+//   * every wait for a slot is a hand-counted s_waitcnt vmcnt(n): n = the vector-memory operations of this wave that are
+//     younger than the slot's last piece -- the later slots' pieces (16 per sub-tile) and the drains' stores (12 per
+//     sub-tile) -- loads, stores and DMAs retire in issue order;
+//   * no compiler-counted LOAD may be in flight while DMAs are: hipcc would wait for it with a count that ignores the
+//     DMAs, i.e. for the whole ring.  The kernel therefore pins its small prologue loads (spine, local prefix, halo)
+//     before the first DMA is issued, and everything it loads afterwards comes out of LDS.
+// ---------------------------------------------------------------------------------------------
+// make hipcc finish its own outstanding loads of these values here (it inserts the s_waitcnt in front of the statement)
+__device__ __forceinline__ void pin_values(double* v, int n) {
+    for (int i = 0; i < n; ++i) asm volatile("" : "+v"(v[i]));
+}
+template <typename E>
+__device__ __forceinline__ void pin_elem(E& e) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+    pack(e, v);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) asm volatile("" : "+v"(v[i]));
+    unpack(v, e);
+}
+
+#if defined(PGPS_NARROW)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define PGPS_VMC(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+        PGPS_VMC(0) PGPS_VMC(1) PGPS_VMC(2) PGPS_VMC(3) PGPS_VMC(4) PGPS_VMC(5) PGPS_VMC(6) PGPS_VMC(7) PGPS_VMC(8)
+        PGPS_VMC(9) PGPS_VMC(10) PGPS_VMC(11) PGPS_VMC(12) PGPS_VMC(13) PGPS_VMC(14) PGPS_VMC(15) PGPS_VMC(16)
+        PGPS_VMC(17) PGPS_VMC(18) PGPS_VMC(19) PGPS_VMC(20) PGPS_VMC(21) PGPS_VMC(22) PGPS_VMC(23) PGPS_VMC(24)
+        PGPS_VMC(25) PGPS_VMC(26) PGPS_VMC(27) PGPS_VMC(28) PGPS_VMC(29) PGPS_VMC(30) PGPS_VMC(31) PGPS_VMC(32)
+        PGPS_VMC(33) PGPS_VMC(34) PGPS_VMC(35) PGPS_VMC(36) PGPS_VMC(37) PGPS_VMC(38) PGPS_VMC(39) PGPS_VMC(40)
+        PGPS_VMC(41) PGPS_VMC(42) PGPS_VMC(43) PGPS_VMC(44) PGPS_VMC(45) PGPS_VMC(46) PGPS_VMC(47) PGPS_VMC(48)
+        PGPS_VMC(49) PGPS_VMC(50) PGPS_VMC(51) PGPS_VMC(52) PGPS_VMC(53) PGPS_VMC(54) PGPS_VMC(55) PGPS_VMC(56)
+        PGPS_VMC(57) PGPS_VMC(58) PGPS_VMC(59) PGPS_VMC(60) PGPS_VMC(61) PGPS_VMC(62)
+#undef PGPS_VMC
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+}
+
+// eight 1 KiB DMA pieces: piece v (owners 8v .. 8v+7) from rs + soff + v * stride + voff{v & 1} to LDS lds + v * 1024
+__device__ __forceinline__ void dma_issue8(__amdgpu_buffer_rsrc_t rs, unsigned voff0, unsigned voff1, unsigned soff,
+                                           unsigned stride, unsigned lds) {
+    unsigned keep, so;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_mov_b32 %[so], %[soff]\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 %[so], %[so], %[stride]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 %[so], %[so], %[stride]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 %[so], %[so], %[stride]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 %[so], %[so], %[stride]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 %[so], %[so], %[stride]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 %[so], %[so], %[stride]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 %[so], %[so], %[stride]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep), [so] "=&s"(so)
+        : [lds] "s"(lds), [soff] "s"(soff), [stride] "s"(stride), [v0] "v"(voff0), [v1] "v"(voff1), [rs] "s"(rs)
+        : "memory");
+}
+__device__ __forceinline__ void dma_issue1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 4\n\t"
+                 "buffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\ts_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep) : [lds] "s"(lds), [so] "s"(soff), [v0] "v"(voff), [rs] "s"(rs) : "memory");
+}
+template <bool SMOOTH, bool NT>
+struct FilterApplyDma {
+    using T = double;
+    static constexpr int D = 2, MAT = 4, G = 4, K = 3;
+    static constexpr int SEG = 128, ARR = kWave * SEG, SLOT = 2 * ARR;     // F | Q of one sub-tile
+    static constexpr int YB = 32 * 8 * kWave;                               // y of a whole chunk (<= 32 steps per lane)
+    static constexpr int BYTES = K * SLOT + YB;                             // per wave
+    static constexpr int nD = 16, nS = 12;                                  // DMA pieces / drain stores per sub-tile
+    __amdgpu_buffer_rsrc_t rF, rQ, rP, rM;
+    unsigned voff0, voff1, fo, lbase, pitch;
+    T Fh[MAT], Qh[MAT];
+    bool have_next;
+
+    static __device__ __forceinline__ bool usable(const ScanArgs<T>& a) { return a.Lc == 32 || a.Lc == 16; }
+
+    __device__ __forceinline__ void issue(int sb) const {
+        const unsigned slot = lbase + (unsigned)(sb % K) * SLOT;
+        dma_issue8(rF, voff0, voff1, (unsigned)sb * SEG, 8u * pitch, slot);
+        dma_issue8(rQ, voff0, voff1, (unsigned)sb * SEG, 8u * pitch, slot + ARR);
+    }
+
+    // issues the first K sub-tiles and the chunk's observations; the caller has pinned every load of its own before
+    __device__ __forceinline__ void prefetch(const ScanArgs<T>& a, long wbase, char* lds) {
+        const int lane = threadIdx.x & (kWave - 1);
+        const int S = a.Lc / G;
+        pitch = (unsigned)a.Lc * (MAT * 8u);
+        const unsigned span = kWave * pitch;
+        rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.Fs + wbase * MAT), 0, (int)span, 0x00020000);
+        rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.Qs + wbase * MAT), 0, (int)span, 0x00020000);
+        rP = __builtin_amdgcn_make_buffer_rsrc(a.fPs + wbase * MAT, 0, (int)span, 0x00020000);
+        rM = __builtin_amdgcn_make_buffer_rsrc(a.fms + wbase * D, 0, (int)(span / 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.ys + wbase), 0, kWave * a.Lc * 8, 0x00020000);
+        lbase = (unsigned)(size_t)lds;
+        const unsigned po = lane >> 3, pp = lane & 7;
+        voff0 = po * pitch + ((pp ^ po) << 4);
+        voff1 = po * pitch + ((pp ^ po ^ 1u) << 4);
+        fo = (lane & 7) ^ ((lane >> 3) & 1);
+        issue(0);
+        // y: Lc / 2 granules of 16 bytes per owner, owner-major, granule jj of owner o at physical jj ^ h(o)
+        const unsigned NG = (unsigned)a.Lc / 2;
+        for (int t = 0; t < a.Lc / 2; ++t) {
+            const unsigned q = (unsigned)t * kWave + lane;
+            const unsigned o = q / NG, pj = q % NG;
+            const unsigned ho = (NG == 16) ? (o & 15u) : ((o & 7u) ^ ((o >> 3) & 1u));
+            dma_issue1(rY, (o * NG + (pj ^ ho)) * 16u, 0u, lbase + K * SLOT + (unsigned)t * 1024u);
+        }
+        for (int sb = 1; sb < K && sb < S; ++sb) issue(sb);
+    }
+
+    // this lane's record i of array `seg` (its 128-byte segment of a slot)
+    static __device__ __forceinline__ void get_rec(const char* seg, unsigned f, int i, T* out) {
+        const V4 x0 = *reinterpret_cast<const V4*>(seg + ((((unsigned)(2 * i)) ^ f) << 4));
+        const V4 x1 = *reinterpret_cast<const V4*>(seg + ((((unsigned)(2 * i + 1)) ^ f) << 4));
+        __builtin_memcpy(&out[0], &x0, 16);
+        __builtin_memcpy(&out[2], &x1, 16);
+    }
+
+    __device__ __forceinline__ void run(const ScanArgs<T>& a, long wbase, char* lds, const T* h, MeanCov<T, D>& s,
+                                        LogLik& ll, SmthElem<T, D>& sagg) {
+        const int lane = threadIdx.x & (kWave - 1);
+        const int S = a.Lc / G;
+        const long k0 = wbase + (long)lane * a.Lc;
+        const unsigned NG = (unsigned)a.Lc / 2, hmask = NG - 1;
+        const unsigned hself = (NG == 16) ? ((unsigned)lane & 15u) : fo;
+        const char* sY = lds + K * SLOT + lane * NG * 16;
+        for (int sb = 0; sb < S; ++sb) {
+            int later = S - 1 - sb; if (later > K - 1) later = K - 1;
+            int prev = sb; if (prev > K - 1) prev = K - 1;
+            wait_vmcnt(nD * later + nS * prev);         // 56 at most
+            wave_lds_sync();
+            char* slot = lds + (sb % K) * SLOT;
+            char* sF = slot + lane * SEG;
+            char* sQ = sF + ARR;
+            if (SMOOTH && sb == 0 && lane < kWave - 1) {
+                // record 0 of the next lane = this lane's halo step
+                const unsigned fn = ((unsigned)(lane + 1) & 7) ^ (((unsigned)(lane + 1) >> 3) & 1);
+                get_rec(sF + SEG, fn, 0, Fh);
+                get_rec(sQ + SEG, fn, 0, Qh);
+                have_next = true;
+            }
+            T yv[G];
+            {
+                const V4 y0 = *reinterpret_cast<const V4*>(sY + ((((unsigned)(2 * sb)) ^ hself) & hmask) * 16);
+                const V4 y1 = *reinterpret_cast<const V4*>(sY + ((((unsigned)(2 * sb + 1)) ^ hself) & hmask) * 16);
+                __builtin_memcpy(&yv[0], &y0, 16);
+                __builtin_memcpy(&yv[2], &y1, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const long k = k0 + sb * G + i;
+                T F[MAT], Qf[MAT];
+                get_rec(sF, fo, i, F);
+                get_rec(sQ, fo, i, Qf);
+                filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, yv[i], h, s, ll, sagg);
+                T Pf[MAT];
+                full_from_sym<T, D>(s.P, Pf);
+                V4 p0, p1, m0;
+                __builtin_memcpy(&p0, &Pf[0], 16);
+                __builtin_memcpy(&p1, &Pf[2], 16);
+                __builtin_memcpy(&m0, &s.m[0], 16);
+                *reinterpret_cast<V4*>(sF + ((((unsigned)(2 * i)) ^ fo) << 4)) = p0;         // F_i is dead: P_i takes its place
+                *reinterpret_cast<V4*>(sF + ((((unsigned)(2 * i + 1)) ^ fo) << 4)) = p1;
+                *reinterpret_cast<V4*>(sQ + ((((unsigned)i) ^ fo) << 4)) = m0;               // logical piece i of Q's segment: Q_0 .. Q_i are dead
+            }
+            wave_lds_sync();
+            // drain: P along the road F came by (same permutation), m as 64 contiguous bytes per owner
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const V4 x = *reinterpret_cast<const V4*>(slot + v * 1024 + lane * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(x, rP, (v & 1) ? voff1 : voff0, (unsigned)sb * SEG + (unsigned)v * 8u * pitch, NT ? 2 : 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const unsigned o = 16u * v + ((unsigned)lane >> 2), i = (unsigned)lane & 3;
+                const unsigned f = (o & 7) ^ ((o >> 3) & 1);
+                const V4 x = *reinterpret_cast<const V4*>(slot + ARR + o * SEG + ((i ^ f) << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(x, rM, o * (pitch / 2) + i * 16u, (unsigned)sb * 64u, NT ? 2 : 0);
+            }
+            if (sb + K < S) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read out before the DMA refills it
+                issue(sb + K);
+            }
+        }
+        if (SMOOTH) filter_tail_apply<T, D>(have_next, Fh, Qh, s, sagg);
+    }
+};
+#endif      // PGPS_NARROW
+
+template <typename T, int D, bool SMOOTH, int G, bool NT, bool DMA = false>
 __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     constexpr int MAT = D * D, NF = Dim<D>::NFILT;
     using FE = FiltElem<T, D>;
     using SE = SmthElem<T, D>;
     using MC = MeanCov<T, D>;
     using CFG = StageCfg<T, D, G>;
+#if defined(PGPS_NARROW)
+    using DM = FilterApplyDma<SMOOTH, NT>;
+    constexpr int kStageBytes = DMA ? DM::BYTES : CFG::F3_BYTES;
+#else
+    static_assert(!DMA, "the LDS-DMA ring exists in the 128-lane build only");
+    constexpr int kStageBytes = CFG::F3_BYTES;
+#endif
     __shared__ T lds[kWaves * NF];
     __shared__ double lds_ll[kWaves];
-    __shared__ __attribute__((aligned(16))) char stage[kWaves][CFG::F3_BYTES];
+    __shared__ __attribute__((aligned(16))) char stage[kWaves][kStageBytes];
 
     T h[D];
 #pragma unroll
@@ -829,7 +1175,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
     const long k0 = gt * a.Lc;
     const long k1 = min(a.N, k0 + a.Lc);
-    const int wave = threadIdx.x / kWave;
+    const int wave = DMA ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave)) : (int)(threadIdx.x / kWave);
     const long wbase = ((long)blockIdx.x * kBlock + wave * kWave) * a.Lc;
 
     PGPS_STAMP(1, 0);
@@ -840,7 +1186,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     ws_load(a.lpre, a.nlanes, gt, lp);
     bool staged = false;
     FilterApplyStaged<T, D, SMOOTH, CFG::GG, NT> st;
-    if constexpr (CFG::on) {
+#if defined(PGPS_NARROW)
+    DM dm;
+#endif
+    if constexpr (CFG::on && !DMA) {
         staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
         if (staged) st.prefetch(a, wbase);
     }
@@ -873,6 +1222,30 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
         // keep the next segment's first (F, Q) for the smoother launch of this pass
         a.seg_ws[(D + MAT) + threadIdx.x] = a.halo_FQ[threadIdx.x];
     }
+#if defined(PGPS_NARROW)
+    if constexpr (DMA) {
+        // every load hipcc counts is finished HERE, before the first DMA goes out (see the note above FilterApplyDma);
+        // then the ring fills while the workgroup folds the spine
+        staged = (wbase + (long)kWave * a.Lc <= a.N) && DM::usable(a);
+        dm.have_next = false;
+        if (staged) {
+            const int lane = threadIdx.x & (kWave - 1);
+            if (SMOOTH && lane == kWave - 1) dm.have_next = filter_tail_load<T, D>(a, wbase + (long)kWave * a.Lc, dm.Fh, dm.Qh);
+            pin_values(dm.Fh, MAT);
+            pin_values(dm.Qh, MAT);
+        }
+        if (blockIdx.x > 0) pin_elem(left_part);
+        pin_elem(lp);
+        pin_values(h, D);
+        pin_values(s.m, D);
+        pin_values(s.P, Dim<D>::SYM);
+        if (staged) dm.prefetch(a, wbase, stage[wave]);
+    }
+#endif
+#ifdef PGPS_STAMPS
+    if (blockIdx.x > 0) pin_elem(left_part);            // diagnostic build: when have the spine records arrived?
+    PGPS_STAMP(1, 6);
+#endif
     // ... pushed through the workgroups to the left, then through this lane's local prefix
     if (blockIdx.x > 0) {
         FE left;
@@ -886,7 +1259,12 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     LogLik ll;
     SE sagg;
     smth_identity(sagg);
-    if constexpr (CFG::on) {
+#if defined(PGPS_NARROW)
+    if constexpr (DMA) {
+        if (staged) dm.run(a, wbase, stage[wave], h, s, ll, sagg);
+    }
+#endif
+    if constexpr (CFG::on && !DMA) {
         if (staged) st.run(a, wbase, stage[wave], h, s, ll, sagg);
     }
     if (!staged) lane_filter_apply_direct<T, D, SMOOTH>(a, k0, k1, h, s, ll, sagg);
@@ -1416,6 +1794,10 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
             smth_apply(e, s);
         }
     }
+#ifdef PGPS_STAMPS
+    if ((int)blockIdx.x + 1 < a.nblocks) pin_elem(right_part);
+    PGPS_STAMP(2, 4);
+#endif
     if ((int)blockIdx.x + 1 < a.nblocks) {
         SE right;
         block_reduce_ordered(right_part, right, lds);

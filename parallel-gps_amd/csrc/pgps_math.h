@@ -66,6 +66,32 @@ struct MeanCov {
 template <typename T>
 PGPS_HD bool is_nan(T x) { return x != x; }
 
+// 1 / x.  On the device, for plain float / double: the hardware reciprocal refined by Newton steps (v_rcp_f64 + two
+// steps, v_rcp_f32 + one) instead of the IEEE division sequence (div_scale x 2, rcp, ~8 fma, div_fmas, div_fixup): the
+// operands are innovation variances and 2 x 2 determinants, far from the range limits that sequence exists for, and the
+// result agrees with the quotient to the last bit or the one before it.  Host builds (tests/cpu_math) and dual numbers
+// divide.  -DPGPS_FAST_RCP=0 restores the divisions (A/B: profiles/r03_experiments.txt).
+#ifndef PGPS_FAST_RCP
+#define PGPS_FAST_RCP 1
+#endif
+template <typename T>
+PGPS_HD T recip(T x) { return T(1) / x; }
+#if defined(__HIP_DEVICE_COMPILE__) && PGPS_FAST_RCP
+template <>
+PGPS_HD double recip<double>(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+template <>
+PGPS_HD float recip<float>(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
+#endif
+
 // ------------------------------------------------------------------------------------
 // basic products
 // ------------------------------------------------------------------------------------
@@ -201,13 +227,13 @@ PGPS_HD void predict_cov(const T* F, const T* P, const T* Q, T* FP, T* out) {
 template <typename T, int D, int NR, bool PIVOT>
 PGPS_HD void gj_solve(T* M, T* B) {
     if constexpr (D == 1) {
-        const T inv = T(1) / M[0];
+        const T inv = recip(M[0]);
 #pragma unroll
         for (int j = 0; j < NR; ++j) B[j] *= inv;
         return;
     } else if constexpr (D == 2) {
         const T a = M[0], b = M[1], c = M[2], d = M[3];
-        const T inv = T(1) / (a * d - b * c);
+        const T inv = recip(a * d - b * c);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const T x0 = B[j], x1 = B[NR + j];
@@ -237,7 +263,7 @@ PGPS_HD void gj_solve(T* M, T* B) {
                 }
             }
         }
-        const T inv = T(1) / M[c * D + c];
+        const T inv = recip(M[c * D + c]);
 #pragma unroll
         for (int j = c + 1; j < D; ++j) M[c * D + j] *= inv;
 #pragma unroll
@@ -285,7 +311,7 @@ PGPS_HD void filt_first(FiltElem<T, D>& e, const T* P0 /*sym*/, T y, const T* h,
         T S = R;
 #pragma unroll
         for (int i = 0; i < D; ++i) S += h[i] * u[i];
-        const T inv = T(1) / S;
+        const T inv = recip(S);
 #pragma unroll
         for (int i = 0; i < D; ++i) e.b[i] = u[i] * (y * inv);
 #pragma unroll
@@ -322,7 +348,7 @@ PGPS_HD void filt_extend(FiltElem<T, D>& e, const T* F, const T* Q /*sym*/, T y,
     T S = R, hb = T(0);
 #pragma unroll
     for (int i = 0; i < D; ++i) { S += h[i] * u[i]; hb += h[i] * bp[i]; }
-    const T inv = T(1) / S;
+    const T inv = recip(S);
     const T res = y - hb;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -446,7 +472,7 @@ struct LogLik {
     long long count = 0;    // number of observed steps
 
     PGPS_HD void add(double r, double S) {
-        quad += r * r / S;
+        quad += r * r * recip(S);
         int e;
         mant = std::frexp(mant * S, &e);
         expo += e;
@@ -480,7 +506,7 @@ PGPS_HD void kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, cons
 #pragma unroll
         for (int i = 0; i < D; ++i) { S0 += h[i] * u0[i]; mu0 += h[i] * s.m[i]; }
         if (obs) {
-            const T inv = T(1) / S0;
+            const T inv = recip(S0);
             const T res = y - mu0;
 #pragma unroll
             for (int i = 0; i < D; ++i) s.m[i] += u0[i] * (res * inv);
@@ -492,7 +518,7 @@ PGPS_HD void kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, cons
         return;
     }
     if (obs) {
-        const T inv = T(1) / S;
+        const T inv = recip(S);
         const T res = y - mu;
 #pragma unroll
         for (int i = 0; i < D; ++i) s.m[i] = mp[i] + u[i] * (res * inv);

@@ -49,6 +49,8 @@ def _declare(lib):
     lib.pgps_set_stage.argtypes = [P, c_int]
     lib.pgps_set_family.argtypes = [P, c_int]
     lib.pgps_set_block.argtypes = [P, c_int]
+    if hasattr(lib, "pgps_set_dma"):
+        lib.pgps_set_dma.argtypes = [P, c_int]
     lib.pgps_get_geometry.argtypes = [P, c_long, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_set_single_pass.argtypes = [P, c_int, c_int]
     lib.pgps_get_chunk.argtypes = [P, c_long, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
@@ -65,6 +67,8 @@ def _declare(lib):
     lib.pgps_comm_init.argtypes = [P, P, c_int, c_int]
     lib.pgps_comm_destroy.argtypes = [P]
     lib.pgps_comm_info.argtypes = [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    if hasattr(lib, "pgps_comm_count"):         # (absent from libraries built before round 3: A/B runs load those)
+        lib.pgps_comm_count.argtypes = [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_comm_allgather_dev.argtypes = [P, P, P, ctypes.c_size_t]
     for suf, real in (("f64", c_double), ("f32", c_float)):
         for dev in ("", "_dev"):
@@ -159,6 +163,11 @@ class Context:
     def set_block(self, lanes):
         """Lanes per workgroup of the lane-chunk kernels: 0 = automatic, 128, 256 (pgps_set_block)."""
         check(self, self.lib.pgps_set_block(self.handle, int(lanes)), "pgps_set_block")
+
+    def set_dma(self, mode):
+        """LDS-DMA ring in the Kalman pass (d = 2 fp64, 128-lane build): -1 automatic, 0 off, 1 on (pgps_set_dma)."""
+        if hasattr(self.lib, "pgps_set_dma"):
+            check(self, self.lib.pgps_set_dma(self.handle, int(mode)), "pgps_set_dma")
 
     def get_geometry(self, n, d):
         """(lanes per workgroup, steps per lane, workgroups) of a lane-chunk call of n steps at state dimension d <= 6."""
@@ -258,6 +267,13 @@ class Context:
         r, n = c_int(0), c_int(0)
         check(self, self.lib.pgps_comm_info(self.handle, ctypes.byref(r), ctypes.byref(n)), "pgps_comm_info")
         return r.value, n.value
+
+    def comm_count(self):
+        """(ranks, this rank) as RCCL itself reports them for the context's communicator (ncclCommCount /
+        ncclCommUserRank); (0, 0) without a communicator."""
+        n, r = c_int(0), c_int(0)
+        check(self, self.lib.pgps_comm_count(self.handle, ctypes.byref(n), ctypes.byref(r)), "pgps_comm_count")
+        return n.value, r.value
 
     # -- generic call by name ----------------------------------------------------------------
     def call(self, name, *args):

@@ -4,9 +4,9 @@ GPU, stitched by two tiny all-gathers of segment totals (RCCL over xGMI).
 The product path is `ShardedScan`: the libpgps context owns the RCCL communicator (`pgps_comm_init`) and one call
 per pass (`pgps_pkfs_seg_dev_*`) enqueues reduce -> ncclAllGather -> filter -> ncclAllGather -> smoother on the
 context's stream -- no framework, no host round trip.  Only the 128-byte communicator id has to reach every rank
-once (`share_unique_id`: a file, or any broadcast the launcher offers).  `SegmentScan` is the older framework-hosted
-variant (the same three library phases with torch.distributed's collectives in between), kept for hosts that
-already live inside torch.distributed and for the CPU / gloo tests of the protocol.
+once (`share_unique_id`: a file, or any broadcast the launcher offers).  (The older framework-hosted variant --
+the same three library phases with torch.distributed's collectives in between -- is test / benchmark tooling and
+lives outside the product, in tools/torch_segment_scan.py.)
 
 The reference has no multi-device path; this module is the MI355X
 extension of `pkfs`.  A prefix scan over an associative operator splits into segments whose
@@ -32,12 +32,8 @@ import time
 
 import numpy as np
 
-# NOTE: import this module (or torch) BEFORE the first libpgps context is created: PyTorch-ROCm ships
-# its own HIP runtime and both libraries must share one copy of it in the process.
-try:
-    import torch as _torch  # noqa: F401
-except Exception:  # torch is only needed by SegmentScan
-    _torch = None
+# NOTE for hosts that also use PyTorch-ROCm: import torch BEFORE the first libpgps context is created (it ships its
+# own HIP runtime and both libraries must share one copy of it in the process).  This module itself needs no framework.
 
 
 def record_lengths(d):
@@ -63,36 +59,61 @@ def run_protocol(rank, nranks, phase_reduce, phase_filter, phase_smoother, all_g
     return phase_smoother(gathered_s)
 
 
-def share_unique_id(rank, path=None, broadcast=None, timeout=120.0):
+_UID_MAGIC = b"PGPSUID2"
+
+
+def _run_tag(run_id):
+    """16 bytes that identify one launch: a file left behind by an earlier run at the same path is not this run's."""
+    import hashlib
+    if run_id is None:
+        run_id = "|".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "SLURM_JOB_ID"))
+    return hashlib.sha256(str(run_id).encode()).digest()[:16]
+
+
+def share_unique_id(rank, path=None, broadcast=None, timeout=120.0, run_id=None):
     """The communicator id of rank 0 on every rank.  Either `broadcast(bytes_or_None) -> bytes` (whatever the launcher
     offers: MPI bcast, a torch.distributed / TCP store, ...) or a file all ranks can see (`path`, written atomically
-    by rank 0, polled by the others).  No GPU work."""
+    by rank 0, polled by the others).  The file carries a tag of `run_id` (default: the launcher's rendezvous variables
+    MASTER_ADDR / MASTER_PORT / TORCHELASTIC_RUN_ID / SLURM_JOB_ID), and the other ranks accept only a file with THIS
+    run's tag: an id left at the same path by an earlier run is ignored, not joined.  Rank 0 removes the file with
+    `remove_unique_id_file(path)` once every rank has called pgps_comm_init.  No GPU work."""
     from . import _backend
     uid = _backend.Context.comm_unique_id() if rank == 0 else None
     if broadcast is not None:
         uid = broadcast(uid)
     elif path is not None:
+        tag = _run_tag(run_id)
+        want = len(_UID_MAGIC) + len(tag) + _backend.COMM_ID_BYTES
         if rank == 0:
             tmp = f"{path}.tmp.{os.getpid()}"
             with open(tmp, "wb") as fh:
-                fh.write(uid)
+                fh.write(_UID_MAGIC + tag + uid)
             os.replace(tmp, path)
         else:
             deadline = time.monotonic() + timeout
             while True:
                 try:
                     with open(path, "rb") as fh:
-                        uid = fh.read()
-                    if len(uid) == _backend.COMM_ID_BYTES:
+                        blob = fh.read()
+                    if len(blob) == want and blob.startswith(_UID_MAGIC + tag):
+                        uid = blob[len(_UID_MAGIC) + len(tag):]
                         break
                 except FileNotFoundError:
                     pass
                 if time.monotonic() > deadline:
-                    raise TimeoutError(f"no communicator id at {path} after {timeout} s")
+                    raise TimeoutError(f"no communicator id of this run at {path} after {timeout} s")
                 time.sleep(0.01)
     elif rank != 0:
         raise ValueError("share_unique_id needs `path` or `broadcast` when there is more than one rank")
     return bytes(uid)
+
+
+def remove_unique_id_file(path):
+    """Rank 0, after every rank has joined the communicator: the id file has served its purpose."""
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
 
 
 class ShardedScan:
@@ -114,72 +135,6 @@ class ShardedScan:
 
     def close(self):
         self.ctx.comm_destroy()
-
-
-class SegmentScan:
-    """pkfs for the segment of `rank`; device tensors are torch tensors on `torch_device`.  The collectives are
-    torch.distributed's, so libpgps must launch on the stream they are enqueued on: the constructor binds the
-    context to torch's current stream of `torch_device` (a context's own stream is a private non-blocking one, and
-    nothing would order the kernels that write the records against the all-gathers otherwise)."""
-
-    def __init__(self, ctx, rank, world, d, dtype, torch_device=None, group=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.ctx, self.rank, self.world, self.d = ctx, int(rank), int(world), int(d)
-        self.suf = "f64" if np.dtype(dtype) == np.float64 else "f32"
-        self.real = ctypes.c_double if self.suf == "f64" else ctypes.c_float
-        tdtype = torch.float64 if self.suf == "f64" else torch.float32
-        rf, rs, _ = record_lengths(d)
-        lf, ls = ctypes.c_int(0), ctypes.c_int(0)
-        code = ctx.lib.pgps_seg_record_len(ctypes.c_int(d), ctypes.byref(lf), ctypes.byref(ls))
-        assert code == 0 and (lf.value, ls.value) == (rf, rs), "record layout mismatch with libpgps"
-        self.group = group
-        if torch_device is not None and torch.device(torch_device).type == "cuda":
-            ctx.set_stream(torch.cuda.current_stream(torch_device).cuda_stream)
-        kw = dict(dtype=tdtype, device=torch_device)
-        self.rec_f = torch.zeros(rf, **kw)
-        self.rec_s = torch.zeros(rs, **kw)
-        self.gathered_f = torch.zeros((world, rf), **kw)
-        self.gathered_s = torch.zeros((world, rs), **kw)
-
-    def _gather(self, out, rec):
-        if self.world == 1:
-            out.copy_(rec.view(1, -1))
-        elif self.dist.get_backend(self.group) == "nccl":
-            self.dist.all_gather_into_tensor(out, rec, group=self.group)       # RCCL over xGMI
-        else:
-            # e.g. gloo (tests: several ranks sharing one GPU): list form, staged through the host
-            parts = [self.torch.empty_like(rec) for _ in range(self.world)]
-            self.dist.all_gather(parts, rec, group=self.group)
-            out.copy_(self.torch.stack(parts))
-        return out
-
-    def pkfs(self, n_local, P0, Fs, Qs, H, R, ys, fms, fPs, sms, sPs, ll):
-        """All arguments are device tensors of this rank's segment (ll: float64[>=1])."""
-        P = lambda t: ctypes.c_void_p(t.data_ptr())
-        c, suf = self.ctx, self.suf
-        N, d, r, w = ctypes.c_long(n_local), ctypes.c_int(self.d), ctypes.c_int(self.rank), ctypes.c_int(self.world)
-
-        def phase_reduce():
-            c.call(f"pgps_seg_filter_reduce_dev_{suf}", N, d, r, w, P(P0), P(Fs), P(Qs), P(H), self.real(R), P(ys),
-                   P(self.rec_f))
-            return self.rec_f
-
-        def phase_filter(gathered_f):
-            c.call(f"pgps_seg_filter_apply_dev_{suf}", N, d, r, w, P(P0), P(Fs), P(Qs), P(H), self.real(R), P(ys),
-                   P(gathered_f), P(fms), P(fPs), P(self.rec_s))
-            return self.rec_s
-
-        def phase_smoother(gathered_s):
-            c.call(f"pgps_seg_smoother_apply_dev_{suf}", N, d, r, w, P(Fs), P(Qs), P(fms), P(fPs), P(gathered_s),
-                   P(sms), P(sPs), P(ll))
-            return ll
-
-        gathers = iter((self.gathered_f, self.gathered_s))
-        with c.lock:        # the three phases share the context's scratch: nothing else may use it in between
-            return run_protocol(self.rank, self.world, phase_reduce, phase_filter, phase_smoother,
-                                lambda rec: self._gather(next(gathers), rec))
 
 
 def split_segments(n_total, world):

@@ -78,13 +78,19 @@ def test_one_gpu_line_has_the_contract_fields():
     j = _run(["--log2n", "14", "--steps", "5", "--warmup", "2"])
     assert CONTRACT <= set(j) and "cpu_baseline" in j
     assert j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2 and j["higher_is_better"] is True
+    assert j["scaling"] is None                     # one GPU: neither weak nor strong
     assert j["unit"] == "timesteps/s" and j["dtype"] == "f64" and j["data"] == "synthetic" and j["vs_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
     assert abs(j["value"] - (1 << 14) * 5 / (j["ms_per_step"] * 5e-3)) < 1e-6 * j["value"]
     r = j["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r)
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches_timed"] >= 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches_timed"] == 5                 # a short timed region samples every launch of the dominant kernel
+    for leg in ("filter+smooth+log-lik", "log-lik only"):
+        f = j["fused_path"][leg]
+        assert f["ms_min"] <= f["ms_per_step"] <= f["ms_max"] and f["rounds"] >= 2
+    assert set(j["fused_path"]["geometry"]) == {"lanes_per_workgroup", "steps_per_lane", "workgroups"}
     assert r["vector_fp"]["unit"] == "TFLOP/s"
     c = j["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["cores"] == 1
@@ -99,3 +105,17 @@ def test_two_ranks_dry_run_reports_the_strong_scaling_line():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["steps_total"] == 1 << 15
     assert j["config"]["steps_per_gpu"] == 1 << 14
     assert abs(j["value"] - (1 << 15) * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    # the line checks itself: the same series on one GPU next to it, which exchange ran, how many ranks it saw
+    ss = j["strong_scaling"]
+    assert ss["one_gpu_ms"] > 0 and abs(ss["speedup"] - ss["one_gpu_ms"] / ss["n_gpu_ms"]) < 1e-9
+    assert abs(ss["efficiency"] - ss["speedup"] / 2) < 1e-12
+    assert j["rccl"]["in_library"] is False and j["exchange_fallback"] is False      # --all-on-gpu0 asks for torch / gloo
+
+
+@pytest.mark.gpu
+def test_segments_at_one_gpu_report_the_in_library_communicator():
+    """`--force-segments` at one GPU runs the product's sharded path on a real RCCL communicator of size 1."""
+    j = _run(["--force-segments", "--log2n", "15", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--main-only"])
+    r = j["rccl"]
+    assert r["in_library"] is True and r["ranks"] == 1 and j["exchange_fallback"] is False
+    assert len(r["allgather_us"]) == 2 and all(0 < v < 1e4 for v in r["allgather_us"])

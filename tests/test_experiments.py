@@ -178,7 +178,7 @@ def test_reference_named_enums_and_factories():
     squared-exponential base kernel), model factory (the dense GPflow GPR is not part of this backend)."""
     from pssgp.experiments.common import CovarianceEnum, MCMC, ModelEnum, get_model, get_simple_covariance_function
     from pssgp.kernels import Matern52, Periodic, RBF
-    from pssgp.misc_utils import rmse
+    from pssgp.experiments.toy import rmse
     assert [m.value for m in MCMC] == ["HMC", "MALA", "NUTS"] and [m.value for m in ModelEnum] == ["GP", "SSGP", "PSSGP"]
     assert isinstance(get_simple_covariance_function(CovarianceEnum.Matern52, variance=2., lengthscales=.5), Matern52)
     assert isinstance(get_simple_covariance_function("RBF", variance=1., lengthscales=1., order=4), RBF)
@@ -196,7 +196,7 @@ def test_reference_named_enums_and_factories():
 @pytest.mark.gpu
 def test_factory_models_agree():
     from pssgp.experiments.common import get_model, get_simple_covariance_function
-    from pssgp.toymodels import obs_noise, sinu
+    from pssgp.experiments.toy import obs_noise, sinu
     t = np.sort(np.random.default_rng(4).uniform(0, 1, 300))
     y = obs_noise(sinu(t), 0.1, 4)
     lls = [float(get_model(name, (t[:, None], y[:, None]), 0.1,

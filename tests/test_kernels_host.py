@@ -185,10 +185,10 @@ def test_native_balancing_sweep_equals_the_numpy_loop(monkeypatch):
     assert np.all(np.isnan(out)) and np.all(np.isnan(ref))
 
 
-def test_toymodels_import_path():
-    """The reference's tests import their signals as `from pssgp.toymodels import sinu, obs_noise`
-    (tests/test_gp_vs_kfs.py); the same path works here."""
-    from pssgp.toymodels import comp_sinu, obs_noise, rect, sinu
+def test_toy_signals():
+    """The reference's test signals (pssgp/toymodels/data_funcs.py:10-97; its tests import sinu / obs_noise from there):
+    here they live with the experiment drivers, pssgp/experiments/toy.py."""
+    from pssgp.experiments.toy import comp_sinu, obs_noise, rect, sinu
     t = np.linspace(0.0, 1.0, 11)
     for f in (sinu, comp_sinu, rect):
         assert f(t).shape == t.shape and np.all(np.isfinite(f(t)))

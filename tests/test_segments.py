@@ -261,7 +261,7 @@ def test_segmentscan_world1_with_torch():
     """The torch.distributed driver at world_size 1 (what bench.py runs per rank), on the GPU."""
     torch = pytest.importorskip("torch")
     from pssgp import _backend as B
-    from pssgp.distributed import SegmentScan
+    from tools.torch_segment_scan import SegmentScan
     ssm, y = _problem(n=4000, seed=2)
     d = ssm[1].shape[1]
     dev = torch.device("cuda", 0)
@@ -291,7 +291,8 @@ import torch.distributed as dist
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "parallel-gps_amd"))
 from oracle import np_oracle as O
 from pssgp import _backend as B
-from pssgp.distributed import SegmentScan, split_segments
+from pssgp.distributed import split_segments
+from tools.torch_segment_scan import SegmentScan
 from tests.test_segments import _problem, _slice
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

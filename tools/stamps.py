@@ -11,9 +11,11 @@ from pssgp.kernels import Matern32
 chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 stage = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 single = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 1: single-pass filter kernel (k_filter_single)
+block = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # lanes per workgroup: 0 auto, 128, 256
+dma = int(sys.argv[5]) if len(sys.argv) > 5 else -1        # LDS-DMA ring in the Kalman pass: -1 auto, 0 off, 1 on
 n, d = 1 << 20, 2
 ctx = B.Context(0)
-ctx.set_chunk(chunk); ctx.set_stage(stage)
+ctx.set_chunk(chunk); ctx.set_stage(stage); ctx.set_block(block); ctx.set_dma(dma)
 if single:
     ctx.set_single_pass(1, 256)
 sde = Matern32(1., 1.).get_sde()
@@ -31,7 +33,7 @@ for it in range(5):
     ctx.call("pgps_pkfs_dev_f64", ctypes.c_long(n), ctypes.c_int(d), P(P0), P(F_), P(Q_), P(H), ctypes.c_double(0.1),
              P(Y), P(fms), P(fPs), P(sms), P(sPs), P(ll))
 ctx.synchronize()
-lc, nb = ctx.get_chunk(n)
+lanes, lc, nb = ctx.get_geometry(n, d)
 buf = np.zeros((3, nb, 8), dtype=np.int64)
 nstamps = {0: 4, 1: 6, 2: 4}
 ctx.lib.pgps_debug_read_stamps.argtypes = [P, P, ctypes.c_long]
@@ -39,11 +41,18 @@ B.check(ctx, ctx.lib.pgps_debug_read_stamps(ctx.handle, buf.ctypes.data_as(P), b
 names = {0: ["lane-serial reduce", "block scan", "store lpre/spine"],
          1: ["fold spine (prologue)", "lpre load+apply", "lane-serial KF+smooth-agg", "ll reduce", "suffix scan+store"],
          2: ["fold sspine (prologue)", "lsuf load+apply", "lane-serial RTS"]}
-print(f"chunk {lc}, {nb} workgroups, stage {stage}; s_memtime ticks are 100 MHz-domain? printing raw ticks and share")
+print(f"{lanes} lanes per workgroup, chunk {lc}, {nb} workgroups, stage {stage}; s_memtime ticks are 100 MHz-domain? printing raw ticks and share")
 if single:
     names[1] = ["stream to registers + reduce", "block scan", "publish + wait for left totals", "fold + apply",
                 "Kalman pass from registers + stores", "ll reduce + suffix scan (+ publish)"]
 
+for k, extra in ((1, 6), (2, 4)):
+    arrive = (buf[k][:, extra] - buf[k][:, 0]).astype(np.float64)
+    arrive = arrive[buf[k][:, extra] > 0]
+    if arrive.size:
+        print(f"kernel {k}: spine records in registers {np.median(arrive):.0f} ticks after the workgroup's first stamp (max {arrive.max():.0f})")
+    t0 = buf[k][:, 0].astype(np.float64)
+    print(f"kernel {k}: workgroup start skew: median {np.median(t0 - t0.min()):.0f} ticks, max {(t0 - t0.min()).max():.0f}")
 for k, kn in enumerate(["k_filter_reduce", "k_filter_apply", "k_smoother_apply"]):
     st = buf[k]
     nph = len(names[k])
