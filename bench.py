@@ -68,7 +68,10 @@ def parse():
     ap.add_argument("--kernel", default="matern32",
                     choices=["matern32", "matern52", "matern12", "c5", "periodic10"] + [f"rbf{n}" for n in range(2, 33)],
                     help="rbfN = RBF of order N (state dimension N)")
-    ap.add_argument("--family", type=int, default=0, help="0 auto, 1 lane-chunk, 2 wave-cooperative kernels")
+    ap.add_argument("--family", type=int, default=0,
+                    help="0 auto, 1 lane-chunk, 2 wave-cooperative, 3 row-cooperative, 4 quad-cooperative (fp32, d = 5..8) kernels")
+    ap.add_argument("--rc-scan", type=int, default=-1, choices=[-1, 0, 1],
+                    help="scans of the chain totals (families 3, 4): -1 auto, 0 one launch per Kogge-Stone level, 1 blocked")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--block", type=int, default=0, choices=[0, 128, 256],
                     help="lanes per workgroup of the lane-chunk kernels: 0 = library default (pgps_set_block)")
@@ -172,6 +175,11 @@ def dominant_symbol(slot, d, suf, family, segments, n_local):
     wc_names = {"k_filter_reduce": "pgps::wc::wc_reduce1/2 + wc_ks_filter levels", "k_filter_apply": "pgps::wc::wc_apply1",
                 "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels", "k_smoother_apply": "pgps::wc::wc_smooth1"}
     t = "double" if suf == "f64" else "float"
+    if family == 4 and suf == "f32" and 5 <= d <= 8:
+        return {"k_filter_reduce": f"pgps::qc::q_reduce1<{d}> + the scan of the chain totals (rc_scan_blk_f / rc_ks_filter<float, {d}>)",
+                "k_filter_apply": f"pgps::qc::q_apply1<{d}, ...>",
+                "k_smoother_reduce": f"the scan of the smoothing totals (rc_scan_blk_s / rc_ks_smoother<float, {d}>)",
+                "k_smoother_apply": f"pgps::qc::q_smooth1<{d}>"}[slot]
     rc_auto = (d > 6) if (segments or suf == "f32") else (d >= 5)
     if 2 <= d <= 16 and (family == 3 or (family == 0 and rc_auto)):
         return rc_names[slot].format(t=t, d=d)
@@ -393,6 +401,7 @@ def main():
     ctx.set_family(args.family)
     ctx.set_block(args.block)
     ctx.set_dma(args.dma)
+    ctx.set_rc_scan(args.rc_scan)
     ctx.set_single_pass(args.single_pass, 0)
 
     def dev_from(a):

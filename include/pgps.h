@@ -68,7 +68,8 @@ int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
 /* Kernel family: 0 = automatic (lane-chunk for d <= 4 and for fp32 up to PGPS_MAX_DIM_LANE; row-cooperative for
  * fp64 with 5 <= d <= 16 and fp32 with 7 <= d <= 16, segments use it above d = 6; wave-cooperative otherwise,
  * d <= 32),
- * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64 and fp32, 2 <= d <= 16). */
+ * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64 and fp32, 2 <= d <= 16),
+ * 4 = quad-cooperative level-1 kernels under the row-cooperative driver (fp32 only, 5 <= d <= 8; pkf / pkfs / segments). */
 int pgps_set_family(pgps_ctx* ctx, int family);
 /* Lanes per workgroup of the lane-chunk kernels (d <= PGPS_MAX_DIM_LANE): 0 = automatic (128 -- half the scan tree per
  * step at the same number of workgroups -- except d <= 3 from 2^22 steps of this call / this rank's segment), 128, 256.
@@ -80,6 +81,13 @@ int pgps_set_block(pgps_ctx* ctx, int lanes);
  * -1 = automatic (= off: measured slower at 2^20 steps, profiles/r03_experiments.txt), 0 = off, 1 = on (the ring takes
  * 128 KiB of LDS: one workgroup per CU). */
 int pgps_set_dma(pgps_ctx* ctx, int mode);
+/* Scans over the chain totals of the row- and quad-cooperative families: -1 = automatic (blocked from 64 chains: log2(B)
+ * levels per launch through LDS, B <= 64 records per workgroup), 0 = one launch per Kogge-Stone level, 1 = blocked. */
+int pgps_set_rc_scan(pgps_ctx* ctx, int mode);
+/* Fused (pgps_gp_*) calls of short series -- the reference's own lengths, N = 200 .. 10^4 per evaluation
+ * (pssgp/experiments/toy_models/mcmc.py:55) -- run as ONE workgroup in ONE launch (reduce, scan, Kalman pass, smoother,
+ * projection) up to max_steps steps: -1 = automatic (8192), 0 = never, n > 0 = up to n steps. */
+int pgps_set_one_launch(pgps_ctx* ctx, int max_steps);
 /* What a lane-chunk call (or one rank's segment) of N steps at state dimension d <= PGPS_MAX_DIM_LANE runs with: lanes per
  * workgroup (128 / 256), steps per lane, workgroups -- after pgps_set_block / pgps_set_chunk. */
 int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* steps_per_lane, int* workgroups);
@@ -372,6 +380,26 @@ int pgps_seq_ks_f32(long N, int d, const float* Fs, const float* ms, const float
 /* ---- host helper: the balancing sweep of balance_ss (pssgp/kernels/math_utils.py:10-29, numba in the reference) ----
  * scale[d] = accumulated diagonal scaling after n_iter sweeps over F (d,d).  Host pointers, no context. */
 int pgps_host_balance_f64(int d, const double* F, int n_iter, double* scale);
+
+/* ---- a series kept on the device across calls (round 3) ------------------------------------------------------------
+ * What the reference's drivers do thousands of times per run is evaluate ONE (ts, ys) at changing hyper-parameters
+ * (StateSpaceGP.maximum_log_likelihood_objective / training_loss under L-BFGS and HMC: pssgp/model.py:113-117 called from
+ * pssgp/experiments/sunspot/map.py:74-82, experiments/common.py:95-133) and predict on a fixed grid (predict_f,
+ * pssgp/model.py:92-111 from toy_models/speed_and_stability.py:73-87).  A pgps_series holds ts, ys -- and the query grid
+ * merged with them by _merge_sorted's rule (pssgp/model.py:15-55) -- on the device, so a call moves the model's scalars
+ * in and the results out, nothing else.  fp64; the fused (Matern-family, d <= 3) model of pgps_gp_*: F = -lam I + N1,
+ * N2 = N1^2 / 2, Pinf, H, R.  The handle belongs to its context (one in-flight call per context); destroy it before it. */
+typedef struct pgps_series pgps_series;
+int pgps_series_create_f64(pgps_ctx* ctx, long N, const double* ts, const double* ys, double t0, pgps_series** out);
+int pgps_series_set_queries_f64(pgps_series* s, long K, const double* tq);     /* sorted query times; K = 0 drops them */
+int pgps_series_info(pgps_series* s, long* N, long* K);
+int pgps_series_destroy(pgps_series* s);
+/* results are on the HOST when these return (they synchronise the context's stream) */
+int pgps_series_gp_ll_f64(pgps_series* s, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                          const double* H, double R, double* ll);
+int pgps_series_gp_ll_grad_f64(pgps_series* s, int d, int np, const double* model, double* out /* 1 + np */);
+int pgps_series_gp_predict_f64(pgps_series* s, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                               const double* H, double R, double* mean /* K */, double* var /* K */, double* ll /* or NULL */);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,7 @@ extern "C" int pgps_create(int device, pgps_ctx** out) {
         return PGPS_E_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->n_cu = 0;
     if (const char* e = std::getenv("PGPS_WC_SERIAL3")) ctx->wc_serial3 = (e[0] == '1');      // diagnostic, see pgps_wc.hip
     if (hipMalloc((void**)&ctx->status_word, 256) != hipSuccess || hipMemset(ctx->status_word, 0, 256) != hipSuccess) {
         (void)hipStreamDestroy(ctx->own_stream);
@@ -153,13 +154,25 @@ extern "C" int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window) {
 }
 
 extern "C" int pgps_set_family(pgps_ctx* ctx, int family) {
-    if (!ctx || family < 0 || family > 3) return PGPS_E_INVALID;
+    if (!ctx || family < 0 || family > 4) return PGPS_E_INVALID;
     ctx->family = family;
     return PGPS_OK;
 }
 extern "C" int pgps_set_block(pgps_ctx* ctx, int lanes) {
     if (!ctx || (lanes != 0 && lanes != kBlockNarrow && lanes != 256)) return PGPS_E_INVALID;
     ctx->block = lanes;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_set_one_launch(pgps_ctx* ctx, int max_steps) {
+    if (!ctx || max_steps < -1 || max_steps > (1 << 16)) return PGPS_E_INVALID;
+    ctx->one_launch = max_steps;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_set_rc_scan(pgps_ctx* ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 1) return PGPS_E_INVALID;
+    ctx->rc_scan = mode;
     return PGPS_OK;
 }
 
@@ -403,6 +416,11 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
         // above the lane-chunk kernels' range (at d = 6 those still win in fp32: 0.71 against 0.85 ms at 2^20 steps)
         const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
         if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE))) return launch_scan_rc<float>(ctx, a, d, mode);
+        // quad-cooperative level-1 kernels under the row-cooperative driver: family 4 (fp32, 5 <= d <= 8)
+        if (ctx->family == 4) {
+            if (d < qc::kDimMin || d > qc::kDimMax || mode == MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;
+            return launch_scan_rc<float>(ctx, a, d, mode);
+        }
     }
     if constexpr (sizeof(T) == 8) {
         // row-cooperative family: fp64, d <= 16, whole-series filter / filter+smoother
@@ -720,12 +738,12 @@ static int seg_common(pgps_ctx* ctx, long N, int d, int rank, int nranks, ScanAr
 static bool seg_follows(const pgps_ctx* ctx, int phase, long N, int d, int rank, int nranks) {
     const auto& t = ctx->seg_tag;
     return t.phase == phase - 1 && t.N == N && t.d == d && t.rank == rank && t.nranks == nranks && t.chunk == ctx->chunk && t.block == ctx->block &&
-           t.family == ctx->family && t.stage_g == ctx->stage_g && t.dma == ctx->dma && t.epoch == ctx->ws_epoch;
+           t.family == ctx->family && t.stage_g == ctx->stage_g && t.dma == ctx->dma && t.rc_scan == ctx->rc_scan && t.epoch == ctx->ws_epoch;
 }
 static void seg_mark(pgps_ctx* ctx, int phase, long N, int d, int rank, int nranks) {
     ctx->seg_tag.phase = phase; ctx->seg_tag.N = N; ctx->seg_tag.d = d; ctx->seg_tag.rank = rank;
     ctx->seg_tag.nranks = nranks; ctx->seg_tag.chunk = ctx->chunk; ctx->seg_tag.block = ctx->block; ctx->seg_tag.family = ctx->family;
-    ctx->seg_tag.stage_g = ctx->stage_g; ctx->seg_tag.dma = ctx->dma; ctx->seg_tag.epoch = ctx->ws_epoch;
+    ctx->seg_tag.stage_g = ctx->stage_g; ctx->seg_tag.dma = ctx->dma; ctx->seg_tag.rc_scan = ctx->rc_scan; ctx->seg_tag.epoch = ctx->ws_epoch;
 }
 
 template <typename T>
@@ -1117,6 +1135,173 @@ static int gp_predict_host(pgps_ctx* ctx, long N, long K, int d, double lam, con
 
 PGPS_DEFINE_PREDICT(f64, double)
 PGPS_DEFINE_PREDICT(f32, float)
+
+// ---------------------------------------------------------------------------------------------
+// A series kept on the device across calls (round 3).  The reference's drivers evaluate the SAME (ts, ys) thousands of
+// times with changing hyper-parameters (L-BFGS: pssgp/experiments/sunspot/map.py:74-82; HMC: experiments/common.py:95-133;
+// the speed mesh calls predict_f on fixed grids: toy_models/speed_and_stability.py:73-87): with the host entry points every
+// call copied ts and ys to the device again, merged the query grid again and waited for three or four staged copies.
+// A pgps_series holds ts, ys (and, once set, the query grid MERGED with them: times, observations with NaN at the query
+// rows, query slots) on the device, so that a call sends the model's few scalars and brings back the log-likelihood
+// (+ gradient, or the K means and variances) through a pinned buffer: one short launch set and one copy per call.
+// fp64, the fused (Matern-family, d <= 3) entry points.
+// ---------------------------------------------------------------------------------------------
+struct pgps_series {
+    pgps_ctx* ctx = nullptr;
+    long N = 0, K = 0;
+    double t0 = 0.0;
+    double *ts = nullptr, *ys = nullptr, *tq = nullptr;
+    double *ts_m = nullptr, *ys_m = nullptr, *fms = nullptr, *fPs = nullptr, *pm = nullptr, *pv = nullptr, *res = nullptr;
+    int* qslot = nullptr;
+    double* host = nullptr;             // pinned: 2 K + 32 doubles
+    size_t host_cap = 0;
+};
+
+static void series_free_queries(pgps_series* s) {
+    for (void* p : {(void*)s->tq, (void*)s->ts_m, (void*)s->ys_m, (void*)s->fms, (void*)s->fPs, (void*)s->pm, (void*)s->pv, (void*)s->qslot})
+        if (p) (void)hipFree(p);
+    s->tq = s->ts_m = s->ys_m = s->fms = s->fPs = s->pm = s->pv = nullptr;
+    s->qslot = nullptr;
+    s->K = 0;
+}
+static int series_host(pgps_series* s, size_t doubles) {
+    if (s->host_cap >= doubles) return PGPS_OK;
+    if (s->host) (void)hipHostFree(s->host);
+    s->host = nullptr; s->host_cap = 0;
+    if (hipHostMalloc((void**)&s->host, doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) return PGPS_E_NOMEM;
+    s->host_cap = doubles;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_series_destroy(pgps_series* s) {
+    if (!s) return PGPS_OK;
+    if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
+    series_free_queries(s);
+    if (s->ts) (void)hipFree(s->ts);
+    if (s->ys) (void)hipFree(s->ys);
+    if (s->res) (void)hipFree(s->res);
+    if (s->host) (void)hipHostFree(s->host);
+    delete s;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_series_create_f64(pgps_ctx* ctx, long N, const double* ts, const double* ys, double t0, pgps_series** out) {
+    if (!ctx || N < 1 || !ts || !ys || !out) return PGPS_E_INVALID;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pgps_series* s = new (std::nothrow) pgps_series();
+    if (!s) return PGPS_E_NOMEM;
+    s->ctx = ctx; s->N = N; s->t0 = t0;
+    const size_t nb = (size_t)N * sizeof(double);
+    if (hipMalloc((void**)&s->ts, nb) != hipSuccess || hipMalloc((void**)&s->ys, nb) != hipSuccess ||
+        hipMalloc((void**)&s->res, 64 * sizeof(double)) != hipSuccess || series_host(s, 64) != PGPS_OK) {
+        pgps_series_destroy(s);
+        return PGPS_E_NOMEM;
+    }
+    if (hipMemcpyAsync(s->ts, ts, nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(s->ys, ys, nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        pgps_series_destroy(s);
+        return PGPS_E_HIP;
+    }
+    *out = s;
+    return PGPS_OK;
+}
+
+// the query grid of predict_f: merged with the training series on the device ONCE (pssgp/model.py:15-55 tie rule)
+extern "C" int pgps_series_set_queries_f64(pgps_series* s, long K, const double* tq) {
+    if (!s || K < 0 || (K > 0 && !tq)) return PGPS_E_INVALID;
+    pgps_ctx* ctx = s->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    series_free_queries(s);
+    if (K == 0) return PGPS_OK;
+    if (s->N + K > 0x7fffffffL) return PGPS_E_INVALID;
+    const size_t m = (size_t)(s->N + K);
+    if (hipMalloc((void**)&s->tq, (size_t)K * 8) != hipSuccess || hipMalloc((void**)&s->ts_m, m * 8) != hipSuccess ||
+        hipMalloc((void**)&s->ys_m, m * 8) != hipSuccess || hipMalloc((void**)&s->qslot, m * 4) != hipSuccess ||
+        hipMalloc((void**)&s->fms, m * 3 * 8) != hipSuccess || hipMalloc((void**)&s->fPs, m * 9 * 8) != hipSuccess ||
+        hipMalloc((void**)&s->pm, (size_t)K * 8) != hipSuccess || hipMalloc((void**)&s->pv, (size_t)K * 8) != hipSuccess ||
+        series_host(s, 2 * (size_t)K + 64) != PGPS_OK) {
+        series_free_queries(s);
+        return PGPS_E_NOMEM;
+    }
+    s->K = K;
+    HIPCHK(ctx, hipMemcpyAsync(s->tq, tq, (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream));
+    TRY(pgps::launch_merge<double>(ctx, s->N, K, s->ts, s->ys, s->tq, s->ts_m, s->ys_m, s->qslot));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGPS_OK;
+}
+
+extern "C" int pgps_series_info(pgps_series* s, long* N, long* K) {
+    if (!s || !N || !K) return PGPS_E_INVALID;
+    *N = s->N; *K = s->K;
+    return PGPS_OK;
+}
+
+// log-likelihood of the fused model on the resident series; ll on the host when the call returns
+extern "C" int pgps_series_gp_ll_f64(pgps_series* s, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                                     const double* H, double R, double* ll) {
+    if (!s || !ll) return PGPS_E_INVALID;
+    pgps_ctx* ctx = s->ctx;
+    TRY(gp_dev<double>(ctx, s->N, d, lam, N1, N2, Pinf, H, R, s->ts, s->t0, s->ys, nullptr, nullptr, nullptr, nullptr, s->res));
+    HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *ll = s->host[0];
+    return std::isfinite(*ll) ? PGPS_OK : PGPS_E_NUMERIC;
+}
+
+// log-likelihood and its gradient (forward-mode duals, pgps_gp_ll_grad_*): out = [ll, d ll / d theta_1 .. np] on the host
+extern "C" int pgps_series_gp_ll_grad_f64(pgps_series* s, int d, int np, const double* model, double* out) {
+    if (!s || !model || !out || np < 1 || np > 16) return PGPS_E_INVALID;
+    pgps_ctx* ctx = s->ctx;
+    TRY(launch_grad(ctx, s->N, d, np, model, s->ts, s->t0, s->ys, s->res));
+    HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, (size_t)(1 + np) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i <= np; ++i) out[i] = s->host[i];
+    return std::isfinite(out[0]) ? PGPS_OK : PGPS_E_NUMERIC;
+}
+
+// predict_f at the query grid set by pgps_series_set_queries_f64: K means and variances (and the log-likelihood of the
+// training series: the query rows are missing observations and contribute nothing) on the host when the call returns
+extern "C" int pgps_series_gp_predict_f64(pgps_series* s, int d, double lam, const double* N1, const double* N2,
+                                          const double* Pinf, const double* H, double R, double* mean, double* var, double* ll) {
+    if (!s || s->K < 1 || !mean || !var || !N1 || !Pinf || !H) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    pgps_ctx* ctx = s->ctx;
+    RoctxRange range_("parallel_filter");
+    GpArgs<double> g{};
+    g.s.N = s->N + s->K;
+    g.s.R = R;
+    g.s.ys = s->ys_m;
+    g.s.fms = s->fms; g.s.fPs = s->fPs; g.s.sms = nullptr; g.s.sPs = nullptr;
+    g.s.ll = s->res;
+    g.m.lam = lam;
+    for (int i = 0; i < 9; ++i) { g.m.N1[i] = 0; g.m.N2[i] = 0; g.m.Pinf[i] = 0; }
+    for (int i = 0; i < d * d; ++i) { g.m.N1[i] = N1[i]; g.m.N2[i] = N2 ? N2[i] : 0.0; g.m.Pinf[i] = Pinf[i]; }
+    for (int i = 0; i < 3; ++i) g.m.H[i] = i < d ? H[i] : 0.0;
+    g.m.ts = s->ts_m;
+    g.m.t_prev = s->t0;
+    g.qslot = s->qslot;
+    g.pmean = s->pm;
+    g.pvar = s->pv;
+    int rc;
+    switch (d) {
+        case 1: rc = launch_gp<double, 1>(ctx, g, 1, 1); break;
+        case 2: rc = launch_gp<double, 2>(ctx, g, 1, 1); break;
+        default: rc = launch_gp<double, 3>(ctx, g, 1, 1); break;
+    }
+    if (rc) return rc;
+    const size_t K = (size_t)s->K;
+    HIPCHK(ctx, hipMemcpyAsync(s->host, s->pm, K * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(s->host + K, s->pv, K * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(s->host + 2 * K, s->res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(mean, s->host, K * 8);
+    std::memcpy(var, s->host + K, K * 8);
+    if (ll) *ll = s->host[2 * K];
+    return std::isfinite(s->host[2 * K]) ? PGPS_OK : PGPS_E_NUMERIC;
+}
 
 // ---------------------------------------------------------------------------------------------
 // general LTI models on the device (fp64, 2 <= d <= 16): _get_ssm -> pkf / pkfs for any kernel, with

@@ -64,12 +64,23 @@ __device__ __forceinline__ void gp_prior(const GpModel<T>& m, T* h, T* P0 /*sym*
 // ---------------------------------------------------------------------------------------------
 // reduce
 // ---------------------------------------------------------------------------------------------
+// LDS of the fused kernels: declared once per kernel and handed to the bodies, so that the one-launch kernel (below), which
+// runs the three bodies one after the other, pays for the largest of them and not for their sum
 template <typename T, int D>
-__device__ __forceinline__ void gp_reduce_body(const GpArgs<T>& g) {
+struct GpLds {
+    static constexpr int G = 4;
+    using GF = StageGeom<D * D * (int)sizeof(T), G>;
+    using GM = StageGeom<D * (int)sizeof(T), G>;
+    T lds[kWaves * Dim<D>::NFILT];
+    double lds_ll[kWaves];
+    __attribute__((aligned(16))) char stage[kWaves][GF::BYTES + GM::BYTES];
+};
+
+template <typename T, int D>
+__device__ __forceinline__ void gp_reduce_body(const GpArgs<T>& g, T* lds) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM;
     using FE = FiltElem<T, D>;
     const ScanArgs<T>& a = g.s;
-    __shared__ T lds[kWaves * Dim<D>::NFILT];
     T h[D], P0[SYM];
     gp_prior<T, D>(g.m, h, P0);
     const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -102,14 +113,15 @@ __device__ __forceinline__ void gp_reduce_body(const GpArgs<T>& g) {
 
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock) void k_gp_reduce(const GpArgs<T> g) {
-    gp_reduce_body<T, D>(g);
+    __shared__ T lds[kWaves * Dim<D>::NFILT];
+    gp_reduce_body<T, D>(g, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
 // apply (+ log-likelihood, + smoothing aggregates when SMOOTH); fms / fPs are written when non-null
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D, bool SMOOTH, bool NT>
-__device__ __forceinline__ void gp_apply_body(const GpArgs<T>& g) {
+__device__ __forceinline__ void gp_apply_body(const GpArgs<T>& g, GpLds<T, D>& sh) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT, G = 4;
     using FE = FiltElem<T, D>;
     using SE = SmthElem<T, D>;
@@ -117,9 +129,10 @@ __device__ __forceinline__ void gp_apply_body(const GpArgs<T>& g) {
     using GF = StageGeom<MAT * (int)sizeof(T), G>;
     using GM = StageGeom<D * (int)sizeof(T), G>;
     const ScanArgs<T>& a = g.s;
-    __shared__ T lds[kWaves * NF];
-    __shared__ double lds_ll[kWaves];
-    __shared__ __attribute__((aligned(16))) char stage[kWaves][GF::BYTES + GM::BYTES];
+    T* lds = sh.lds;
+    double* lds_ll = sh.lds_ll;
+    auto& stage = sh.stage;
+    (void)NF;
 
     T h[D];
     MC s;
@@ -212,7 +225,8 @@ __device__ __forceinline__ void gp_apply_body(const GpArgs<T>& g) {
 
 template <typename T, int D, bool SMOOTH, bool NT>
 __global__ __launch_bounds__(kBlock) void k_gp_apply(const GpArgs<T> g) {
-    gp_apply_body<T, D, SMOOTH, NT>(g);
+    __shared__ GpLds<T, D> sh;
+    gp_apply_body<T, D, SMOOTH, NT>(g, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,13 +260,15 @@ __device__ __forceinline__ GpArgs<T> gp_batch_select(const GpBatchArgs<T>& b) {
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock) void k_gpb_reduce(const GpBatchArgs<T> b) {
     const GpArgs<T> g = gp_batch_select<T, D>(b);
-    gp_reduce_body<T, D>(g);
+    __shared__ T lds[kWaves * Dim<D>::NFILT];
+    gp_reduce_body<T, D>(g, lds);
 }
 
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock) void k_gpb_apply(const GpBatchArgs<T> b) {
     const GpArgs<T> g = gp_batch_select<T, D>(b);
-    gp_apply_body<T, D, false, false>(g);
+    __shared__ GpLds<T, D> sh;
+    gp_apply_body<T, D, false, false>(g, sh);
 }
 
 // one workgroup per model: ll[m] = sum of its block partials
@@ -269,16 +285,17 @@ static __global__ __launch_bounds__(kBlock) void k_gpb_finalize(const double* ll
 // smoother apply
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D, bool NT, bool PROJ = false>
-__global__ __launch_bounds__(kBlock) void k_gp_smooth(const GpArgs<T> g) {
+__device__ __forceinline__ void gp_smooth_body(const GpArgs<T>& g, GpLds<T, D>& sh) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM, NS = Dim<D>::NSMTH, G = 4;
     using SE = SmthElem<T, D>;
     using MC = MeanCov<T, D>;
     using GF = StageGeom<MAT * (int)sizeof(T), G>;
     using GM = StageGeom<D * (int)sizeof(T), G>;
     const ScanArgs<T>& a = g.s;
-    __shared__ T lds[kWaves * NS];
-    __shared__ double lds_ll[kWaves];
-    __shared__ __attribute__((aligned(16))) char stage[kWaves][GF::BYTES + GM::BYTES];
+    T* lds = sh.lds;                    // (NFILT >= NSMTH scalars per wave)
+    double* lds_ll = sh.lds_ll;
+    auto& stage = sh.stage;
+    (void)NS;
 
     const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
     const long k0 = gt * a.Lc;
@@ -386,6 +403,37 @@ __global__ __launch_bounds__(kBlock) void k_gp_smooth(const GpArgs<T> g) {
         for (int b = threadIdx.x; b < a.nblocks; b += kBlock) v += a.llpart[b];
         const double t = block_sum_double(v, lds_ll);
         if (threadIdx.x == 0) *a.ll = t;
+    }
+}
+
+template <typename T, int D, bool NT, bool PROJ = false>
+__global__ __launch_bounds__(kBlock) void k_gp_smooth(const GpArgs<T> g) {
+    __shared__ GpLds<T, D> sh;
+    gp_smooth_body<T, D, NT, PROJ>(g, sh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONE launch for a short series (round 3): the reference's own lengths are N = 200 .. 10^4 per call
+// (pssgp/experiments/toy_models/mcmc.py:55, speed_and_stability.py:73), where three dependent launches of a few
+// workgroups each cost more in launch gaps than in work.  A single workgroup runs the three bodies above one after
+// the other -- its lanes own up to kOneLaunchSteps consecutive steps each, nblocks = 1, so there is no spine to fold and
+// the "inter-workgroup" scratch (lpre, lsuf, the filtered moments) is written and read back by the same CU behind a
+// workgroup barrier.  SMOOTH: 0 = log-likelihood (and filtered moments when asked for), 1 = + smoother, 2 = + smoother
+// in projection mode (predict_f).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int SMOOTH>
+__global__ __launch_bounds__(kBlock) void k_gp_one(const GpArgs<T> g) {
+    __shared__ GpLds<T, D> sh;
+    gp_reduce_body<T, D>(g, sh.lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gp_apply_body<T, D, SMOOTH != 0, false>(g, sh);
+    if constexpr (SMOOTH != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        gp_smooth_body<T, D, false, SMOOTH == 2>(g, sh);
+    } else {
+        if (threadIdx.x == 0 && g.s.ll != nullptr) *g.s.ll = g.s.llpart[0];      // (this lane wrote the partial)
     }
 }
 

@@ -29,6 +29,11 @@
 #error "compile with -DPGPS_INST_T=<float|double> -DPGPS_INST_D=<d>"
 #endif
 
+// single-pass filter where the grid fits the chip: automatic choice (A/B: profiles/r03_experiments.txt)
+#ifndef PGPS_SINGLE_PASS_AUTO
+#define PGPS_SINGLE_PASS_AUTO false
+#endif
+
 namespace pgps {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -44,7 +49,7 @@ static int carve_workspace(pgps_ctx* ctx, ScanArgs<T>& a) {
     const size_t o_ll = off;     off = align_up(off + nb * sizeof(double), 256);
     const size_t o_status = off; off = align_up(off + 16, 256);
     const size_t o_seg = off;    off = align_up(off + (2 * (size_t)(D + D * D) + 2 * D * D) * sizeof(T), 256);
-    const size_t o_flags = off;  off = align_up(off + (nb + 4) * sizeof(int), 256);       // ticket + flags
+    const size_t o_flags = off;  off = align_up(off + (nb + 4 + 8 * 32) * sizeof(int), 256);       // (ticket +) the single-pass barrier's counter shards
     const size_t o_incl = off;   off = align_up(off + nb * Dim<D>::NMP * sizeof(T), 256);
     int rc = ensure(ctx, ctx->ws, off);
     if (rc) return rc;
@@ -136,14 +141,14 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         return PGPS_OK;
     }
     if constexpr (G == 4 && D <= 2) {
-        // single-pass filter: whole series on this GPU, 16 steps per lane (they live in registers).
-        // Off by default: measured 55 us against 52 us for reduce + apply at N = 2^20 (with one wave per
-        // SIMD the memory-bound phase A and the compute-bound phase B of a workgroup do not overlap,
-        // and 128 fp64 of chunk data spill to AGPRs); it is kept as a tested option.
-        const bool want = ctx->single_pass < 0 ? false : ctx->single_pass != 0;
-        if (want && (mode == MODE_PKF || mode == MODE_PKFS) && a.Lc == 16) {
-            a.win = ctx->lookback_window < 1 ? 1 : (ctx->lookback_window > kBlock ? kBlock : ctx->lookback_window);
-            HIPCHK(ctx, hipMemsetAsync(a.ticket, 0, ((size_t)a.nblocks + 4) * sizeof(int), s));
+        // single-pass filter: whole series on this GPU, 16 steps per lane (they live in registers), one grid barrier
+        // inside -- so every workgroup must be resident: one wave per SIMD (the chunk's registers allow no more), i.e.
+        // workgroups x waves <= 4 x CUs.  Automatic where that holds (pgps_set_single_pass(ctx, 0) turns it off).
+        const bool fits = (long)a.nblocks * kWaves <= 4L * ctx->n_cu && a.Lc == 16;
+        const bool want = ctx->single_pass < 0 ? PGPS_SINGLE_PASS_AUTO : ctx->single_pass != 0;
+        if (want && fits && (mode == MODE_PKF || mode == MODE_PKFS)) {
+            a.win = 0;
+            HIPCHK(ctx, hipMemsetAsync(a.flags, 0, 8 * 32 * sizeof(int), s));        // the barrier's 8 counter shards
             if (mode == MODE_PKFS) {
                 timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_single<T, D, true, 16, NT>, grid, block, 0, a);
             } else {
@@ -259,11 +264,28 @@ int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed) 
         HIPCHK(ctx, hipSetDevice(ctx->device));
         ScanArgs<T>& a = g.s;
         geometry(ctx, a.N, &a.Lc, &a.nblocks);
+        // a short series: ONE workgroup, ONE launch (k_gp_one) instead of three launches of a few workgroups
+        const bool one = ctx->one_launch != 0 && ctx->chunk <= 0 &&
+                         a.N <= (ctx->one_launch > 0 ? (long)ctx->one_launch : (long)kOneLaunchAuto);
+        if (one) {
+            long v = (a.N + kBlock - 1) / kBlock;
+            v = (v + 3) / 4 * 4;
+            a.Lc = (int)v;
+            a.nblocks = 1;
+        }
         a.nlanes = (long)a.nblocks * kBlock;
         a.seg_first = 1;
         a.seg_last = 1;
         int rc = carve_workspace<T, D>(ctx, a);
         if (rc) return rc;
+        if (one) {
+            const dim3 grid1(1), block1(kBlock);
+            if (!want_smoothed) timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_one<T, D, 0>, grid1, block1, 0, g);
+            else if (g.qslot) timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_one<T, D, 2>, grid1, block1, 0, g);
+            else timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_one<T, D, 1>, grid1, block1, 0, g);
+            HIPCHK(ctx, hipGetLastError());
+            return PGPS_OK;
+        }
         // bytes one pass moves: t, y in; (d^2 + d) filtered out and back in, (d^2 + d) smoothed out
         const double pass = (double)a.N * (2 + 3 * (D * D + D)) * sizeof(T);
         if (pass > 512.0 * 1024 * 1024) return launch_gp_nt<T, D, true>(ctx, g, want_filtered, want_smoothed);

@@ -18,6 +18,7 @@ struct DevBuf {
 
 struct pgps_ctx {
     int device = 0;
+    int n_cu = 0;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int chunk = 0;                      // 0 = auto
@@ -25,6 +26,8 @@ struct pgps_ctx {
     int single_pass = -1;               // single-pass filter kernel: -1 = auto, 0 = off, 1 = on
     int lookback_window = 256;          // tiles per look-back window (<= 256; small values are for tests)
     int block = 0;                      // lane-chunk workgroups: 0 = auto, 128 / 256 lanes (pgps_set_block)
+    int one_launch = -1;                // fused (pgps_gp_*) calls of short series in ONE launch: -1 = auto (N <= kOneLaunchAuto), 0 = never, n > 0 = up to n steps
+    int rc_scan = -1;                   // scans of the chain totals (row- / quad-cooperative families): -1 = auto, 0 = one launch per Kogge-Stone level, 1 = blocked (pgps_set_rc_scan)
     int dma = -1;                       // LDS-DMA ring in the Kalman pass (d = 2 fp64, 128-lane build): -1 = auto, 0 = off, 1 = on
     int family = 0;                     // 0 = auto (lane-chunk d <= 6; row-cooperative fp64 d <= 16; else wave-cooperative), 1 = lane, 2 = wave, 3 = row
     std::string hip_err;
@@ -40,7 +43,7 @@ struct pgps_ctx {
     DevBuf comm_buf;                    // [rec_f | rec_s | gathered_f | gathered_s] of pgps_pkfs_seg_dev_*
     // the three-phase segment protocol keeps state in `ws` between its calls: what the last phase left, and the
     // workspace epoch (bumped by every call that carves `ws`) it left it at
-    struct SegTag { int phase = 0; long N = 0; int d = 0, rank = 0, nranks = 0, chunk = 0, block = 0, family = 0, stage_g = 0, dma = 0; unsigned long epoch = 0; } seg_tag;
+    struct SegTag { int phase = 0; long N = 0; int d = 0, rank = 0, nranks = 0, chunk = 0, block = 0, family = 0, stage_g = 0, dma = 0, rc_scan = 0; unsigned long epoch = 0; } seg_tag;
     unsigned long ws_epoch = 0;
     unsigned profiling = 0;             // bit i = time launches of slot PGPS_K_* i
     int prof_every = 1;                 // time every n-th launch of an enabled slot
@@ -78,6 +81,7 @@ namespace pgps {
 constexpr int kBlock = PGPS_BLOCK;      // lanes per workgroup (experiments: make EXTRA=-DPGPS_BLOCK=128 ...)
 constexpr int kWave = 64;
 constexpr int kWaves = kBlock / kWave;
+constexpr int kOneLaunchAuto = 8192;    // fused path: series up to this length run as one workgroup, one launch (pgps_set_one_launch)
 
 int ensure(pgps_ctx* ctx, DevBuf& b, size_t bytes);
 // all-gather of `bytes` per rank on the context's stream through the context's RCCL communicator (pgps_comm.hip)
@@ -266,6 +270,7 @@ struct RcArgsT {
     int store_f;                // write fms / fPs (0: log-likelihood-only and projected-posterior calls)
     const int* qslot;           // projected-posterior mode: (N,) slot of step k in pmean / pvar, or -1
     Real *pmean, *pvar;       // (K,) H sm and H sP H^T at the query steps
+    int quad;                   // level-1 kernels of the quad-cooperative family (pgps_qc.hip.h: fp32, 5 <= d <= 8, 16 chains per wave)
 };
 using RcArgs = RcArgsT<double>;
 // defined in pgps_rc_inst.hip, one explicit instantiation per (scalar type, d)
@@ -275,11 +280,19 @@ template <typename Real, int D>
 int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const Real* in, Real* out, int batch, long bstride,
                  const Real* fixed);
 template <typename Real, int D>
+int launch_rc_scan_blocked(pgps_ctx* ctx, int which, long n, Real* data, Real* scratch);
+template <typename Real, int D>
 int launch_rc_seg_carry(pgps_ctx* ctx, int which, const Real* gathered, int rank, int nranks, int reclen, Real* out);
 template <int D>
 int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, const double* ts, double t0, double* Fs,
                    double* Qs, int batch, long bs_model);
 }  // namespace rc
+// quad-cooperative level-1 kernels (pgps_qc.hip.h): fp32, 5 <= d <= 8; they speak the row-cooperative protocol
+namespace qc {
+constexpr int kDimMin = 5, kDimMax = 8;
+template <int D>
+int launch_qc_level1(pgps_ctx* ctx, const rc::RcArgsT<float>& a, int phase);
+}  // namespace qc
 template <typename T>
 int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, const T* ts, T t0, T* Fs, T* Qs);
 

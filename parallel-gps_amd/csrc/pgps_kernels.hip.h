@@ -1291,20 +1291,21 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
 // K-FS: single-pass filter.  k_filter_reduce and k_filter_apply in ONE launch for d <= 2:
 //   phase A  the lane streams its LC steps through LDS into REGISTERS and reduces them (filt_extend);
 //            workgroup scan -> per-lane exclusive prefix (stays in registers) + workgroup total
-//   hand-off the total is published (agent-scope atomic stores, drained, then a flag); the workgroup
-//            waits for the totals of the tiles to its left inside its look-back window and for the
-//            inclusive prefix that closes the previous window, folds them (same tree as fold_spine)
+//   hand-off the total is published (agent-scope atomic stores, drained), one arrival is added to a sharded counter,
+//            and the workgroup waits until every workgroup has arrived: a grid-wide barrier (round 3; round 2 had every
+//            lane poll a flag of its own per predecessor inside look-back windows -- 12 us of wait).  Then it folds the
+//            totals to its left exactly as k_filter_apply folds the spine.
 //   phase B  lane-serial Kalman pass over the SAME registers -> fms, fPs, ll, smoothing aggregates
-// so Fs, Qs, ys are read once (k_filter_reduce's 72 B/step pass, the lpre round trip and a kernel
-// boundary disappear).  Tiles are handed out by an atomic ticket, so a tile only ever waits for
-// tiles that are already running: no assumption about dispatch order or residency.  The window
-// scheme is fixed (tile t folds tiles [W*floor(t/W), t) onto the inclusive prefix of tile
-// W*floor(t/W)-1), so the combine order -- and the result, bit for bit -- does not depend on timing.
-// Inter-workgroup visibility follows the CDNA4 hand-off rules (cdna_hip_programming.md G16): every
-// handed-off byte is written by ONE lane with agent-scope atomic (sc1, write-through) stores, that
-// lane drains its stores (s_waitcnt vmcnt(0)) before the agent-scope flag store; consumers poll the
-// flag relaxed at agent scope, take ONE agent acquire, and read the payload with agent-scope atomic
-// loads only.  Every spin is bounded (status word) so a protocol error cannot hang the GPU.
+// so Fs, Qs, ys are read once: k_filter_reduce's 72 B/step pass -- 295 KB through a CU's memory path, which is what
+// bounds the streaming loops (profiles/r03_experiments.txt) -- the lpre round trip and a kernel boundary disappear.
+// The barrier needs every workgroup resident: the launch function takes this path only when the grid fits the chip
+// (workgroups x waves <= 4 x CUs: one wave per SIMD, the registers of the chunk allow no more), and every spin is
+// bounded (status word) so that a grid that is not resident -- another stream holding CUs -- ends instead of hanging.
+// Inter-workgroup visibility follows the CDNA4 hand-off rules (cdna_hip_programming.md G16): every handed-off byte is
+// written by ONE lane with agent-scope atomic (sc1, write-through) stores, that lane drains its stores
+// (s_waitcnt vmcnt(0)) before its arrival; consumers poll relaxed at agent scope and read the payload with agent-scope
+// atomic (sc1) loads only.  The fold order is fixed (lane-contiguous runs of totals, then the ordered tree), so the
+// result does not depend on timing.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void pub_store(T* p, T v) {
@@ -1328,7 +1329,7 @@ __device__ __forceinline__ bool wait_flag(const int* f, int want, int* status) {
 
 template <typename T, int D, bool SMOOTH, int LC, bool NT>
 __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
-    constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT, NMP = Dim<D>::NMP, G = 4, S = LC / G;
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT, G = 4, S = LC / G;
     using FE = FiltElem<T, D>;
     using SE = SmthElem<T, D>;
     using MC = MeanCov<T, D>;
@@ -1338,14 +1339,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
     static_assert(CFG::on && LC % G == 0, "single-pass filter: staged dims only, whole sub-tiles");
     __shared__ T lds[kWaves * NF];
     __shared__ double lds_ll[kWaves];
-    __shared__ int s_tile;
-    __shared__ T s_base[NMP];
     __shared__ __attribute__((aligned(16))) char stage[kWaves][CFG::F3_BYTES];
 
     PGPS_STAMP(1, 0);
-    if (threadIdx.x == 0) s_tile = atomicAdd(a.ticket, 1);
-    __syncthreads();
-    const int tile = s_tile;
+    const int tile = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
 
@@ -1405,65 +1402,58 @@ __global__ __launch_bounds__(kBlock) void k_filter_single(const ScanArgs<T> a) {
     block_scan_exclusive<FE, true>(agg, excl, total, lds);
     PGPS_STAMP(1, 2);
 
-    // ---- hand-off: publish this tile's total, collect the carry from the left ---------------------
+    // ---- hand-off: publish this tile's total, grid barrier, fold the totals to the left ----------------------
+    // Every workgroup of the launch is resident (the launch function checks the grid against the chip), so the hand-off
+    // is ONE grid-wide barrier: lane 0 stores the total write-through (agent-scope atomic stores = sc1), drains them, and
+    // adds one arrival to the counter shard of its tile (8 shards on cache lines of their own: a single word saturates
+    // at ~90 atomics per us); lanes 0..7 of the workgroup poll one shard each -- relaxed agent-scope loads with s_sleep,
+    // never an acquire per poll -- until every tile has arrived.  The totals are then read with agent-scope atomic
+    // (sc1) loads only, which bypass this CU's L1: no acquire fence is needed (MI355X_MICROARCH.md, hand-offs measured
+    // with sc1 loads in place of the acquire).  Round 2's version polled one flag per predecessor from every lane of
+    // every workgroup (up to 32k pollers hammering L2 while the stragglers were still streaming): its wait took 12 us.
+    // Every spin is bounded: a grid that is not resident ends with bit 1 of the status word set instead of hanging.
     if (threadIdx.x == 0) {
         T v[NF];
         pack(total, v);
 #pragma unroll
         for (int i = 0; i < NF; ++i) pub_store(a.spine + (long)tile * NF + i, v[i]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.flags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.flags + (tile & 7) * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int w0 = (tile / a.win) * a.win;
+    if (threadIdx.x < 8) {
+        const int want = (a.nblocks - (int)threadIdx.x + 7) / 8;       // tiles whose index is threadIdx.x mod 8
+        wait_flag(a.flags + threadIdx.x * 32, want, a.status);
+    }
+    __syncthreads();
+    PGPS_STAMP(1, 3);
     FE mine;
     filt_identity(mine);
-    bool got = true;
     {
-        const int idx = w0 + (int)threadIdx.x;
-        if (idx < tile) got = wait_flag(a.flags + idx, 1, a.status);
-        if (threadIdx.x == 0 && w0 > 0) got = wait_flag(a.flags + (w0 - 1), 2, a.status) && got;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (idx < tile && got) {
+        const int per = (tile + kBlock - 1) / kBlock;
+        const int b0 = (int)threadIdx.x * per, b1 = min(tile, b0 + per);
+        bool have = false;
+        for (int b = b0; b < b1; ++b) {
             T v[NF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) v[i] = pub_load(a.spine + (long)idx * NF + i);
-            unpack(v, mine);
-        }
-        if (threadIdx.x == 0) {
-            if (w0 > 0) {
-#pragma unroll
-                for (int i = 0; i < NMP; ++i) s_base[i] = pub_load(a.incl + (long)(w0 - 1) * NMP + i);
-            } else {
-                T P0f[MAT], P0s[SYM];
-#pragma unroll
-                for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
-                sym_from_full<T, D>(P0f, P0s);
-#pragma unroll
-                for (int i = 0; i < D; ++i) s_base[i] = T(0);
-#pragma unroll
-                for (int i = 0; i < SYM; ++i) s_base[D + i] = P0s[i];
-            }
+            for (int i = 0; i < NF; ++i) v[i] = pub_load(a.spine + (long)b * NF + i);
+            FE e;
+            unpack(v, e);
+            if (have) { FE r; filt_combine(mine, e, r); mine = r; } else { mine = e; have = true; }
         }
     }
-    PGPS_STAMP(1, 3);
-    FE left;
-    block_reduce_ordered(mine, left, lds);          // (its barriers also publish s_base)
     MC s;
+    {
+        T P0f[MAT];
 #pragma unroll
-    for (int i = 0; i < D; ++i) s.m[i] = s_base[i];
+        for (int i = 0; i < MAT; ++i) P0f[i] = a.P0[i];
 #pragma unroll
-    for (int i = 0; i < SYM; ++i) s.P[i] = s_base[D + i];
-    filt_apply(s, left);                            // filtered state entering this tile
-    if ((tile + 1) % a.win == 0 && tile + 1 < a.nblocks && threadIdx.x == 0) {
-        // this tile closes a window: its inclusive prefix is the base of the next one
-        MC inc = s;
-        filt_apply(inc, total);
-#pragma unroll
-        for (int i = 0; i < D; ++i) pub_store(a.incl + (long)tile * NMP + i, inc.m[i]);
-#pragma unroll
-        for (int i = 0; i < SYM; ++i) pub_store(a.incl + (long)tile * NMP + D + i, inc.P[i]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.flags + tile, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < D; ++i) s.m[i] = T(0);
+        sym_from_full<T, D>(P0f, s.P);
+    }
+    if (tile > 0) {
+        FE left;
+        block_reduce_ordered(mine, left, lds);
+        filt_apply(s, left);                        // filtered state entering this tile
     }
     filt_apply(s, excl);                            // ... and this lane's chunk
 
@@ -1771,6 +1761,9 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
     SmootherApplyStaged<T, D, CFG::GG, NT> st;
     if constexpr (CFG::on) {
         staged = (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
+        // (tried in round 3: finishing the spine / lsuf loads before the prefetch goes out -- hipcc waits for them with
+        // s_waitcnt vmcnt(9), which drains most of the 56 KiB prefetch issued after them before the fold's tree starts --
+        // same pass time, 82.8 vs 83.0 us: the prefetch then starts a load latency later; profiles/r03_experiments.txt)
         if (staged) st.prefetch(a, wbase);
     }
     // smoothed state of the first step AFTER this segment (irrelevant when seg_last: E = 0 there)

@@ -1227,9 +1227,11 @@ __device__ __forceinline__ void st_filt(Real* r, bool ok, int lane, const Real* 
 
 // out[c] = in[c - stride] (x) in[c]; with `fixed` given: out[c] = fixed (x) in[c] for every c (a segment's
 // carry-in combined into all its prefixes)
+// With fixblk > 0 (the last stage of the blocked scan below): record c takes the fixed operand fixed[c / fixblk - 1] --
+// the scanned total of the blocks before its own -- and the records of block 0 pass through.
 template <typename Real, int D>
 __global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const Real* in, Real* out, long bstride,
-                                                   const Real* fixed) {
+                                                   const Real* fixed, long fixblk = 0) {
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     Real* patch = patch_init(tl, row);
@@ -1237,7 +1239,7 @@ __global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const Re
     out += blockIdx.y * bstride;
     constexpr int dd = D * D, nf = 3 * D * D + 2 * D;
     const long c = (long)blockIdx.x * 4 + row;
-    const bool lv = lane < D, cv = c < n, comb = cv && (fixed != nullptr || c >= stride);
+    const bool lv = lane < D, cv = c < n, comb = cv && (fixblk > 0 ? c >= fixblk : (fixed != nullptr || c >= stride));
     const bool ok = lv && cv;
     // later operand (also the pass-through value)
     Real A2[D], C2[D], J2[D], b2 = Real(0.0), e2 = Real(0.0);
@@ -1248,7 +1250,7 @@ __global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const Re
     Real A1[D], C1[D], J1[D], b1 = Real(0.0), e1 = Real(0.0);
 #pragma unroll
     for (int i = 0; i < D; ++i) { A1[i] = (i == lane) ? Real(1.0) : Real(0.0); C1[i] = Real(0.0); J1[i] = Real(0.0); }
-    const Real* r1 = fixed ? fixed : in + (comb ? c - stride : 0) * nf;
+    const Real* r1 = fixblk > 0 ? fixed + (comb ? c / fixblk - 1 : 0) * nf : (fixed ? fixed : in + (comb ? c - stride : 0) * nf);
     ld_filt<D>(r1, lv && comb, lane, A1, C1, J1, b1, e1);
     Real Ao[D], bo, eo;
     filt_combine_rc<D>(patch, lane, A1, C1, J1, b1, e1, A2, C2, J2, b2, e2, Ao, bo, eo);
@@ -1269,14 +1271,18 @@ __global__ __launch_bounds__(64) void rc_ks_filter(long n, long stride, const Re
 }
 
 // out[c] = in[c] (x) in[c + stride] in time order; with `fixed` given: out[c] = in[c] (x) fixed for every c
+// (fixblk > 0: record c takes fixed[c / fixblk + 1], the scanned total of the blocks after its own; the last block passes)
 template <typename Real, int D>
-__global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const Real* in, Real* out, const Real* fixed) {
+__global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const Real* in, Real* out, const Real* fixed,
+                                                     long fixblk = 0) {
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
     Real* patch = patch_init(tl, row);
     constexpr int dd = D * D, ns = 2 * D * D + D;
     const long c = (long)blockIdx.x * 4 + row;
-    const bool lv = lane < D, cv = c < n, comb = cv && (fixed != nullptr || c + stride < n);
+    const long nblk = fixblk > 0 ? (n + fixblk - 1) / fixblk : 0;
+    const bool lv = lane < D, cv = c < n,
+               comb = cv && (fixblk > 0 ? c / fixblk + 1 < nblk : (fixed != nullptr || c + stride < n));
     const bool ok = lv && cv, okb = lv && comb;
     Real Ea[D], La[D], ga = Real(0.0);
     zero<D>(Ea); zero<D>(La);
@@ -1286,7 +1292,7 @@ __global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const 
     Real Eb[D], Lb[D], gb = Real(0.0);
 #pragma unroll
     for (int i = 0; i < D; ++i) { Eb[i] = (i == lane) ? Real(1.0) : Real(0.0); Lb[i] = Real(0.0); }      // identity when passing through
-    const Real* rb = fixed ? fixed : in + (comb ? c + stride : 0) * ns;
+    const Real* rb = fixblk > 0 ? fixed + (comb ? c / fixblk + 1 : 0) * ns : (fixed ? fixed : in + (comb ? c + stride : 0) * ns);
     ld_rec_mat<D>(rb, okb, lane, Eb); ld_rec_mat<D>(rb + dd, okb, lane, Lb);
     if (okb) gb = rb[2 * dd + lane];
     Real Eo[D], Lo[D], go;
@@ -1298,6 +1304,102 @@ __global__ __launch_bounds__(64) void rc_ks_smoother(long n, long stride, const 
     } else {
         st_rec_mat<D>(ro, ok, lane, Ea); st_rec_mat<D>(ro + dd, ok, lane, La);
         if (ok) ro[2 * dd + lane] = ga;
+    }
+}
+
+// ====================================================================================================
+// Blocked scan of the chain totals (round 3).  The Kogge-Stone scan above is one LAUNCH per level -- 12 to 14 launches
+// per scan, each a 10 - 15 us round trip of every record through global memory (c5: 24 launches = 0.3 ms of a 2.7 ms
+// pass).  Here a workgroup of B rows (one 16-lane row per record, B <= 64 by the LDS budget) runs log2(B) levels inside
+// ONE launch, exchanging records through LDS, and writes its block's inclusive local scan plus the block total; the
+// totals are scanned the same way (recursively: n / B, n / B^2, ...), and one more launch per level combines the scanned
+// total of the neighbouring blocks into every record (rc_ks_* with fixblk).  n = 4096 at B = 16: 5 launches instead of
+// 12; n = 16384 at B = 64: 5 instead of 14.  The scan is in place.
+// ====================================================================================================
+template <typename Real, int D, int B>
+__global__ __launch_bounds__(B * 16) void rc_scan_blk_f(long n, Real* data, Real* tot) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int dd = D * D, nf = 3 * D * D + 2 * D;
+    Real* recs = reinterpret_cast<Real*>(smem_raw);                 // B records
+    Real* tl = recs + (size_t)B * nf;                               // B transpose patches
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    for (int e = threadIdx.x; e < B * kPatch; e += blockDim.x) tl[e] = Real(0.0);
+    __syncthreads();
+    Real* patch = tl + row * kPatch;
+    const long c = (long)blockIdx.x * B + row;
+    const bool lv = lane < D, cv = c < n, ok = lv && cv;
+    // this row's record; rows beyond the last record hold the identity (A = I)
+    Real A2[D], C2[D], J2[D], b2 = Real(0.0), e2 = Real(0.0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { A2[i] = (i == lane && lv) ? Real(1.0) : Real(0.0); C2[i] = Real(0.0); J2[i] = Real(0.0); }
+    Real* rg = data + (cv ? c : 0) * nf;
+    ld_filt<D>(rg, ok, lane, A2, C2, J2, b2, e2);
+    Real* mine = recs + (size_t)row * nf;
+    for (int s = 1; s < B; s <<= 1) {
+        if (lv) st_filt<D>(mine, true, lane, A2, C2, J2, b2, e2);
+        __syncthreads();
+        const bool have = row >= s;
+        // earlier operand: the record s rows before (rows without one combine with the identity and keep their own)
+        Real A1[D], C1[D], J1[D], b1 = Real(0.0), e1 = Real(0.0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { A1[i] = (i == lane && lv) ? Real(1.0) : Real(0.0); C1[i] = Real(0.0); J1[i] = Real(0.0); }
+        ld_filt<D>(recs + (size_t)(have ? row - s : 0) * nf, lv && have, lane, A1, C1, J1, b1, e1);
+        Real Ao[D], Co[D], bo, eo;
+        copy<D>(Co, C2);
+        filt_combine_rc<D>(patch, lane, A1, C1, J1, b1, e1, A2, Co, J2, b2, e2, Ao, bo, eo);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { A2[i] = have ? Ao[i] : A2[i]; C2[i] = have ? Co[i] : C2[i]; J2[i] = have ? J1[i] : J2[i]; }
+        b2 = have ? bo : b2;
+        e2 = have ? eo : e2;
+        __syncthreads();
+    }
+    st_filt<D>(rg, ok, lane, A2, C2, J2, b2, e2);
+    if (row == B - 1 && lv) st_filt<D>(tot + (long)blockIdx.x * nf, true, lane, A2, C2, J2, b2, e2);
+}
+
+template <typename Real, int D, int B>
+__global__ __launch_bounds__(B * 16) void rc_scan_blk_s(long n, Real* data, Real* tot) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int dd = D * D, ns = 2 * D * D + D;
+    Real* recs = reinterpret_cast<Real*>(smem_raw);
+    Real* tl = recs + (size_t)B * ns;
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    for (int e = threadIdx.x; e < B * kPatch; e += blockDim.x) tl[e] = Real(0.0);
+    __syncthreads();
+    Real* patch = tl + row * kPatch;
+    const long c = (long)blockIdx.x * B + row;
+    const bool lv = lane < D, cv = c < n, ok = lv && cv;
+    // this row's record (the EARLIER operand of a suffix step); rows beyond the last record hold the identity (E = I)
+    Real Ea[D], La[D], ga = Real(0.0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Ea[i] = (i == lane && lv) ? Real(1.0) : Real(0.0); La[i] = Real(0.0); }
+    Real* rg = data + (cv ? c : 0) * ns;
+    ld_rec_mat<D>(rg, ok, lane, Ea); ld_rec_mat<D>(rg + dd, ok, lane, La);
+    if (ok) ga = rg[2 * dd + lane];
+    Real* mine = recs + (size_t)row * ns;
+    for (int s = 1; s < B; s <<= 1) {
+        if (lv) { st_rec_mat<D>(mine, true, lane, Ea); st_rec_mat<D>(mine + dd, true, lane, La); mine[2 * dd + lane] = ga; }
+        __syncthreads();
+        const bool have = row + s < B;
+        Real Eb[D], Lb[D], gb = Real(0.0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { Eb[i] = (i == lane && lv) ? Real(1.0) : Real(0.0); Lb[i] = Real(0.0); }
+        const Real* rb = recs + (size_t)(have ? row + s : 0) * ns;
+        ld_rec_mat<D>(rb, lv && have, lane, Eb); ld_rec_mat<D>(rb + dd, lv && have, lane, Lb);
+        if (lv && have) gb = rb[2 * dd + lane];
+        Real Eo[D], Lo[D], go;
+        smth_combine_rc<D>(patch, lane, Ea, La, ga, Eb, Lb, gb, Eo, Lo, go);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { Ea[i] = have ? Eo[i] : Ea[i]; La[i] = have ? Lo[i] : La[i]; }
+        ga = have ? go : ga;
+        __syncthreads();
+    }
+    st_rec_mat<D>(rg, ok, lane, Ea); st_rec_mat<D>(rg + dd, ok, lane, La);
+    if (ok) rg[2 * dd + lane] = ga;
+    if (row == 0 && lv) {
+        Real* rt = tot + (long)blockIdx.x * ns;
+        st_rec_mat<D>(rt, true, lane, Ea); st_rec_mat<D>(rt + dd, true, lane, La);
+        rt[2 * dd + lane] = ga;
     }
 }
 
@@ -1529,9 +1631,50 @@ template <typename Real, int D>
 int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const Real* in, Real* out, int batch, long bstride,
                  const Real* fixed) {
     const dim3 blk(64), g((unsigned)((n + 3) / 4), (unsigned)batch);
-    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<Real, D>, g, blk, 0u, n, stride, in, out, bstride, fixed);
-    else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<Real, D>, g, blk, 0u, n, stride, in, out, fixed);
+    if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<Real, D>, g, blk, 0u, n, stride, in, out, bstride, fixed, 0L);
+    else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<Real, D>, g, blk, 0u, n, stride, in, out, fixed, 0L);
     HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+// rows (records) per workgroup of the blocked scan: the largest power of two <= 64 whose records + transpose patches
+// fit 144 KiB of LDS
+template <typename Real, int D>
+constexpr int scan_block_rows(int which) {
+    const int rec = which == 0 ? 3 * D * D + 2 * D : 2 * D * D + D;
+    int b = 64;
+    while (b > 2 && (size_t)b * (rec + kPatch) * sizeof(Real) > 144 * 1024) b /= 2;
+    return b;
+}
+// inclusive scan of n records in place (which = 0: filter totals, prefix; 1: smoothing totals, suffix); `scratch` holds the
+// block totals of every level (n / (B - 1) + 8 records are enough)
+template <typename Real, int D>
+int launch_rc_scan_blocked(pgps_ctx* ctx, int which, long n, Real* data, Real* scratch) {
+    if (n <= 1) return PGPS_OK;
+    constexpr int BF = scan_block_rows<Real, D>(0), BS = scan_block_rows<Real, D>(1);
+    const int B = which == 0 ? BF : BS;
+    const int rec = which == 0 ? 3 * D * D + 2 * D : 2 * D * D + D;
+    const long nblk = (n + B - 1) / B;
+    const size_t shmem = (size_t)B * (rec + kPatch) * sizeof(Real);
+    const dim3 grid((unsigned)nblk), blk((unsigned)B * 16);
+    if (which == 0) {
+        static bool attr_f = false;
+        if (!attr_f) { HIPCHK(ctx, hipFuncSetAttribute((const void*)rc_scan_blk_f<Real, D, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_f = true; }
+        timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_scan_blk_f<Real, D, BF>, grid, blk, (unsigned)shmem, n, data, scratch);
+    } else {
+        static bool attr_s = false;
+        if (!attr_s) { HIPCHK(ctx, hipFuncSetAttribute((const void*)rc_scan_blk_s<Real, D, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_s = true; }
+        timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_scan_blk_s<Real, D, BS>, grid, blk, (unsigned)shmem, n, data, scratch);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (nblk > 1) {
+        int rcode = launch_rc_scan_blocked<Real, D>(ctx, which, nblk, scratch, scratch + nblk * rec);
+        if (rcode) return rcode;
+        const dim3 g((unsigned)((n + 3) / 4));
+        if (which == 0) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc_ks_filter<Real, D>, g, dim3(64), 0u, n, 0L, (const Real*)data, data, 0L, (const Real*)scratch, (long)B);
+        else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc_ks_smoother<Real, D>, g, dim3(64), 0u, n, 0L, (const Real*)data, data, (const Real*)scratch, (long)B);
+        HIPCHK(ctx, hipGetLastError());
+    }
     return PGPS_OK;
 }
 

@@ -11,6 +11,7 @@ namespace pgps {
 namespace rc {
 template int launch_rc_level1<PGPS_RC_T, PGPS_RC_D>(pgps_ctx*, const RcArgsT<PGPS_RC_T>&, int);
 template int launch_rc_ks<PGPS_RC_T, PGPS_RC_D>(pgps_ctx*, int, long, long, const PGPS_RC_T*, PGPS_RC_T*, int, long, const PGPS_RC_T*);
+template int launch_rc_scan_blocked<PGPS_RC_T, PGPS_RC_D>(pgps_ctx*, int, long, PGPS_RC_T*, PGPS_RC_T*);
 template int launch_rc_seg_carry<PGPS_RC_T, PGPS_RC_D>(pgps_ctx*, int, const PGPS_RC_T*, int, int, int, PGPS_RC_T*);
 #ifndef PGPS_RC_NO_DISC
 template int launch_rc_disc<PGPS_RC_D>(pgps_ctx*, long, const double*, const double*, const double*, double, double*, double*, int, long);

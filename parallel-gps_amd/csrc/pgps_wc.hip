@@ -1647,6 +1647,17 @@ static __global__ __launch_bounds__(1024) void ll_finalize(const double* llpart,
 
 template <typename Real>
 static int level1(pgps_ctx* ctx, int d, const RcArgsT<Real>& a, int phase) {
+    if constexpr (sizeof(Real) == 4) {
+        if (a.quad) {                           // quad-cooperative level-1 kernels (pgps_qc.hip.h), same records
+            switch (d) {
+                case 5: return qc::launch_qc_level1<5>(ctx, a, phase);
+                case 6: return qc::launch_qc_level1<6>(ctx, a, phase);
+                case 7: return qc::launch_qc_level1<7>(ctx, a, phase);
+                case 8: return qc::launch_qc_level1<8>(ctx, a, phase);
+            }
+            return PGPS_E_UNSUPPORTED_DIM;
+        }
+    }
     switch (d) {
 #define PGPS_RC_CASE(DV) case DV: return launch_rc_level1<Real, DV>(ctx, a, phase);
         PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
@@ -1671,6 +1682,41 @@ static int ks_step(pgps_ctx* ctx, int d, int which, long n, long stride, const R
 }
 
 template <typename Real>
+static int scan_blocked(pgps_ctx* ctx, int d, int which, long n, Real* data, Real* scratch) {
+    switch (d) {
+#define PGPS_RC_CASE(DV) case DV: return launch_rc_scan_blocked<Real, DV>(ctx, which, n, data, scratch);
+        PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
+        PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
+        PGPS_RC_CASE(15) PGPS_RC_CASE(16)
+#undef PGPS_RC_CASE
+    }
+    return PGPS_E_UNSUPPORTED_DIM;
+}
+
+// Which scan runs over n chain totals: the blocked one (in place, a handful of launches: pgps_rc.hip.h) or one launch per
+// Kogge-Stone level (ping-pong between the two buffers).  A pure function of the context's setting and n, so the three
+// phases of a segment pass agree on where the result lives.
+static inline bool scan_is_blocked(const pgps_ctx* ctx, long n, int batch) {
+    return batch <= 1 && (ctx->rc_scan == 1 || (ctx->rc_scan < 0 && n >= 64));
+}
+// inclusive scan of the n records in A (B: second buffer / scratch); *res = where the result is
+template <typename Real>
+static int ks_scan(pgps_ctx* ctx, int d, int which, long n, Real* A, Real* B, Real** res, int batch = 1, long bstride = 0) {
+    if (scan_is_blocked(ctx, n, batch)) {
+        *res = A;
+        return scan_blocked(ctx, d, which, n, A, B);
+    }
+    Real *src = A, *dst = B;
+    for (long s = 1; s < n; s *= 2) {
+        int rcode = ks_step(ctx, d, which, n, s, src, dst, batch, bstride);
+        if (rcode) return rcode;
+        Real* t = src; src = dst; dst = t;
+    }
+    *res = src;
+    return PGPS_OK;
+}
+
+template <typename Real>
 static int seg_carry(pgps_ctx* ctx, int d, int which, const Real* gathered, int rank, int nranks, int reclen, Real* out) {
     switch (d) {
 #define PGPS_RC_CASE(DV) case DV: return launch_rc_seg_carry<Real, DV>(ctx, which, gathered, rank, nranks, reclen, out);
@@ -1692,7 +1738,8 @@ struct SegInfo {
 
 // number of Kogge-Stone steps over n records, and the buffer the result ends up in
 template <typename Real>
-static inline Real* ks_result(long n, Real* A, Real* B) {
+static inline Real* ks_result(const pgps_ctx* ctx, long n, Real* A, Real* B) {
+    if (scan_is_blocked(ctx, n, 1)) return A;
     int steps = 0;
     for (long s = 1; s < n; s *= 2) ++steps;
     return (steps & 1) ? B : A;
@@ -1712,18 +1759,15 @@ static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgsT<Real> a, Mode mode, Real* a
     if (mode == MODE_SEG_REDUCE) {
         a.agg1 = aggA;
         if ((rcode = level1(ctx, d, a, 0))) return rcode;
-        Real *src = aggA, *dst = aggB;
-        for (long s = 1; s < a.nchunk; s *= 2) {
-            if ((rcode = ks_step(ctx, d, 0, a.nchunk, s, src, dst))) return rcode;
-            Real* t = src; src = dst; dst = t;
-        }
+        Real* src = aggA;
+        if ((rcode = ks_scan(ctx, d, 0, a.nchunk, aggA, aggB, &src))) return rcode;
         hipLaunchKernelGGL(seg_pack_f<Real>, dim3(1), dim3(256), 0, ctx->stream, d, (const Real*)(src + (a.nchunk - 1) * nf), a.Fs,
                            a.Qs, sg.rec_f);
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
     }
     if (mode == MODE_SEG_FILTER) {
-        Real* pre = ks_result(a.nchunk, aggA, aggB);
+        Real* pre = ks_result(ctx, a.nchunk, aggA, aggB);
         if (!a.seg_first) {
             // everything before this segment, combined into every local prefix (and the entry state of chain 0)
             if ((rcode = seg_carry(ctx, d, 0, sg.gathered_f, sg.rank, sg.nranks, rf, sg.carry_rec))) return rcode;
@@ -1739,18 +1783,15 @@ static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgsT<Real> a, Mode mode, Real* a
         a.pre = pre;
         a.sagg1 = saggA;
         if ((rcode = level1(ctx, d, a, 1))) return rcode;
-        Real *src = saggA, *dst = saggB;
-        for (long s = 1; s < a.nchunk; s *= 2) {
-            if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, src, dst))) return rcode;
-            Real* t = src; src = dst; dst = t;
-        }
+        Real* src = saggA;
+        if ((rcode = ks_scan(ctx, d, 1, a.nchunk, saggA, saggB, &src))) return rcode;
         hipLaunchKernelGGL(seg_pack_s<Real>, dim3(1), dim3(256), 0, ctx->stream, d, (const Real*)src, (const double*)a.llpart,
                            (long)a.nchunk, pad, sg.rec_s);
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
     }
     // MODE_SEG_SMOOTHER
-    Real* suf = ks_result(a.nchunk, saggA, saggB);
+    Real* suf = ks_result(ctx, a.nchunk, saggA, saggB);
     if (!a.seg_last) {
         if ((rcode = seg_carry(ctx, d, 1, sg.gathered_s, sg.rank, sg.nranks, rs, sg.cb_rec))) return rcode;
         Real* other = suf == saggA ? saggB : saggA;
@@ -1773,31 +1814,22 @@ static int scan_rc(pgps_ctx* ctx, int d, RcArgsT<Real> a, Mode mode, Real* aggA,
     if (mode == MODE_PKS) {                     // stand-alone smoother: elements from the given filtered moments
         a.sagg1 = saggA;
         if ((rcode = level1(ctx, d, a, 5))) return rcode;
-        Real *ssrc = saggA, *sdst = saggB;
-        for (long s = 1; s < a.nchunk; s *= 2) {
-            if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, ssrc, sdst))) return rcode;
-            Real* t = ssrc; ssrc = sdst; sdst = t;
-        }
+        Real* ssrc = saggA;
+        if ((rcode = ks_scan(ctx, d, 1, a.nchunk, saggA, saggB, &ssrc))) return rcode;
         a.suf = ssrc;
         return level1(ctx, d, a, 3);
     }
     a.agg1 = aggA;
     if ((rcode = level1(ctx, d, a, 0))) return rcode;
-    Real *src = aggA, *dst = aggB;
+    Real* src = aggA;
     const int nb = a.batch > 1 ? a.batch : 1;
-    for (long s = 1; s < a.nchunk; s *= 2) {
-        if ((rcode = ks_step(ctx, d, 0, a.nchunk, s, src, dst, nb, a.bs_agg))) return rcode;
-        Real* t = src; src = dst; dst = t;
-    }
+    if ((rcode = ks_scan(ctx, d, 0, a.nchunk, aggA, aggB, &src, nb, a.bs_agg))) return rcode;
     a.pre = src;
     if (mode == MODE_PKFS) {
         a.sagg1 = saggA;
         if ((rcode = level1(ctx, d, a, 1))) return rcode;
-        src = saggA; dst = saggB;
-        for (long s = 1; s < a.nchunk; s *= 2) {
-            if ((rcode = ks_step(ctx, d, 1, a.nchunk, s, src, dst))) return rcode;
-            Real* t = src; src = dst; dst = t;
-        }
+        src = saggA;
+        if ((rcode = ks_scan(ctx, d, 1, a.nchunk, saggA, saggB, &src))) return rcode;
         a.suf = src;
         if ((rcode = level1(ctx, d, a, a.qslot ? 4 : 3))) return rcode;
     } else {
@@ -1867,8 +1899,16 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode, int
     HIPCHK(ctx, hipSetDevice(ctx->device));
     rc::RcArgsT<Real> a{};
     a.N = sa.N;
+    // quad-cooperative level-1 kernels: fp32, 5 <= d <= 8, filter and filter + smoother (family 4)
+    const bool quad = sizeof(Real) == 4 && ctx->family == 4 && d >= qc::kDimMin && d <= qc::kDimMax && mode != MODE_PKS &&
+                      batch <= 1 && bs_model == 0 && !qslot;
+    a.quad = quad ? 1 : 0;
     if (ctx->chunk > 0) {
         a.Lw = ctx->chunk;
+    } else if (quad) {
+        // sixteen chains per wave: 64 steps per chain put one wave on every SIMD at 2^20 steps
+        long lw = (sa.N + 16383) / 16384;
+        a.Lw = (int)(lw < 8 ? 8 : lw > 64 ? 64 : lw);
     } else {
         // four chains per wave: 4096 chains put one wave on every SIMD, and every doubling adds a Kogge-Stone
         // launch to both scans.  Measured at d = 11: 2^17 steps 0.67 ms with 4096 chains against 0.79 ms with 8192;

@@ -51,6 +51,10 @@ def _declare(lib):
     lib.pgps_set_block.argtypes = [P, c_int]
     if hasattr(lib, "pgps_set_dma"):
         lib.pgps_set_dma.argtypes = [P, c_int]
+    if hasattr(lib, "pgps_set_rc_scan"):
+        lib.pgps_set_rc_scan.argtypes = [P, c_int]
+    if hasattr(lib, "pgps_set_one_launch"):
+        lib.pgps_set_one_launch.argtypes = [P, c_int]
     lib.pgps_get_geometry.argtypes = [P, c_long, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.pgps_set_single_pass.argtypes = [P, c_int, c_int]
     lib.pgps_get_chunk.argtypes = [P, c_long, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
@@ -157,7 +161,8 @@ class Context:
         check(self, self.lib.pgps_set_single_pass(self.handle, int(mode), int(window)), "pgps_set_single_pass")
 
     def set_family(self, family):
-        """0 auto, 1 lane-chunk kernels (d <= 6), 2 wave-cooperative kernels (any d <= 32)."""
+        """0 auto, 1 lane-chunk kernels (d <= 6), 2 wave-cooperative (any d <= 32), 3 row-cooperative (2 <= d <= 16), 4 quad-cooperative
+        level-1 kernels (fp32, 5 <= d <= 8)."""
         check(self, self.lib.pgps_set_family(self.handle, int(family)), "pgps_set_family")
 
     def set_block(self, lanes):
@@ -168,6 +173,16 @@ class Context:
         """LDS-DMA ring in the Kalman pass (d = 2 fp64, 128-lane build): -1 automatic, 0 off, 1 on (pgps_set_dma)."""
         if hasattr(self.lib, "pgps_set_dma"):
             check(self, self.lib.pgps_set_dma(self.handle, int(mode)), "pgps_set_dma")
+
+    def set_one_launch(self, max_steps):
+        """Fused calls of short series in ONE launch up to max_steps steps: -1 automatic (8192), 0 never."""
+        if hasattr(self.lib, "pgps_set_one_launch"):
+            check(self, self.lib.pgps_set_one_launch(self.handle, int(max_steps)), "pgps_set_one_launch")
+
+    def set_rc_scan(self, mode):
+        """Scans of the chain totals (row- / quad-cooperative families): -1 automatic, 0 one launch per level, 1 blocked."""
+        if hasattr(self.lib, "pgps_set_rc_scan"):
+            check(self, self.lib.pgps_set_rc_scan(self.handle, int(mode)), "pgps_set_rc_scan")
 
     def get_geometry(self, n, d):
         """(lanes per workgroup, steps per lane, workgroups) of a lane-chunk call of n steps at state dimension d <= 6."""
@@ -533,15 +548,16 @@ class LtiLlStream:
     (17..32, e.g. the reference's CO2 kernel, d = 18)."""
 
     def __init__(self, ts, ys, capacity, t0=0.0, device=0):
-        self.ctx = get_context(device)
         ts_a = _prep(ts, np.float64, (-1,))
         ys_a = _prep(ys, np.float64, (-1,))
         if ys_a.shape[0] != ts_a.shape[0]:
             raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
         self.n, self.t0, self.capacity, self.count = ts_a.shape[0], float(t0), int(capacity), 0
         self.d_ts = self.d_ys = self.d_ll = None
-        self.ctx.lock.acquire()             # the context is this stream's until close(): its scratch carries the
-        self._locked = True                 # asynchronous evaluations (one call in flight per context, pgps.h)
+        # A context of its own: the asynchronous evaluations keep their scratch in the context between push() and
+        # finish(), so the stream must own one -- and with a private context it never holds the shared default
+        # context's lock (a stream dropped without finish() / close() used to leave that lock held for ever).
+        self.ctx = Context(device)
         try:
             self.d_ts = self.ctx.malloc(ts_a.nbytes)
             self.d_ys = self.ctx.malloc(ys_a.nbytes)
@@ -551,6 +567,19 @@ class LtiLlStream:
         except Exception:
             self.close()
             raise
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def push(self, F, Pinf, H, R):
         if self.count >= self.capacity:
@@ -571,14 +600,106 @@ class LtiLlStream:
         return out
 
     def close(self):
-        for name in ("d_ts", "d_ys", "d_ll"):
-            p = getattr(self, name, None)
-            if p:
-                self.ctx.free(p)
-            setattr(self, name, None)
-        if getattr(self, "_locked", False):
-            self._locked = False
-            self.ctx.lock.release()
+        ctx = getattr(self, "ctx", None)
+        if ctx is None:
+            return
+        self.ctx = None
+        try:
+            for name in ("d_ts", "d_ys", "d_ll"):
+                p = getattr(self, name, None)
+                setattr(self, name, None)
+                if p:
+                    ctx.free(p)
+        finally:
+            ctx.close()
+
+
+class Series:
+    """A series kept on the device across calls (pgps_series_*, include/pgps.h): what an optimiser or sampler loop
+    evaluates thousands of times is ONE (ts, ys) at changing hyper-parameters, and predict_f on a fixed grid.  The
+    handle holds ts, ys and -- once set -- the query grid merged with them; a call sends the fused model's scalars and
+    returns the log-likelihood (+ gradient), or the K posterior means and variances.  fp64, Matern-family models."""
+
+    def __init__(self, ts, ys, t0=0.0, device=0):
+        self.ctx = get_context(device)
+        ts_a = _prep(ts, np.float64, (-1,))
+        ys_a = _prep(ys, np.float64, (-1,))
+        if ys_a.shape[0] != ts_a.shape[0]:
+            raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
+        lib = self.ctx.lib
+        if not hasattr(lib, "pgps_series_create_f64"):
+            raise RuntimeError("this libpgps has no pgps_series_* entry points")
+        P = c_void_p
+        lib.pgps_series_create_f64.argtypes = [P, c_long, P, P, c_double, ctypes.POINTER(P)]
+        lib.pgps_series_set_queries_f64.argtypes = [P, c_long, P]
+        lib.pgps_series_destroy.argtypes = [P]
+        lib.pgps_series_gp_ll_f64.argtypes = [P, c_int, c_double, P, P, P, P, c_double, P]
+        lib.pgps_series_gp_ll_grad_f64.argtypes = [P, c_int, c_int, P, P]
+        lib.pgps_series_gp_predict_f64.argtypes = [P, c_int, c_double, P, P, P, P, c_double, P, P, P]
+        self.N, self.K = ts_a.shape[0], 0
+        self._tq = None
+        h = P()
+        with self.ctx.lock:
+            check(self.ctx, lib.pgps_series_create_f64(self.ctx.handle, c_long(self.N), _ptr(ts_a), _ptr(ys_a),
+                                                       c_double(float(t0)), ctypes.byref(h)), "pgps_series_create_f64")
+        self.handle = h
+        self._ll = c_double(0.0)
+        self._llp = ctypes.cast(ctypes.byref(self._ll), P)
+        self._gout = np.zeros(32, np.float64)
+
+    def set_queries(self, tq):
+        """The (sorted) query times of predict(); merged with the series on the device once."""
+        tq_a = _prep(tq, np.float64, (-1,))
+        if self._tq is not None and self._tq.shape == tq_a.shape and np.array_equal(self._tq, tq_a):
+            return
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_set_queries_f64(self.handle, c_long(tq_a.shape[0]), _ptr(tq_a)),
+                  "pgps_series_set_queries_f64")
+        self._tq, self.K = tq_a.copy(), tq_a.shape[0]
+        self._mean, self._var = np.empty(self.K, np.float64), np.empty(self.K, np.float64)
+
+    @staticmethod
+    def pack(form, Pinf, H):
+        """The fused model as the contiguous float64 arrays the calls take: (lam, N1, N2, Pinf, H, d)."""
+        lam, N1, N2 = form
+        d = N1.shape[0]
+        return (float(lam), _prep(N1, np.float64), _prep(N2, np.float64), _prep(Pinf, np.float64, (d, d)),
+                _prep(H, np.float64, (d,)), d)
+
+    def gp_ll(self, packed, R):
+        lam, N1, N2, Pinf, H, d = packed
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_gp_ll_f64(self.handle, d, lam, _ptr(N1), _ptr(N2), _ptr(Pinf), _ptr(H),
+                                                               float(R), self._llp), "pgps_series_gp_ll_f64")
+        return self._ll.value
+
+    def gp_ll_grad(self, model, d, npar):
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_gp_ll_grad_f64(self.handle, d, npar, _ptr(model), _ptr(self._gout)),
+                  "pgps_series_gp_ll_grad_f64")
+        return float(self._gout[0]), self._gout[1:1 + npar].copy()
+
+    def gp_predict(self, packed, R):
+        """(mean (K,), var (K,), ll) at the query grid of set_queries()."""
+        lam, N1, N2, Pinf, H, d = packed
+        mean, var = np.empty(self.K, np.float64), np.empty(self.K, np.float64)
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_gp_predict_f64(self.handle, d, lam, _ptr(N1), _ptr(N2), _ptr(Pinf),
+                                                                    _ptr(H), float(R), _ptr(mean), _ptr(var), self._llp),
+                  "pgps_series_gp_predict_f64")
+        return mean, var, self._ll.value
+
+    def close(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h and self.ctx is not None and getattr(self.ctx.handle, "value", None):
+            with self.ctx.lock:
+                self.ctx.lib.pgps_series_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 def lti_ll_batch(models, ts, ys, t0=0.0, device=0):

@@ -67,7 +67,58 @@ class StateSpaceGP:
             self._kf = lambda ssm, y: pkf(ssm, y, return_loglikelihood=True, max_parallel=ts.shape[0])
             self._kfs = lambda ssm, y: pkfs(ssm, y, max_parallel=max_parallel)
 
+    def _param_key(self):
+        """The kernel's hyper-parameters as a tuple (the memo key of _device_forms: an evaluation repeated at the same
+        setting -- predict_f after the objective, a benchmark loop -- does not rebuild the SDE)."""
+        return tuple(getattr(o, n) for o, n in self.trainable_parameters()[:-1])
+
+    def _device_series(self):
+        """The training series resident on the device (pgps_series_*, fp64 fused path): created at the first call, kept
+        for the model's life -- an optimiser or sampler loop then sends only the model's scalars per evaluation.  None
+        when the data are not sorted or not float64 (the host entry points take those)."""
+        ser = getattr(self, "_series", None)
+        if ser is None:
+            from . import _backend
+            ts, ys = self.data
+            t = ts.reshape(-1)
+            if ts.dtype != np.float64 or t.size < 1 or not np.all(np.diff(t) >= 0):
+                self._series = False
+                return None
+            try:
+                self._series = _backend.Series(t, ys.reshape(-1))
+            except RuntimeError:
+                self._series = False
+            ser = self._series
+        return ser or None
+
+    def invalidate_device_series(self):
+        """Call after changing `self.data` in place: the device copy is rebuilt at the next evaluation."""
+        ser = getattr(self, "_series", None)
+        if ser:
+            ser.close()
+        self._series = None
+
     def _device_forms(self):
+        key = self._param_key()
+        memo = getattr(self, "_forms_memo", None)
+        if memo is not None and memo[0] == key:
+            return memo[1]
+        out = self._device_forms_uncached()
+        self._forms_memo = (key, out)
+        return out
+
+    def _packed_fused(self, fused):
+        """The fused model as the contiguous arrays the series calls take, memoised with the forms."""
+        memo = getattr(self, "_packed_memo", None)
+        if memo is not None and memo[0] is fused:
+            return memo[1]
+        from . import _backend
+        sde, form = fused
+        packed = _backend.Series.pack(form, sde.P0, sde.H)
+        self._packed_memo = (fused, packed)
+        return packed
+
+    def _device_forms_uncached(self):
         """(fused, lti) from ONE get_sde() (for composite kernels that call is the host cost of an evaluation):
         `fused` = (sde, (lam, N1, N2)) when the SDE has the closed-form discretisation of the fused HIP path
         (F = -lam I + N, N nilpotent, d <= 3: the Matern family), `lti` = the SDE when the general-LTI device path applies
@@ -111,6 +162,14 @@ class StateSpaceGP:
         squeezed_ts = ts.reshape(-1)
         squeezed_Xnew = Xnew.reshape(-1)
         fused, lti = self._device_forms()
+        if fused is not None and squeezed_Xnew.size > 0 and dtype == np.float64 and np.all(np.diff(squeezed_Xnew) >= 0):
+            ser = self._device_series()
+            if ser is not None:
+                # series and query grid resident on the device (merged once): the call sends the model, K means and
+                # variances come back
+                ser.set_queries(squeezed_Xnew)
+                mean, var, _ = ser.gp_predict(self._packed_fused(fused), self.noise_variance)
+                return mean[:, None], var[:, None]
         if (fused is not None and squeezed_Xnew.size > 0 and np.all(np.diff(squeezed_ts) >= 0)
                 and np.all(np.diff(squeezed_Xnew) >= 0)):
             # the whole of predict_f on the device: merge, missing-marking, filter + smoother, projection
@@ -154,6 +213,9 @@ class StateSpaceGP:
         fused, lti = self._device_forms()
         if fused is not None:
             from . import _backend
+            ser = self._device_series() if ts.dtype == np.float64 else None
+            if ser is not None:
+                return np.float64(ser.gp_ll(self._packed_fused(fused), self.noise_variance))
             sde, form = fused
             return _backend.gp(form, sde.P0, sde.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))["ll"]
         if lti is not None:
@@ -294,6 +356,10 @@ class StateSpaceGP:
             # no dual-number path: batched differences on the general-LTI kernels (d <= 16), one evaluation at a
             # time above that (e.g. the CO2 kernel at its reference order, d = 18)
             return self._lti_ll_and_grad(batched=lti is not None, wrt=wrt)
+        ser = self._device_series() if ts.dtype == np.float64 else None
+        if ser is not None:
+            model, d, npar = _backend.pack_grad_model(self._grad_blocks())
+            return ser.gp_ll_grad(model, d, npar)
         ll, g = _backend.gp_ll_grad(self._grad_blocks(), ts.reshape(-1), Y.reshape(-1))
         return ll, g
 
