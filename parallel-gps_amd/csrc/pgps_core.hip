@@ -415,7 +415,7 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
         // row-cooperative family in fp32: its own instantiations (16-lane rows, v_fmac_f32_dpp), every mode; automatic
         // above the lane-chunk kernels' range (at d = 6 those still win in fp32: 0.71 against 0.85 ms at 2^20 steps)
         const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
-        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE))) return launch_scan_rc<float>(ctx, a, d, mode);
+        if (rc_ok && (ctx->family == 3 || ((ctx->family == 0 || ctx->family == 4) && d > PGPS_MAX_DIM_LANE))) return launch_scan_rc<float>(ctx, a, d, mode);
         // quad-cooperative level-1 kernels under the row-cooperative driver: family 4 (fp32, 5 <= d <= 8)
         if (ctx->family == 4) {
             if (d < qc::kDimMin || d > qc::kDimMax || mode == MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;
@@ -518,10 +518,11 @@ static int disc_dev(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, con
     if (!ctx || N < 1 || !F || !Pinf || !ts || !Fs || !Qs) return PGPS_E_INVALID;
     if constexpr (sizeof(T) == 8) {
         const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
-        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)))
+        if (rc_ok && (ctx->family == 3 || ((ctx->family == 0 || ctx->family == 4) && d > PGPS_MAX_DIM_LANE)))
             return launch_disc_rc(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
     } else {
-        if (((ctx->family == 0 && d > PGPS_MAX_DIM_LANE) || ctx->family == 3) && d >= rc::kDimMin && d <= rc::kDimMax) {
+        if ((((ctx->family == 0 || ctx->family == 4) && d > PGPS_MAX_DIM_LANE) || ctx->family == 3) && d >= rc::kDimMin &&
+            d <= rc::kDimMax) {
             // fp32 at 7 <= d <= 16 (or with the row-cooperative family forced): the arithmetic is fp64 in every
             // discretisation kernel anyway; widen the inputs,
             // run the row-cooperative kernel, narrow the results

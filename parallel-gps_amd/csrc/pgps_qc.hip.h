@@ -34,8 +34,25 @@ namespace pgps {
 namespace qc {
 
 constexpr int kChains = 16;                 // chains (quads) per wavefront
-#ifndef PGPS_QC_WAVES
-#define PGPS_QC_WAVES 2                      // waves per SIMD the kernels are compiled for (register budget 512 / waves)
+// next step's inputs requested right after the predict (their registers are free again from there: the loads fly under the
+// rest of the step) or at the end of the step (36 registers less alive through the element and total phases)
+#ifndef PGPS_QC_PREFETCH_EARLY
+#define PGPS_QC_PREFETCH_EARLY 1
+#endif
+constexpr bool kPrefetchEarly = PGPS_QC_PREFETCH_EARLY != 0;
+// Waves per SIMD each kernel is compiled for (register budget 512 / waves; PGPS_QC_WAVES forces one value on all).  The
+// filter + smoothing-element pass holds a dozen 2 d-register matrices and spills on 256 registers at every d (d = 6:
+// 100 B a lane inside the step loop, 450 us against 348 us on 512); the reduce pass fits 256 up to d = 6 (95 against
+// 109 us); the smoother and the filter-only pass fit everywhere (d = 6: 131 against 186 us).  Measured at 2^20 steps:
+// profiles/r03_experiments.txt.
+#ifdef PGPS_QC_WAVES
+constexpr int waves_reduce(int) { return PGPS_QC_WAVES; }
+constexpr int waves_apply(int, bool) { return PGPS_QC_WAVES; }
+constexpr int waves_smooth(int) { return PGPS_QC_WAVES; }
+#else
+constexpr int waves_reduce(int d) { return d <= 6 ? 2 : 1; }
+constexpr int waves_apply(int, bool smooth) { return smooth ? 1 : 2; }
+constexpr int waves_smooth(int) { return 2; }
 #endif
 
 // A lane's two columns of a matrix: m[i] = (M[i][2q], M[i][2q+1]) -- the pair sits in adjacent registers, so that one
@@ -250,6 +267,121 @@ __device__ __forceinline__ void ident2(const Lane<D>& ln, float dg, V2 (&z)[D]) 
     for (int i = 0; i < D; ++i) z[i] = V2{(i == ln.cj[0]) ? dg : 0.0f, (i == ln.cj[1]) ? dg : 0.0f};
 }
 
+// ---- whole records as 16-byte pieces through LDS ----------------------------------------------------------------
+// A lane's own accesses to its chain's record are 8 bytes wide and sixteen chains apart: every memory instruction of a
+// step touches sixteen cache lines for 512 useful bytes, and the kernels are bound by the number of such instructions
+// (the row-cooperative family measured the same: pgps_rc.hip.h Io).  FAST waves at even d therefore move the sixteen
+// records of a step as 16-byte pieces, lane t of instruction v carrying piece v * 64 + t (piece j of chain r:
+// r * NPC + j), through an LDS slot that holds the records back to back; the lanes pick their columns / rows out of it.
+// d = 6: 3 instructions per matrix instead of 6 (columns) or 12 (rows + columns); vectors: 1 instead of 6.
+#ifndef PGPS_QC_WIDE
+#define PGPS_QC_WIDE 1
+#endif
+constexpr unsigned kOob = 0x7ffff000u;
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int D>
+struct Wide {
+    static constexpr bool kOn = (D % 2 == 0) && (PGPS_QC_WIDE != 0);
+    static constexpr int REC = D * D * 4, NPC = REC / 16, NV = (kChains * NPC + 63) / 64, SLOT = NV * 1024;
+    static constexpr int VREC = D * 4, NPV = VREC / 8, VSLOT = 512;        // vectors: 8-byte pieces, one instruction
+    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+    using U2 = __attribute__((ext_vector_type(2))) unsigned int;
+    unsigned wg[NV], wv, lrec, lvec, span_m, span_v;
+    int tid;
+    __device__ __forceinline__ void init(int t, int Lw) {
+        tid = t & 63;
+        const unsigned pitch = (unsigned)Lw * (unsigned)REC, vpitch = (unsigned)Lw * (unsigned)VREC;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int q = v * 64 + tid;
+            wg[v] = q < kChains * NPC ? (unsigned)(q / NPC) * pitch + (unsigned)(q % NPC) * 16u : kOob;
+        }
+        wv = tid < kChains * NPV ? (unsigned)(tid / NPV) * vpitch + (unsigned)(tid % NPV) * 8u : kOob;
+        lrec = (unsigned)(tid >> 2) * (unsigned)REC;
+        lvec = (unsigned)(tid >> 2) * (unsigned)VREC;
+        span_m = (unsigned)(kChains - 1) * pitch + (unsigned)REC;
+        span_v = (unsigned)(kChains - 1) * vpitch + (unsigned)VREC;
+    }
+    static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+    }
+    // the bytes an access may touch from its base: everything the sixteen chains span (FAST waves), or what is left of
+    // the array (`left` steps from the base's one to the end; none at all when the base is beyond it)
+    template <bool FAST>
+    __device__ __forceinline__ unsigned limit(long left) const {
+        if constexpr (FAST) return span_m;
+        const long b = left * (long)REC;
+        return b <= 0 ? 0u : (b < (long)span_m ? (unsigned)b : span_m);
+    }
+    template <bool FAST>
+    __device__ __forceinline__ unsigned vlimit(long left) const {
+        if constexpr (FAST) return span_v;
+        const long b = left * (long)VREC;
+        return b <= 0 ? 0u : (b < (long)span_v ? (unsigned)b : span_v);
+    }
+    // base = the record of the wave's first chain at the step
+    __device__ __forceinline__ void load(const float* base, unsigned lim, V4 (&r)[NV]) const {
+        const __amdgpu_buffer_rsrc_t rs = rsrc(base, lim);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) r[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wg[v], 0, 0);
+    }
+    __device__ __forceinline__ void commit(char* slot, const V4 (&r)[NV]) const {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) *reinterpret_cast<V4*>(slot + (v * 64 + tid) * 16) = r[v];
+    }
+    __device__ __forceinline__ void cols(const char* slot, const Lane<D>& ln, V2 (&c)[D]) const {
+        const char* p = slot + lrec + ln.cj[0] * 4;
+#pragma unroll
+        for (int i = 0; i < D; ++i) c[i] = *reinterpret_cast<const V2*>(p + i * D * 4);
+    }
+    __device__ __forceinline__ void rows(const char* slot, const Lane<D>& ln, V2 (&r)[D]) const {
+        const char* p0 = slot + lrec + ln.cj[0] * D * 4;
+        const char* p1 = slot + lrec + ln.cj[1] * D * 4;
+#pragma unroll
+        for (int k = 0; k < D; ++k) r[k] = V2{*reinterpret_cast<const float*>(p0 + 4 * k), *reinterpret_cast<const float*>(p1 + 4 * k)};
+    }
+    __device__ __forceinline__ void put_cols(char* slot, const Lane<D>& ln, const V2 (&c)[D]) const {
+        if (ln.ok[0]) {
+            char* p = slot + lrec + ln.cj[0] * 4;
+#pragma unroll
+            for (int i = 0; i < D; ++i) *reinterpret_cast<V2*>(p + i * D * 4) = c[i];
+        }
+    }
+    __device__ __forceinline__ void drain(float* base, unsigned lim, const char* slot) const {
+        const __amdgpu_buffer_rsrc_t rs = rsrc(base, lim);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const V4 x = *reinterpret_cast<const V4*>(slot + (v * 64 + tid) * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(x, rs, (int)wg[v], 0, 0);
+        }
+    }
+    __device__ __forceinline__ U2 vload(const float* base, unsigned lim) const {
+        return __builtin_amdgcn_raw_buffer_load_b64(rsrc(base, lim), (int)wv, 0, 0);
+    }
+    __device__ __forceinline__ void vcommit(char* vslot, U2 x) const { *reinterpret_cast<U2*>(vslot + tid * 8) = x; }
+    __device__ __forceinline__ void vget(const char* vslot, float (&v)[D]) const {
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) {
+            const V2 t = *reinterpret_cast<const V2*>(vslot + lvec + 8 * i);
+            v[2 * i] = t.x; v[2 * i + 1] = t.y;
+        }
+    }
+    __device__ __forceinline__ void vput(char* vslot, const Lane<D>& ln, const float (&v)[D]) const {
+        if (ln.lead) {
+#pragma unroll
+            for (int i = 0; i < D / 2; ++i) *reinterpret_cast<V2*>(vslot + lvec + 8 * i) = V2{v[2 * i], v[2 * i + 1]};
+        }
+    }
+    __device__ __forceinline__ void vdrain(float* base, unsigned lim, const char* vslot) const {
+        const U2 x = *reinterpret_cast<const U2*>(vslot + tid * 8);
+        __builtin_amdgcn_raw_buffer_store_b64(x, rsrc(base, lim), (int)wv, 0, 0);
+    }
+};
+
 __host__ __device__ inline int nfilt(int d) { return 3 * d * d + 2 * d; }      // [A | C | J | b | eta]
 __host__ __device__ inline int nsmth(int d) { return 2 * d * d + d; }          // [E | L | g]
 
@@ -263,9 +395,17 @@ __device__ __forceinline__ bool wave_fast(const rc::RcArgsT<float>& a) {
 // ====================================================================================================
 // level 1: reduce -- filt_extend over the chain (pgps_math.h filt_extend, parallel.py:46-72,100-118)
 // ====================================================================================================
+// Edge waves (the first and the last ones of a series) run the same road as the others -- whole records through LDS, the
+// buffer range cut at the end of the array so that what lies beyond reads as zeros and is not stored -- plus a handful of
+// selects per step; only odd d (records that are not whole 16-byte pieces) goes lane by lane.
 template <int D, bool FAST>
-__device__ __forceinline__ void reduce1_body(const rc::RcArgsT<float>& a) {
+__device__ __forceinline__ void reduce1_body(const rc::RcArgsT<float>& a, char* lds) {
     constexpr int dd = D * D;
+    using Wd = Wide<D>;
+    constexpr bool WD = Wd::kOn;
+    Wd w;
+    typename Wd::V4 rf[Wd::NV], rq[Wd::NV];
+    const long kw = (long)blockIdx.x * kChains * a.Lw;      // first step of the wave's first chain
     Lane<D> ln;
     ln.init(threadIdx.x);
     const long c = (long)blockIdx.x * kChains + (threadIdx.x >> 2);
@@ -283,21 +423,45 @@ __device__ __forceinline__ void reduce1_body(const rc::RcArgsT<float>& a) {
     for (int i = 0; i < D; ++i) { b[i] = 0.0f; eta[i] = 0.0f; }
     V2 Fr[D], Fc[D], Q[D];
     float y;
-    auto load = [&](int s) {
+    // steps outside the chain, and the series' first one, run as the identity transition without a measurement
+    auto fix = [&](int s) {
+        if constexpr (!FAST) {
+            const long k = k0 + s;
+            const bool real = k < k1 && !(k == 0 && a.seg_first);
+            if (!real) { ident2<D>(ln, 1.0f, Fr); ident2<D>(ln, 1.0f, Fc); zero2<D>(Q); }
+        }
+    };
+    auto load_y = [&](int s) {
+        const long k = k0 + s;
+        y = a.ys[FAST || k < a.N ? k : a.N - 1];
+        if constexpr (!FAST) { if (k >= k1) y = __builtin_nanf(""); }
+    };
+    auto load = [&](int s) {                    // lane by lane (odd d)
         const long k = k0 + s;
         const long kc = k < a.N ? k : a.N - 1;
         ln.rows(a.Fs + kc * dd, Fr);
         ln.cols(a.Fs + kc * dd, Fc);
         ln.cols(a.Qs + kc * dd, Q);
-        y = a.ys[kc];
-        if constexpr (!FAST) {
-            const bool real = k < k1 && !(k == 0 && a.seg_first);
-            if (!real) { ident2<D>(ln, 1.0f, Fr); ident2<D>(ln, 1.0f, Fc); zero2<D>(Q); }
-            if (k >= k1) y = __builtin_nanf("");
-        }
+        load_y(s);
+        fix(s);
     };
-    load(0);
+    auto issue = [&](int s) {                   // whole records, a step ahead
+        const unsigned lim = w.template limit<FAST>(a.N - (kw + s));
+        w.load(a.Fs + (kw + s) * dd, lim, rf); w.load(a.Qs + (kw + s) * dd, lim, rq);
+    };
+    if constexpr (WD) { w.init(threadIdx.x, a.Lw); issue(0); load_y(0); }
+    else load(0);
     for (int s = 0; s < a.Lw; ++s) {
+        const int sn = s + 1 < a.Lw ? s + 1 : s;        // (clamped, not skipped: no branch inside the step)
+        if constexpr (WD) {
+            wsync();
+            w.commit(lds, rf); w.commit(lds + Wd::SLOT, rq);
+            wsync();
+            w.rows(lds, ln, Fr); w.cols(lds, ln, Fc); w.cols(lds + Wd::SLOT, ln, Q);
+            fix(s);
+            issue(sn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         V2 Ap[D], FC[D], Cp[D];
         float bp[D];
         zero2<D>(Ap); mm<D, false>(Ap, Fc, A);
@@ -305,7 +469,8 @@ __device__ __forceinline__ void reduce1_body(const rc::RcArgsT<float>& a) {
         copy2<D>(Cp, Q); mm<D, false>(Cp, FC, Fr);
         spread<D>(coldot<D>(Fr, b), bp);                 // (F b)[own rows], spread
         const float yk = y;
-        load(s + 1 < a.Lw ? s + 1 : s);         // (clamped, not skipped: no branch inside the step)
+        if constexpr (WD) load_y(sn);
+        else load(sn);
         float u[D], v[D];
         const V2 ul = coldot<D>(Cp, h), vl = coldot<D>(Ap, h);
         spread<D>(ul, u); spread<D>(vl, v);
@@ -328,9 +493,10 @@ __device__ __forceinline__ void reduce1_body(const rc::RcArgsT<float>& a) {
 }
 
 template <int D>
-__global__ __launch_bounds__(64, PGPS_QC_WAVES) void q_reduce1(const rc::RcArgsT<float> a) {
-    if (wave_fast(a)) reduce1_body<D, true>(a);
-    else reduce1_body<D, false>(a);
+__global__ __launch_bounds__(64, waves_reduce(D)) void q_reduce1(const rc::RcArgsT<float> a) {
+    __shared__ __attribute__((aligned(16))) char lds[Wide<D>::kOn ? 2 * Wide<D>::SLOT : 16];
+    if (wave_fast(a)) reduce1_body<D, true>(a, lds);
+    else reduce1_body<D, false>(a, lds);
 }
 
 // ====================================================================================================
@@ -338,8 +504,17 @@ __global__ __launch_bounds__(64, PGPS_QC_WAVES) void q_reduce1(const rc::RcArgsT
 // (kf_step / smth_element / smth_combine of pgps_math.h; parallel.py:135-151, 155-184)
 // ====================================================================================================
 template <int D, bool SMOOTH, bool FAST, bool STORE>
-__device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a) {
+__device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a, char* lds) {
     constexpr int dd = D * D;
+    using Wd = Wide<D>;
+    constexpr bool WD = Wd::kOn;
+    Wd w;
+    typename Wd::V4 rf[Wd::NV], rq[Wd::NV];
+    const long kw = (long)blockIdx.x * kChains * a.Lw;
+    // LDS: [F | Q] in, [W | Ln | P] out, [gn | m] vectors out
+    char* const sF = lds; char* const sQ = lds + Wd::SLOT;
+    char* const sW = lds + 2 * Wd::SLOT; char* const sL = lds + 3 * Wd::SLOT; char* const sP_ = lds + 4 * Wd::SLOT;
+    char* const sg = lds + 5 * Wd::SLOT; char* const sm_ = sg + Wd::VSLOT;
     Lane<D> ln;
     ln.init(threadIdx.x);
     const long c = (long)blockIdx.x * kChains + (threadIdx.x >> 2);
@@ -348,16 +523,19 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a) {
     float h[D];
     ld_vec<D>(a.H, h);
     // state entering the chain: (b, C) of the inclusive prefix of the chain before (A = 0 there); the prior for chain 0
-    // (a later segment of a sharded series enters its first chain with the carry-in of the ranks before it)
+    // (a later segment of a sharded series enters its first chain with the carry-in of the ranks before it).
+    // The mean is carried twice: replicated (m) and as the lane's own elements (ml) -- what `m - E mp` takes.
     float m[D];
+    V2 ml;
     V2 P[D];
     {
         const bool pr = cv && (c > 0 || !a.seg_first);
         const float* rec = c > 0 ? a.pre + (cv ? c - 1 : 0) * nfilt(D) : (a.seg_first ? a.pre : a.carry);
-        if (pr) { ld_vec<D>(rec + 3 * dd, m); ld_sym_cols<D>(ln, rec + dd, P); }
+        if (pr) { ld_vec<D>(rec + 3 * dd, m); ld_sym_cols<D>(ln, rec + dd, P); ml = V2{rec[3 * dd + ln.cj[0]], rec[3 * dd + ln.cj[1]]}; }
         else {
 #pragma unroll
             for (int i = 0; i < D; ++i) m[i] = 0.0f;
+            ml = V2{0.0f, 0.0f};
             if (c == 0) ld_sym_cols<D>(ln, a.P0, P); else zero2<D>(P);
         }
     }
@@ -374,71 +552,90 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a) {
     float y;
     // steps at or beyond N run with F = 0, Q = I: the element built from them is (0, m, P), i.e. the last element of the
     // series (parallel.py:155-156), and a total whose E is 0 absorbs whatever follows unchanged
-    auto load = [&](int s) {
-        const long k = k0 + s;
-        const long kc = k < a.N ? k : a.N - 1;
-        const float* pF = a.Fs + kc * dd;
-        const float* pQ = a.Qs + kc * dd;
+    auto fix = [&](int s) {
         if constexpr (!FAST) {
+            const long k = k0 + s;
             // step N of a segment that is not the last: the first step of the next rank (halo), out of its record
-            if (k == a.N && a.halo_F != nullptr) { pF = a.halo_F; pQ = a.halo_Q; }
-        }
-        ln.rows(pF, Fr);
-        ln.cols(pF, Fc);
-        ln.cols(pQ, Q);
-        y = a.ys[kc];
-        if constexpr (!FAST) {
-            const bool real = k < a.N || (k == a.N && a.halo_F != nullptr);
-            if (!real) { zero2<D>(Fr); zero2<D>(Fc); ident2<D>(ln, 1.0f, Q); }
-            if (!(s < a.Lw && k < k1)) y = __builtin_nanf("");
+            const bool halo = k == a.N && a.halo_F != nullptr;
+            if (halo) { ln.rows(a.halo_F, Fr); ln.cols(a.halo_F, Fc); ln.cols(a.halo_Q, Q); }
+            if (!(k < a.N || halo)) { zero2<D>(Fr); zero2<D>(Fc); ident2<D>(ln, 1.0f, Q); }
         }
     };
-    load(0);
+    auto load_y = [&](int s) {
+        const long k = k0 + s;
+        y = a.ys[(FAST && s < a.Lw) || k < a.N ? k : a.N - 1];
+        if constexpr (!FAST) { if (!(s < a.Lw && k < k1)) y = __builtin_nanf(""); }
+    };
+    auto load = [&](int s) {                    // lane by lane (odd d)
+        const long k = k0 + s;
+        const long kc = k < a.N ? k : a.N - 1;
+        ln.rows(a.Fs + kc * dd, Fr);
+        ln.cols(a.Fs + kc * dd, Fc);
+        ln.cols(a.Qs + kc * dd, Q);
+        load_y(s);
+        fix(s);
+    };
+    auto issue = [&](int s) {
+        const unsigned lim = w.template limit<FAST>(a.N - (kw + s));
+        w.load(a.Fs + (kw + s) * dd, lim, rf); w.load(a.Qs + (kw + s) * dd, lim, rq);
+    };
     const int nsteps = SMOOTH ? a.Lw + 1 : a.Lw;
+    if constexpr (WD) { w.init(threadIdx.x, a.Lw); issue(0); load_y(0); }
+    else load(0);
     for (int s = 0; s < nsteps; ++s) {
         const long k = k0 + s;
         const bool last = SMOOTH && s == a.Lw;          // the step after the chain: builds the last element, does not filter
-        // predict
+        const int sn = s + 1 < nsteps ? s + 1 : s;      // (clamped, not skipped: no branch inside the step)
+        if constexpr (WD) {
+            wsync();
+            w.commit(sF, rf); w.commit(sQ, rq);
+            wsync();
+            w.rows(sF, ln, Fr); w.cols(sF, ln, Fc); w.cols(sQ, ln, Q);
+            fix(s);
+            issue(sn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- phase A: predict; element of step k-1 (W = Pp^-1 F P = E^T, i.e. E in row layout; g = m - E mp; L = P - E F P)
         V2 FP[D], Pp[D];
         float mp[D];
         zero2<D>(FP); mm<D, false>(FP, Fc, P);
         copy2<D>(Pp, Q); mm<D, false>(Pp, FP, Fr);
-        spread<D>(coldot<D>(Fr, m), mp);
+        const V2 mpl = coldot<D>(Fr, m);                // (F m)[own rows]
+        spread<D>(mpl, mp);
         const float yk = y;
-        load(s + 1 < nsteps ? s + 1 : s);       // (clamped, not skipped: no branch inside the step)
-        if (SMOOTH && s > 0) {
-            // element of step k-1: W = Pp^-1 F P = E^T (E in row layout), g = m - E mp, L = P - E F P
-            V2 M[D], W[D];
+        if constexpr (WD) load_y(sn);
+        else if constexpr (kPrefetchEarly) load(sn);
+        V2 W[D], Ln[D];
+        float gn[D];
+        const bool elem = SMOOTH && s > 0;
+        if (elem) {
+            V2 M[D];
             copy2<D>(M, Pp); copy2<D>(W, FP);
             spd_solve<D>(M, W);
-            float gn[D];
-            spread<D>(V2{pick<D>(m, ln.cj[0]), pick<D>(m, ln.cj[1])} - coldot<D>(W, mp), gn);      // m - E mp
-            V2 Ln[D], T[D];
+            spread<D>(ml - coldot<D>(W, mp), gn);       // m - E mp
+            V2 T[D];
             zero2<D>(T); mm<D, true>(T, W, FP);         // E (F P)
 #pragma unroll
             for (int i = 0; i < D; ++i) Ln[i] = P[i] - T[i];
-            {
+            if constexpr (WD) {
+                const long left = a.N - (kw + s - 1);
+                wsync();
+                w.put_cols(sW, ln, W); w.put_cols(sL, ln, Ln); w.vput(sg, ln, gn);
+                wsync();
+                w.drain(a.Es + (kw + s - 1) * dd, w.template limit<FAST>(left), sW);      // W = E^T, row-major: what the
+                w.drain(a.Lws + (kw + s - 1) * dd, w.template limit<FAST>(left), sL);     // smoother's products take
+                w.vdrain(a.gs + (kw + s - 1) * D, w.template vlimit<FAST>(left), sg);
+            } else {
                 const bool st = FAST || (k - 1 < k1);
-                ln.st_cols(a.Es + (k - 1) * dd, st, W);          // W = E^T, row-major: what the smoother's products take
+                ln.st_cols(a.Es + (k - 1) * dd, st, W);
                 ln.st_cols(a.Lws + (k - 1) * dd, st, Ln);
                 ln.st_vec(a.gs + (k - 1) * D, st, gn);
             }
-            // total <- total (x) element, with Tt = E_tot^T:  Tt' = W Tt;  g' = Tt^T gn + gt;  L' = Tt^T (Ln Tt) + Ls
-            // Beyond the end of a segment that is NOT the last of its series there is nothing to fold: the F = 0 steps
-            // would put E = 0 into a total that the ranks after this one still have to extend.
-            const bool fold = FAST || a.seg_last || (k - 1 < a.N);
-            V2 X[D], T2[D], L2[D];
-            float g2[D];
-            zero2<D>(X); mm<D, false>(X, Ln, Tt);
-            copy2<D>(L2, Ls); mm<D, true>(L2, Tt, X);
-            spread<D>(coldot<D>(Tt, gn), g2);
-            zero2<D>(T2); mm<D, false>(T2, W, Tt);
-            if (fold) {
-                copy2<D>(Ls, L2); copy2<D>(Tt, T2);
-#pragma unroll
-                for (int i = 0; i < D; ++i) gt[i] += g2[i];
-            }
         }
+        // (the three phases of a step are kept apart: interleaved by the scheduler, their operands -- a dozen 2 d-register
+        // matrices -- are all alive at once and the kernel spills)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B: Kalman update
         if (!last) {
             const bool upd = FAST || k < k1;
             const bool obs = !(yk != yk);
@@ -447,12 +644,14 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a) {
             spread<D>(ul, u);
             float S = dot<D>(h, u, a.R), mu = dot<D>(h, mp, 0.0f);
             if (obs) ll.add((double)yk - (double)mu, (double)S);
+            V2 mq = mpl;
             if (!FAST && blockIdx.x == 0 && s == 0 && c == 0 && a.seg_first) {
                 // first step of the series: the update uses the prior itself (parallel.py:24-30), the likelihood term
                 // above used F0 P0 F0^T + Q0 (parallel.py:136-141)
                 copy2<D>(Pp, P);
 #pragma unroll
                 for (int i = 0; i < D; ++i) mp[i] = m[i];
+                mq = ml;
                 ul = coldot<D>(Pp, h);
                 spread<D>(ul, u);
                 S = dot<D>(h, u, a.R); mu = dot<D>(h, mp, 0.0f);
@@ -461,12 +660,39 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a) {
             const float ri = (obs ? yk - mu : 0.0f) * inv;
 #pragma unroll
             for (int i = 0; i < D; ++i) m[i] = __builtin_fmaf(u[i], ri, mp[i]);
+            ml = fma2(ri, ul, mq);
             copy2<D>(P, Pp); rank1<D>(P, u, ul * (-inv));
-            if constexpr (STORE) {
+            if constexpr (STORE && WD) {
+                const long left = a.N - (kw + s);
+                wsync();
+                w.put_cols(sP_, ln, P); w.vput(sm_, ln, m);
+                wsync();
+                w.drain(a.fPs + (kw + s) * dd, w.template limit<FAST>(left), sP_);
+                w.vdrain(a.fms + (kw + s) * D, w.template vlimit<FAST>(left), sm_);
+            } else if constexpr (STORE) {
                 ln.st_cols(a.fPs + k * dd, upd, P);
                 ln.st_vec(a.fms + k * D, upd, m);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase C: total <- total (x) element, with Tt = E_tot^T:  L' = Ls + Tt^T (Ln Tt);  g' = gt + Tt^T gn;  Tt' = W Tt
+        if (elem) {
+            V2 X[D];
+            float g2[D];
+            zero2<D>(X); mm<D, false>(X, Ln, Tt);
+            spread<D>(coldot<D>(Tt, gn), g2);
+            // Beyond the end of a segment that is NOT the last of its series there is nothing to fold: the F = 0 steps
+            // would put E = 0 into a total that the ranks after this one still have to extend.  (A whole quad takes the
+            // branch or none of it does: the broadcasts inside stay within the quad.)
+            if (FAST || a.seg_last || (k - 1 < a.N)) {
+                mm<D, true>(Ls, Tt, X);
+#pragma unroll
+                for (int i = 0; i < D; ++i) gt[i] += g2[i];
+                zero2<D>(X); mm<D, false>(X, W, Tt);
+                copy2<D>(Tt, X);
+            }
+        }
+        if constexpr (!WD && !kPrefetchEarly) load(sn);
     }
     if (cv) {
         if (SMOOTH) {
@@ -480,17 +706,26 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a) {
 }
 
 template <int D, bool SMOOTH, bool STORE>
-__global__ __launch_bounds__(64, PGPS_QC_WAVES) void q_apply1(const rc::RcArgsT<float> a) {
-    if (wave_fast(a)) apply1_body<D, SMOOTH, true, STORE>(a);
-    else apply1_body<D, SMOOTH, false, STORE>(a);
+__global__ __launch_bounds__(64, waves_apply(D, SMOOTH)) void q_apply1(const rc::RcArgsT<float> a) {
+    __shared__ __attribute__((aligned(16))) char lds[Wide<D>::kOn ? 5 * Wide<D>::SLOT + 2 * Wide<D>::VSLOT : 16];
+    if (wave_fast(a)) apply1_body<D, SMOOTH, true, STORE>(a, lds);
+    else apply1_body<D, SMOOTH, false, STORE>(a, lds);
 }
 
 // ====================================================================================================
 // level 1: smoother -- sm = E sm' + g, sP = E sP' E^T + L from the stored elements (parallel.py:176-184)
 // ====================================================================================================
 template <int D, bool FAST>
-__device__ __forceinline__ void smooth1_body(const rc::RcArgsT<float>& a) {
+__device__ __forceinline__ void smooth1_body(const rc::RcArgsT<float>& a, char* lds) {
     constexpr int dd = D * D;
+    using Wd = Wide<D>;
+    constexpr bool WD = Wd::kOn;
+    Wd w;
+    typename Wd::V4 rw[Wd::NV], rl[Wd::NV];
+    typename Wd::U2 rg;
+    const long kw = (long)blockIdx.x * kChains * a.Lw;
+    char* const sW = lds; char* const sL = lds + Wd::SLOT; char* const sO = lds + 2 * Wd::SLOT;
+    char* const sg = lds + 3 * Wd::SLOT; char* const so = sg + Wd::VSLOT;
     Lane<D> ln;
     ln.init(threadIdx.x);
     const long c = (long)blockIdx.x * kChains + (threadIdx.x >> 2);
@@ -510,43 +745,68 @@ __device__ __forceinline__ void smooth1_body(const rc::RcArgsT<float>& a) {
             zero2<D>(sP);
         }
     }
-    V2 W[D], L[D];
-    float g[D];
+    V2 W[D], L[D], gl;
     // stored element of the chain's step; steps outside the chain run as the identity element (I, 0, 0)
-    auto load = [&](int s) {
+    auto fix = [&](int s) {
+        if constexpr (!FAST) {
+            if (!(k0 + s < k1)) { ident2<D>(ln, 1.0f, W); zero2<D>(L); gl = V2{0.0f, 0.0f}; }
+        }
+    };
+    auto load = [&](int s) {                    // lane by lane (odd d)
         const long k = k0 + s;
         const long kc = k < a.N ? k : a.N - 1;
         ln.cols(a.Es + kc * dd, W);              // (q_apply1 stored W = E^T)
         ln.cols(a.Lws + kc * dd, L);
-        ld_vec<D>(a.gs + kc * D, g);
-        if constexpr (!FAST) {
-            if (!(k < k1)) {
-                ident2<D>(ln, 1.0f, W); zero2<D>(L);
-#pragma unroll
-                for (int i = 0; i < D; ++i) g[i] = 0.0f;
-            }
-        }
+        gl = V2{a.gs[kc * D + ln.cj[0]], a.gs[kc * D + ln.cj[1]]};
+        fix(s);
     };
-    load(a.Lw - 1);
+    auto issue = [&](int s) {
+        const long left = a.N - (kw + s);
+        w.load(a.Es + (kw + s) * dd, w.template limit<FAST>(left), rw); w.load(a.Lws + (kw + s) * dd, w.template limit<FAST>(left), rl);
+        rg = w.vload(a.gs + (kw + s) * D, w.template vlimit<FAST>(left));
+    };
+    if constexpr (WD) { w.init(threadIdx.x, a.Lw); issue(a.Lw - 1); }
+    else load(a.Lw - 1);
     for (int s = a.Lw - 1; s >= 0; --s) {
         const long k = k0 + s;
+        const int sn = s > 0 ? s - 1 : 0;
+        if constexpr (WD) {
+            wsync();
+            w.commit(sW, rw); w.commit(sL, rl); w.vcommit(sg, rg);
+            wsync();
+            w.cols(sW, ln, W); w.cols(sL, ln, L);
+            gl = *reinterpret_cast<const V2*>(sg + w.lvec + ln.cj[0] * 4);      // (columns in pairs at even d)
+            fix(s);
+            issue(sn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         V2 T[D], nP[D];
         zero2<D>(T); mm<D, true>(T, W, sP);             // E sP
         copy2<D>(nP, L); mm<D, false>(nP, T, W);        // + (E sP) E^T
-        const V2 sl = coldot<D>(W, sm) + V2{pick<D>(g, ln.cj[0]), pick<D>(g, ln.cj[1])};      // (E sm + g)[own rows]
-        load(s > 0 ? s - 1 : 0);
+        const V2 sl = coldot<D>(W, sm) + gl;            // (E sm + g)[own rows]
+        if constexpr (!WD) load(sn);
         spread<D>(sl, sm);
         copy2<D>(sP, nP);
-        const bool st = FAST || k < k1;
-        ln.st_cols(a.sPs + k * dd, st, sP);
-        ln.st_vec(a.sms + k * D, st, sm);
+        if constexpr (WD) {
+            const long left = a.N - (kw + s);
+            wsync();
+            w.put_cols(sO, ln, sP); w.vput(so, ln, sm);
+            wsync();
+            w.drain(a.sPs + (kw + s) * dd, w.template limit<FAST>(left), sO);
+            w.vdrain(a.sms + (kw + s) * D, w.template vlimit<FAST>(left), so);
+        } else {
+            const bool st = FAST || k < k1;
+            ln.st_cols(a.sPs + k * dd, st, sP);
+            ln.st_vec(a.sms + k * D, st, sm);
+        }
     }
 }
 
 template <int D>
-__global__ __launch_bounds__(64, PGPS_QC_WAVES) void q_smooth1(const rc::RcArgsT<float> a) {
-    if (wave_fast(a)) smooth1_body<D, true>(a);
-    else smooth1_body<D, false>(a);
+__global__ __launch_bounds__(64, waves_smooth(D)) void q_smooth1(const rc::RcArgsT<float> a) {
+    __shared__ __attribute__((aligned(16))) char lds[Wide<D>::kOn ? 3 * Wide<D>::SLOT + 2 * Wide<D>::VSLOT : 16];
+    if (wave_fast(a)) smooth1_body<D, true>(a, lds);
+    else smooth1_body<D, false>(a, lds);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------

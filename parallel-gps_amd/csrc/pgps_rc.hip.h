@@ -1639,10 +1639,15 @@ int launch_rc_ks(pgps_ctx* ctx, int which, long n, long stride, const Real* in, 
 
 // rows (records) per workgroup of the blocked scan: the largest power of two <= 64 whose records + transpose patches
 // fit 144 KiB of LDS
+#ifndef PGPS_RC_SCAN_ROWS
+#define PGPS_RC_SCAN_ROWS 32
+#endif
 template <typename Real, int D>
 constexpr int scan_block_rows(int which) {
     const int rec = which == 0 ? 3 * D * D + 2 * D : 2 * D * D + D;
-    int b = 64;
+    // (a level of a block costs one combine per wave, the block's waves sharing four SIMDs: at 64 rows -- sixteen waves --
+    // a launch of six levels took 36 us at d = 6 fp32, whatever the number of blocks; eight waves do five in about half)
+    int b = PGPS_RC_SCAN_ROWS;
     while (b > 2 && (size_t)b * (rec + kPatch) * sizeof(Real) > 144 * 1024) b /= 2;
     return b;
 }

@@ -42,6 +42,10 @@ def _merge_sorted(a, b, *args):
     return (weave(a, b),) + tuple(weave(i, j) for i, j in args)
 
 
+class _StructureChanged(Exception):
+    """_grad_rows_composite: the block partition of the drift is not the same at the perturbed parameters."""
+
+
 class StateSpaceGP:
     def __init__(self, data, kernel, noise_variance=1.0, parallel=False, max_parallel=10000):
         self.noise_variance = float(noise_variance)
@@ -246,10 +250,48 @@ class StateSpaceGP:
         walk(self.kernel)
         return ps + [(self, "noise_variance")]
 
-    def _grad_blocks(self):
+    def _grad_blocks_matern(self):
+        """_grad_blocks() of a single Matern-1/2, -3/2 or -5/2 kernel in closed form, from the memoised get_sde() of the
+        evaluation -- no further SDE construction (four of them per parameter were what a small-N gradient call cost on
+        the host).  With lam = sqrt(2 nu) / l and F = -lam I + N:
+          variance s2:  Pinf is linear in it, nothing else moves  ->  dPinf = Pinf / s2;
+          lengthscale:  dlam = -lam / l.  Matern-3/2 keeps the companion form (matern32.py:10-28: N = [[lam, 1],
+            [-lam^2, -lam]], Pinf = diag(s2, lam^2 s2)); Matern-5/2 is balanced (matern52.py: balance_ss + Lyapunov), and
+            Osborne's balancing iteration commutes with the time scaling x_i -> lam^i x_i that relates the companion
+            forms at two lengthscales, so the balanced drift is lam * (a constant matrix) and Pinf, H do not move:
+            dN = N / lam * dlam, dPinf = 0, dH = 0  (checked against the differences: tests/test_model_host.py);
+          noise:        R alone.
+        None for any other kernel."""
+        k = self.kernel
+        name = type(k).__name__
+        if name not in ("Matern12", "Matern32", "Matern52") or getattr(k, "kernels", None) or not k.variance:
+            return None
+        fused = self._fused_form() if self.parallel else None
+        if fused is None:
+            return None
+        sde, form = fused
+        lam, N = np.float64(form[0]), np.asarray(form[1], np.float64)
+        Pinf, H = np.asarray(sde.P0, np.float64), np.asarray(sde.H, np.float64).reshape(-1)
+        zN, zP, zH, z = np.zeros_like(N), np.zeros_like(Pinf), np.zeros_like(H), np.float64(0.0)
+        dlam = -lam / k.lengthscales
+        if name == "Matern32":
+            dN = dlam * np.array([[1.0, 0.0], [-2.0 * lam, -1.0]])
+            dP = np.diag([0.0, 2.0 * lam * k.variance * dlam])
+        else:
+            dN, dP = N * (dlam / lam), zP
+        by_name = {"variance": (z, zN, Pinf / k.variance, zH, z), "lengthscales": (dlam, dN, dP, zH, z),
+                   "noise_variance": (z, zN, zP, zH, np.float64(1.0))}
+        return [(lam, N, Pinf, H, np.float64(self.noise_variance))] + [by_name[n] for _, n in self.trainable_parameters()]
+
+    def _grad_blocks(self, closed_form=True):
         """The fused model (lam, N, Pinf, H, R) and its partial derivatives with respect to each
-        trainable parameter.  The SDE coefficients are low-degree rational functions of the
-        parameters; a Richardson-extrapolated central difference of get_sde() is exact to ~1e-11."""
+        trainable parameter: closed form for a single Matern kernel; otherwise the SDE coefficients are low-degree
+        rational functions of the parameters and a Richardson-extrapolated central difference of get_sde() is exact
+        to ~1e-11."""
+        closed = self._grad_blocks_matern() if closed_form else None
+        if closed is not None:
+            return closed
+
         def block():
             sde = self.kernel.get_sde()
             from . import _backend
@@ -293,7 +335,8 @@ class StateSpaceGP:
         """(rows, block sizes) for pgps_gp_ll_grad_blocks_*: the block-nilpotent model (lam_b, N, Pinf, H, R) of a sum /
         product of Matern kernels and its partial derivatives with respect to each trainable parameter (Richardson
         central differences of get_sde(): its entries are low-degree rational functions of the parameters, exact to
-        ~1e-11), or None when the kernel's drift does not have that form / the state dimension is not 2..6."""
+        ~1e-11), or (None, None) when the kernel's drift does not have that form, the state dimension is not 2..6, or
+        the partition into blocks changes under the perturbation."""
         from . import _backend
 
         def row():
@@ -323,13 +366,16 @@ class StateSpaceGP:
                 setattr(owner, name, x0 - h)
                 dn, sd = row()
                 if up is None or dn is None or su != sizes or sd != sizes:
-                    raise NotImplementedError("the kernel's block structure changes with its parameters")
+                    # (a coupling entry near nilpotent_blocks' threshold: the partition found at x0 +- h differs)
+                    raise _StructureChanged()
                 return [(u - v) / (2.0 * h) for u, v in zip(up, dn)]
 
             try:
                 h = 1e-3 * max(abs(x0), 1e-3)
                 d1, d2 = central(h), central(0.5 * h)
                 rows.append(tuple((4.0 * b - a) / 3.0 for a, b in zip(d1, d2)))
+            except _StructureChanged:
+                return None, None               # the caller differentiates the likelihood itself instead
             finally:
                 setattr(owner, name, x0)
         return rows, sizes
@@ -352,7 +398,12 @@ class StateSpaceGP:
             if lti is not None and lti.F.shape[0] <= _backend.GRAD_BLOCKS_DIM_MAX:
                 rows, sizes = self._grad_rows_composite()
             if rows is not None:
-                return _backend.gp_ll_grad_blocks(rows, sizes, ts.reshape(-1), Y.reshape(-1))
+                ll, g = _backend.gp_ll_grad_blocks(rows, sizes, ts.reshape(-1), Y.reshape(-1))
+                if wrt is not None:             # (one pass gives every direction; the ones not asked for read 0)
+                    keep = np.zeros(len(g), bool)
+                    keep[[int(i) for i in wrt]] = True
+                    g = np.where(keep, g, 0.0)
+                return ll, g
             # no dual-number path: batched differences on the general-LTI kernels (d <= 16), one evaluation at a
             # time above that (e.g. the CO2 kernel at its reference order, d = 18)
             return self._lti_ll_and_grad(batched=lti is not None, wrt=wrt)

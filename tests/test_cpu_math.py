@@ -175,3 +175,47 @@ def test_grad_model_blocks_are_exact():
     assert np.allclose(d_l[2], np.diag([0.0, 2 * lam * dlam * s2]), rtol=1e-8, atol=1e-8)
     assert abs(d_r[4] - 1.0) < 1e-9 and np.allclose(d_r[2], 0.0, atol=1e-9)
     assert m.kernel.lengthscales == l and m.kernel.variance == s2 and m.noise_variance == r
+
+
+@pytest.mark.parametrize("kname", ["m12", "m32", "m52"])
+def test_closed_form_grad_blocks_match_the_differences(kname):
+    """A single Matern kernel's model derivatives come in closed form (no get_sde() beyond the evaluation's own); they
+    are the Richardson differences of get_sde() -- for Matern-5/2 that is the statement that the balancing iteration
+    commutes with the lengthscale's time scaling (model.py _grad_blocks_matern)."""
+    from pssgp.kernels import Matern12, Matern32, Matern52
+    from pssgp.model import StateSpaceGP
+    cls = {"m12": Matern12, "m32": Matern32, "m52": Matern52}[kname]
+    rng = np.random.default_rng(17)
+    for _ in range(4):
+        s2, l, r = float(rng.uniform(0.2, 3.0)), float(rng.uniform(0.05, 2.0)), float(rng.uniform(0.01, 1.0))
+        m = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), cls(s2, l), noise_variance=r, parallel=True)
+        closed, diffs = m._grad_blocks(), m._grad_blocks(closed_form=False)
+        assert m._grad_blocks_matern() is not None and len(closed) == len(diffs) == 4
+        for rc, rd in zip(closed, diffs):
+            for a, b in zip(rc, rd):
+                a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+                assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-9 * (1.0 + np.max(np.abs(b)))
+    # anything else keeps the differences
+    m = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), Matern32(1.0, 1.0) + Matern52(1.0, 1.0), parallel=True)
+    assert m._grad_blocks_matern() is None
+
+
+def test_composite_gradient_rows_give_way_when_the_block_structure_moves(monkeypatch):
+    """A coupling entry near nilpotent_blocks' threshold can put x0 + h and x0 - h into different block partitions; the
+    dual-number rows are then not defined and the model falls back to differencing the likelihood (no exception)."""
+    from pssgp import _backend
+    from pssgp.kernels import Matern32, Matern52
+    from pssgp.model import StateSpaceGP
+    m = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), Matern32(1.0, 1.0) + Matern52(0.5, 2.0), parallel=True)
+    rows, sizes = m._grad_rows_composite()
+    assert rows is not None and sizes == [2, 3] and len(rows) == 1 + len(m.trainable_parameters())
+    real = _backend.nilpotent_blocks
+    calls = []
+
+    def moving(F, *a, **k):
+        calls.append(1)
+        out = real(F, *a, **k)
+        return out if len(calls) < 3 else out[:1] + [(2, 1, out[1][2], out[1][3][:1, :1]), (3, 2, out[1][2], out[1][3][1:, 1:])]
+    monkeypatch.setattr(_backend, "nilpotent_blocks", moving)
+    assert m._grad_rows_composite() == (None, None)
+    assert m.kernel.kernels[0].variance == 1.0 and m.kernel.kernels[1].lengthscales == 2.0     # parameters restored

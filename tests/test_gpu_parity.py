@@ -359,6 +359,29 @@ def test_full_size_against_c_oracle(dtype, kname, n):
         assert np.all(got["sPs"][:, i, i] <= got["fPs"][:, i, i] * (1 + slack) + slack)
 
 
+@pytest.mark.parametrize("n", [4096, 32768, 1 << 20])
+@pytest.mark.parametrize("kname", ["m32", "m52", "rbf6"])
+def test_fp32_on_the_reference_grid(kname, n):
+    """The reference's own benchmark grid -- N equally spaced points on [0, 4] (its scripts use
+    np.linspace(0, 4, N)) -- in fp32 at the north star's tolerance.  At 2^20 points the spacing is 3.8e-6: F is the
+    identity to five digits and Q is a million times smaller than Pinf, which is where a float32 filter is most exposed.
+    Against the fp64 C oracle on the same (fp64-discretised) model."""
+    from pssgp.kernels import Matern32, Matern52, RBF
+    B = _gpu()
+    k = {"m32": lambda: Matern32(1., 1.), "m52": lambda: Matern52(1., 1.),
+         "rbf6": lambda: RBF(1., 1., order=6, balancing_iter=10)}[kname]()
+    sde = k.get_sde()
+    t = np.linspace(0.0, 4.0, n)
+    Fs, Qs = B.discretise(sde.F, sde.P0, t, 0.0)
+    ssm = (sde.P0, Fs, Qs, np.asarray(sde.H).reshape(1, -1), np.array([[0.1]]))
+    y = sample_series_fast(ssm, seed=n % 89, nan_frac=0.1)
+    cf, cP, cs, csP, cll = C.kfs(ssm, y, np.float64)
+    got = _gpu_all(ssm, y, np.float32)
+    assert relerr(got["fms"], cf) < TOL32 and relerr(got["fPs"], cP) < TOL32
+    assert relerr(got["sms"], cs) < TOL32 and relerr(got["sPs"], csP) < TOL32
+    assert abs(got["ll"][0] - cll) < TOL32 * abs(cll)
+
+
 @pytest.mark.parametrize("kname", ["m12", "m32", "m52"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,chunk", [(1, 0), (5, 0), (300, 0), (5000, 0), (256 * 16 * 3 + 77, 16), (256 * 8 * 2 + 9, 8),
