@@ -175,7 +175,8 @@ def dominant_symbol(slot, d, suf, family, segments, n_local):
     wc_names = {"k_filter_reduce": "pgps::wc::wc_reduce1/2 + wc_ks_filter levels", "k_filter_apply": "pgps::wc::wc_apply1",
                 "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels", "k_smoother_apply": "pgps::wc::wc_smooth1"}
     t = "double" if suf == "f64" else "float"
-    if suf == "f32" and ((family == 4 and 5 <= d <= 8) or (family == 0 and d == 8)):
+    quad_auto = d == 8 or (d == 6 and not segments and (n_local <= (3 << 17) or n_local >= (3 << 19)))
+    if suf == "f32" and ((family == 4 and 5 <= d <= 8) or (family == 0 and quad_auto)):
         return {"k_filter_reduce": f"pgps::qc::q_reduce1<{d}> + the scan of the chain totals (rc_scan_blk_f / rc_ks_filter<float, {d}>)",
                 "k_filter_apply": f"pgps::qc::q_apply1<{d}, ...>",
                 "k_smoother_reduce": f"the scan of the smoothing totals (rc_scan_blk_s / rc_ks_smoother<float, {d}>)",

@@ -416,6 +416,13 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
         // above the lane-chunk kernels' range (at d = 6 those still win in fp32: 0.71 against 0.85 ms at 2^20 steps)
         const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
         if (rc_ok && (ctx->family == 3 || ((ctx->family == 0 || ctx->family == 4) && d > PGPS_MAX_DIM_LANE))) return launch_scan_rc<float>(ctx, a, d, mode);
+        // d = 6, whole-series filter / filter + smoother: the quad-cooperative kernels are ahead of the lane-chunk ones
+        // except where the latter's geometry fits the chip exactly (same box, ms per pass, lane-chunk / quad:
+        // 2^14 0.212 / 0.171, 2^16 0.218 / 0.192, 2^17 0.230 / 0.218, 2^18 0.286 / 0.261, 2^19 0.395 / 0.398,
+        // 2^20 0.627 / 0.650, 2^21 1.266 / 1.217, 2^22 2.566 / 2.357)
+        if (ctx->family == 0 && d == 6 && (mode == MODE_PKF || mode == MODE_PKFS) && ctx->chunk == 0 && ctx->stage_g < 0 &&
+            (a.N <= (3L << 17) || a.N >= (3L << 19)) && a.N >= 64)
+            return launch_scan_rc<float>(ctx, a, d, mode);
         // quad-cooperative level-1 kernels under the row-cooperative driver: family 4 (fp32, 5 <= d <= 8)
         if (ctx->family == 4) {
             if (d < qc::kDimMin || d > qc::kDimMax || mode == MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;

@@ -241,6 +241,72 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned off, f
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, (int)off, 0, 0);
 }
 
+// NV 1 KiB pieces straight from global memory into LDS (LDS-DMA: buffer_load_dwordx4 ... lds -- lane t of piece v
+// lands at lds + v * 1024 + t * 16; out-of-range lanes land zeros), no staging registers.  The compiler does not count
+// these loads: whoever reads the slot waits for them itself (dma_wait_all: s_waitcnt vmcnt(0) -- hipcc's own waits can
+// only be stricter than it thinks, never laxer: it counts the younger operations it knows of, and there are at least
+// those).  M0 is restored.
+#define PGPS_DMA_NEXT "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#define PGPS_DMA_LD(n) "buffer_load_dwordx4 %[v" #n "], %[rs], 0 offen lds\n\t"
+template <int NV>
+__device__ __forceinline__ void dma_pieces(__amdgpu_buffer_rsrc_t rs, const unsigned (&vo)[NV], unsigned lds) {
+    static_assert(NV >= 1 && NV <= 8, "one to eight pieces per matrix");
+    unsigned keep;
+    constexpr const char* dummy = "";
+    (void)dummy;
+#define PGPS_DMA_HEAD "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 4\n\t"
+#define PGPS_DMA_TAIL "s_mov_b32 m0, %[keep]"
+#define PGPS_DMA_OUT [keep] "=&s"(keep)
+#define PGPS_DMA_IN [lds] "s"(lds), [rs] "s"(rs)
+    if constexpr (NV == 1) {
+        asm volatile(PGPS_DMA_HEAD PGPS_DMA_LD(0) PGPS_DMA_TAIL : PGPS_DMA_OUT : PGPS_DMA_IN, [v0] "v"(vo[0]) : "memory");
+    } else if constexpr (NV == 2) {
+        asm volatile(PGPS_DMA_HEAD PGPS_DMA_LD(0) PGPS_DMA_NEXT PGPS_DMA_LD(1) PGPS_DMA_TAIL
+                     : PGPS_DMA_OUT : PGPS_DMA_IN, [v0] "v"(vo[0]), [v1] "v"(vo[1]) : "memory");
+    } else if constexpr (NV == 3) {
+        asm volatile(PGPS_DMA_HEAD PGPS_DMA_LD(0) PGPS_DMA_NEXT PGPS_DMA_LD(1) PGPS_DMA_NEXT PGPS_DMA_LD(2) PGPS_DMA_TAIL
+                     : PGPS_DMA_OUT : PGPS_DMA_IN, [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]) : "memory");
+    } else if constexpr (NV == 4) {
+        asm volatile(PGPS_DMA_HEAD PGPS_DMA_LD(0) PGPS_DMA_NEXT PGPS_DMA_LD(1) PGPS_DMA_NEXT PGPS_DMA_LD(2) PGPS_DMA_NEXT
+                     PGPS_DMA_LD(3) PGPS_DMA_TAIL
+                     : PGPS_DMA_OUT : PGPS_DMA_IN, [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]) : "memory");
+    } else if constexpr (NV == 5) {
+        asm volatile(PGPS_DMA_HEAD PGPS_DMA_LD(0) PGPS_DMA_NEXT PGPS_DMA_LD(1) PGPS_DMA_NEXT PGPS_DMA_LD(2) PGPS_DMA_NEXT
+                     PGPS_DMA_LD(3) PGPS_DMA_NEXT PGPS_DMA_LD(4) PGPS_DMA_TAIL
+                     : PGPS_DMA_OUT : PGPS_DMA_IN, [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [v4] "v"(vo[4])
+                     : "memory");
+    } else if constexpr (NV == 6) {
+        asm volatile(PGPS_DMA_HEAD PGPS_DMA_LD(0) PGPS_DMA_NEXT PGPS_DMA_LD(1) PGPS_DMA_NEXT PGPS_DMA_LD(2) PGPS_DMA_NEXT
+                     PGPS_DMA_LD(3) PGPS_DMA_NEXT PGPS_DMA_LD(4) PGPS_DMA_NEXT PGPS_DMA_LD(5) PGPS_DMA_TAIL
+                     : PGPS_DMA_OUT : PGPS_DMA_IN, [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [v4] "v"(vo[4]),
+                       [v5] "v"(vo[5]) : "memory");
+    } else if constexpr (NV == 7) {
+        asm volatile(PGPS_DMA_HEAD PGPS_DMA_LD(0) PGPS_DMA_NEXT PGPS_DMA_LD(1) PGPS_DMA_NEXT PGPS_DMA_LD(2) PGPS_DMA_NEXT
+                     PGPS_DMA_LD(3) PGPS_DMA_NEXT PGPS_DMA_LD(4) PGPS_DMA_NEXT PGPS_DMA_LD(5) PGPS_DMA_NEXT PGPS_DMA_LD(6) PGPS_DMA_TAIL
+                     : PGPS_DMA_OUT : PGPS_DMA_IN, [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [v4] "v"(vo[4]),
+                       [v5] "v"(vo[5]), [v6] "v"(vo[6]) : "memory");
+    } else {
+        asm volatile(PGPS_DMA_HEAD PGPS_DMA_LD(0) PGPS_DMA_NEXT PGPS_DMA_LD(1) PGPS_DMA_NEXT PGPS_DMA_LD(2) PGPS_DMA_NEXT
+                     PGPS_DMA_LD(3) PGPS_DMA_NEXT PGPS_DMA_LD(4) PGPS_DMA_NEXT PGPS_DMA_LD(5) PGPS_DMA_NEXT PGPS_DMA_LD(6) PGPS_DMA_NEXT
+                     PGPS_DMA_LD(7) PGPS_DMA_TAIL
+                     : PGPS_DMA_OUT : PGPS_DMA_IN, [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [v4] "v"(vo[4]),
+                       [v5] "v"(vo[5]), [v6] "v"(vo[6]), [v7] "v"(vo[7]) : "memory");
+    }
+#undef PGPS_DMA_HEAD
+#undef PGPS_DMA_TAIL
+#undef PGPS_DMA_OUT
+#undef PGPS_DMA_IN
+}
+#undef PGPS_DMA_NEXT
+#undef PGPS_DMA_LD
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Level-1 kernels fetch their per-step inputs by LDS-DMA (two slots per matrix, alternating) instead of through NVW x 4
+// staging registers per matrix: at d = 11 fp64 that is what takes rc_reduce1 / rc_apply1 from 274 / 283 registers to
+// under 256, i.e. to two waves per SIMD.
+#ifndef PGPS_RC_DMA
+#define PGPS_RC_DMA 1
+#endif
+
 template <int D, typename Real>
 struct Io {
     static constexpr unsigned W = sizeof(Real);
@@ -424,6 +490,9 @@ struct Io {
 #pragma unroll
         for (int v = 0; v < NVW; ++v) r[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wg[v], 0, 0);
     }
+    __device__ __forceinline__ void wide_dma(const Real* base, const char* slot) const {
+        dma_pieces<NVW>(make_rsrc(base, span_m + 16u), wg, (unsigned)(size_t)slot);
+    }
     __device__ __forceinline__ void wide_commit(char* slot, const V4* r) const {
 #pragma unroll
         for (int v = 0; v < NVW; ++v) *reinterpret_cast<V4*>(slot + (v * 64 + tid) * 16) = r[v];
@@ -576,21 +645,36 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
     };
     // FAST: whole records as 16-byte pieces through LDS (Io, WIDE path), requested a whole step ahead
     using IOT = Io<D, Real>;
-    typename IOT::V4 pF[IOT::NVW], pQ[IOT::NVW];
+    constexpr bool DMA = PGPS_RC_DMA != 0;
+    typename IOT::V4 pF[DMA ? 1 : IOT::NVW], pQ[DMA ? 1 : IOT::NVW];
     Real ny = Real(0.0);
-    char* slotF = wslots;
-    char* slotQ = wslots + (IOT::SLOT + 16);
+    // slots: [F | Q] of even steps, [F | Q] of odd steps (DMA: the next step lands while this one is read)
+    constexpr int SL = IOT::SLOT + 16;
     auto prefetch = [&](int s) {
-        io.wide_load(a.Fs + (kw + s) * dd, pF);
-        if (!impq) io.wide_load(a.Qs + (kw + s) * dd, pQ);
+        if constexpr (DMA) {
+            char* sl = wslots + (s & 1) * 2 * SL;
+            io.wide_dma(a.Fs + (kw + s) * dd, sl);
+            if (!impq) io.wide_dma(a.Qs + (kw + s) * dd, sl + SL);
+        } else {
+            io.wide_load(a.Fs + (kw + s) * dd, pF);
+            if (!impq) io.wide_load(a.Qs + (kw + s) * dd, pQ);
+        }
         ny = a.ys[k0 + s];
     };
     auto take = [&](int s) {                    // step s's pieces into LDS, step s + 1's on their way, both layouts out
-        sync();
-        io.wide_commit(slotF, pF);
-        if (!impq) io.wide_commit(slotQ, pQ);
-        y = ny;
-        sync();
+        char* slotF = wslots + (DMA ? (s & 1) * 2 * SL : 0);
+        char* slotQ = slotF + SL;
+        if constexpr (DMA) {
+            dma_wait_all();                     // step s's pieces (requested a step ago) have landed
+            y = ny;
+            sync();
+        } else {
+            sync();
+            io.wide_commit(slotF, pF);
+            if (!impq) io.wide_commit(slotQ, pQ);
+            y = ny;
+            sync();
+        }
         PGPS_RC_PIN();
         prefetch(s + 1);                        // (one step beyond the chunk at the end: inside the series for a FAST wave)
         PGPS_RC_PIN();
@@ -645,12 +729,16 @@ template <typename Real, int D>
 __global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_reduce1(const RcArgsT<Real> a0) {
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    __shared__ __attribute__((aligned(16))) char wslots[2 * (Io<D, Real>::SLOT + 16)];
+    __shared__ __attribute__((aligned(16))) char wslots[(PGPS_RC_DMA ? 4 : 2) * (Io<D, Real>::SLOT + 16)];
     lds_clear(wslots, (int)sizeof(wslots));
     Real* patch = patch_init(tl, row);
     const RcArgsT<Real> a = model_view(a0);
+#ifdef PGPS_RC_FAST_ONLY              // (diagnostic: the FAST body's registers alone)
+    reduce1_body<Real, D, true>(a, patch, wslots, lane, row);
+#else
     if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<Real, D, true>(a, patch, wslots, lane, row);
     else reduce1_body<Real, D, false>(a, patch, wslots, lane, row);
+#endif
 }
 
 // ====================================================================================================

@@ -1900,10 +1900,11 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode, int
     rc::RcArgsT<Real> a{};
     a.N = sa.N;
     // quad-cooperative level-1 kernels: fp32, 5 <= d <= 8, filter and filter + smoother (family 4)
-    // (automatic at d = 8, where half of a 16-lane row idles: 0.94 against 1.10 ms at 2^20 steps; at d = 6 the lane-chunk
-    // kernels stay ahead, 0.63 against 0.78 ms, and odd d goes lane by lane -- profiles/r03_experiments.txt)
-    const bool quad = sizeof(Real) == 4 && (ctx->family == 4 || (ctx->family == 0 && d == 8)) && d >= qc::kDimMin &&
-                      d <= qc::kDimMax && mode != MODE_PKS && batch <= 1 && bs_model == 0 && !qslot;
+    // (automatic at d = 8, where half of a 16-lane row idles: 0.91 against 1.10 ms at 2^20 steps; odd d goes lane by
+    // lane and loses.  d = 6 reaches this driver only when the caller -- dispatch_scan in pgps_core.hip -- prefers it to
+    // the lane-chunk kernels: profiles/r03_experiments.txt)
+    const bool quad = sizeof(Real) == 4 && (ctx->family == 4 || (ctx->family == 0 && (d == 8 || d == 6))) &&
+                      d >= qc::kDimMin && d <= qc::kDimMax && mode != MODE_PKS && batch <= 1 && bs_model == 0 && !qslot;
     a.quad = quad ? 1 : 0;
     if (ctx->chunk > 0) {
         a.Lw = ctx->chunk;
