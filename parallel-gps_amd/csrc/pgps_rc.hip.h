@@ -219,6 +219,9 @@ struct GjStep {
 #ifndef PGPS_RC_WAVES
 #define PGPS_RC_WAVES 1
 #endif
+#ifndef PGPS_RC_WAVES_R
+#define PGPS_RC_WAVES_R PGPS_RC_WAVES           // rc_reduce1 alone
+#endif
 
 constexpr unsigned kOob = 0x7ffff000u;         // + any immediate offset: beyond every descriptor's range, no 32-bit wrap
 
@@ -648,13 +651,13 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
     constexpr bool DMA = PGPS_RC_DMA != 0;
     typename IOT::V4 pF[DMA ? 1 : IOT::NVW], pQ[DMA ? 1 : IOT::NVW];
     Real ny = Real(0.0);
-    // slots: [F | Q] of even steps, [F | Q] of odd steps (DMA: the next step lands while this one is read)
+    // slots: [F | Q].  DMA: the next step's pieces are requested into the same slots as soon as this step's have been
+    // read out of them (lgkmcnt(0): the reads are in registers) -- the whole step's arithmetic is still ahead of them
     constexpr int SL = IOT::SLOT + 16;
     auto prefetch = [&](int s) {
         if constexpr (DMA) {
-            char* sl = wslots + (s & 1) * 2 * SL;
-            io.wide_dma(a.Fs + (kw + s) * dd, sl);
-            if (!impq) io.wide_dma(a.Qs + (kw + s) * dd, sl + SL);
+            io.wide_dma(a.Fs + (kw + s) * dd, wslots);
+            if (!impq) io.wide_dma(a.Qs + (kw + s) * dd, wslots + SL);
         } else {
             io.wide_load(a.Fs + (kw + s) * dd, pF);
             if (!impq) io.wide_load(a.Qs + (kw + s) * dd, pQ);
@@ -662,25 +665,32 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
         ny = a.ys[k0 + s];
     };
     auto take = [&](int s) {                    // step s's pieces into LDS, step s + 1's on their way, both layouts out
-        char* slotF = wslots + (DMA ? (s & 1) * 2 * SL : 0);
+        char* slotF = wslots;
         char* slotQ = slotF + SL;
         if constexpr (DMA) {
             dma_wait_all();                     // step s's pieces (requested a step ago) have landed
             y = ny;
             sync();
+            io.template lds_get<false>(slotF, Fc);
+            io.template lds_get<true>(slotF, Fr);
+            if (!impq) io.template lds_get<false>(slotQ, Q);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PGPS_RC_PIN();
+            prefetch(s + 1);                    // (one step beyond the chunk at the end: inside the series for a FAST wave)
+            PGPS_RC_PIN();
         } else {
             sync();
             io.wide_commit(slotF, pF);
             if (!impq) io.wide_commit(slotQ, pQ);
             y = ny;
             sync();
+            PGPS_RC_PIN();
+            prefetch(s + 1);
+            PGPS_RC_PIN();
+            io.template lds_get<false>(slotF, Fc);
+            io.template lds_get<true>(slotF, Fr);
+            if (!impq) io.template lds_get<false>(slotQ, Q);
         }
-        PGPS_RC_PIN();
-        prefetch(s + 1);                        // (one step beyond the chunk at the end: inside the series for a FAST wave)
-        PGPS_RC_PIN();
-        io.template lds_get<false>(slotF, Fc);
-        io.template lds_get<true>(slotF, Fr);
-        if (!impq) io.template lds_get<false>(slotQ, Q);
     };
     if constexpr (FAST) { io.init_wide(row, a.Lw, (unsigned)IOT::SLOT); prefetch(0); }
     else load(0);
@@ -726,10 +736,10 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
 }
 
 template <typename Real, int D>
-__global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_reduce1(const RcArgsT<Real> a0) {
+__global__ __launch_bounds__(64, PGPS_RC_WAVES_R) void rc_reduce1(const RcArgsT<Real> a0) {
     __shared__ Real tl[4 * kPatch];
     const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
-    __shared__ __attribute__((aligned(16))) char wslots[(PGPS_RC_DMA ? 4 : 2) * (Io<D, Real>::SLOT + 16)];
+    __shared__ __attribute__((aligned(16))) char wslots[2 * (Io<D, Real>::SLOT + 16)];
     lds_clear(wslots, (int)sizeof(wslots));
     Real* patch = patch_init(tl, row);
     const RcArgsT<Real> a = model_view(a0);
@@ -737,7 +747,11 @@ __global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_reduce1(const RcArgsT<Re
     reduce1_body<Real, D, true>(a, patch, wslots, lane, row);
 #else
     if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<Real, D, true>(a, patch, wslots, lane, row);
+#ifdef PGPS_RC_SKIP_EDGE               // (timing experiment: what the kernel costs without its edge waves; results are wrong)
+    else return;
+#else
     else reduce1_body<Real, D, false>(a, patch, wslots, lane, row);
+#endif
 #endif
 }
 
@@ -987,8 +1001,16 @@ __global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_apply1(const RcArgsT<Rea
     lds_clear(wslots, (int)sizeof(wslots));
     Real* patch = patch_init(tl, row);
     const RcArgsT<Real> a = model_view(a0);
+#ifdef PGPS_RC_FAST_ONLY
+    apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, wslots, lane, row);
+#else
     if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, wslots, lane, row);
+#ifdef PGPS_RC_SKIP_EDGE               // (timing experiment: what the kernel costs without its edge waves; results are wrong)
+    else return;
+#else
     else apply1_body<Real, D, SMOOTH, false, IMPQS, STORE>(a, patch, wslots, lane, row);
+#endif
+#endif
 }
 
 // ====================================================================================================
@@ -1197,7 +1219,11 @@ __global__ __launch_bounds__(64) void rc_smooth1(const RcArgsT<Real> a) {
     lds_clear(wslots, (int)sizeof(wslots));
     Real* patch = patch_init(tl, row);
     if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<Real, D, true, PROJ>(a, patch, wslots, lane, row);
+#ifdef PGPS_RC_SKIP_EDGE               // (timing experiment: what the kernel costs without its edge waves; results are wrong)
+    else return;
+#else
     else smooth1_body<Real, D, false, PROJ>(a, patch, wslots, lane, row);
+#endif
 }
 
 // ====================================================================================================
