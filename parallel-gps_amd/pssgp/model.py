@@ -172,7 +172,10 @@ class StateSpaceGP:
                 # series and query grid resident on the device (merged once): the call sends the model, K means and
                 # variances come back
                 ser.set_queries(squeezed_Xnew)
-                mean, var, _ = ser.gp_predict(self._packed_fused(fused), self.noise_variance)
+                mean, var, ll = ser.gp_predict(self._packed_fused(fused), self.noise_variance)
+                # (the filter pass of the prediction IS the training log-likelihood -- the query rows are missing
+                # observations: an objective evaluated next at the same setting costs nothing)
+                self._ll_memo = (self._param_key(), self.noise_variance, ser, np.float64(ll))
                 return mean[:, None], var[:, None]
         if (fused is not None and squeezed_Xnew.size > 0 and np.all(np.diff(squeezed_ts) >= 0)
                 and np.all(np.diff(squeezed_Xnew) >= 0)):
@@ -219,6 +222,9 @@ class StateSpaceGP:
             from . import _backend
             ser = self._device_series() if ts.dtype == np.float64 else None
             if ser is not None:
+                memo = getattr(self, "_ll_memo", None)
+                if memo is not None and memo[2] is ser and memo[1] == self.noise_variance and memo[0] == self._param_key():
+                    return memo[3]
                 return np.float64(ser.gp_ll(self._packed_fused(fused), self.noise_variance))
             sde, form = fused
             return _backend.gp(form, sde.P0, sde.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))["ll"]

@@ -40,6 +40,23 @@ def main():
         med, mn = bench(fn)
         out.append(f"{label} {med:7.1f} ({mn:7.1f})")
     print(f"c1 Matern32 N={n} K={k}:  " + "   ".join(out), flush=True)
+    # the same with a NEW hyper-parameter setting at every call, as an optimiser or sampler makes them: the SDE is rebuilt
+    # (get_sde, closed-form discretisation form, packing) and nothing is reused from the call before
+    state = {"i": 0}
+
+    def fresh(fn):
+        def run():
+            state["i"] += 1
+            gp.kernel.lengthscales = 0.5 * (1.0 + 1e-9 * state["i"])
+            return fn()
+        return run
+    out = []
+    for label, fn in (("ll", gp.maximum_log_likelihood_objective), ("predict_f", lambda: gp.predict_f(tq)),
+                      ("predict_f then ll", lambda: (gp.predict_f(tq), gp.maximum_log_likelihood_objective())),
+                      ("ll+grad", gp.log_likelihood_and_grad)):
+        med, mn = bench(fresh(fn))
+        out.append(f"{label} {med:7.1f} ({mn:7.1f})")
+    print(f"   new setting every call:   " + "   ".join(out), flush=True)
     kernels = (("Matern32", lambda: Matern32(1., 0.5)), ("Matern52", lambda: Matern52(1., 0.5)),
                ("RBF6", lambda: RBF(1., 0.5, order=6, balancing_iter=5)))
     for name, mk in kernels[:1] if quick else kernels:
