@@ -504,7 +504,8 @@ def main():
             n_rccl, r_rccl = ctx.comm_count()       # what RCCL itself says (ncclCommCount / ncclCommUserRank)
             if (n_rccl, r_rccl) != (world, rank):
                 raise SystemExit(f"RCCL communicator reports {n_rccl} ranks / rank {r_rccl}, expected {world} / {rank}")
-            rccl_info = {"in_library": True, "ranks": n_rccl, "allgather_us": allgather_latency(ctx, d, dtype_t, dev, stream, world)}
+            rccl_info = {"in_library": True, "ranks": n_rccl, "allgather_us": allgather_latency(ctx, d, dtype_t, dev, stream, world),
+                         "library": _backend.Context.comm_library()}
 
             def step():
                 seg.pkfs(n_local, *ptrs)

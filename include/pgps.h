@@ -358,6 +358,9 @@ int pgps_comm_init(pgps_ctx* ctx, const void* id, int rank, int nranks);
 int pgps_comm_destroy(pgps_ctx* ctx);
 int pgps_comm_info(pgps_ctx* ctx, int* rank, int* nranks);      /* nranks = 0: no communicator */
 int pgps_comm_count(pgps_ctx* ctx, int* nranks, int* rank);     /* as RCCL reports them (ncclCommCount / ncclCommUserRank); rank may be NULL */
+/* RCCL is loaded on first use of a pgps_comm_* call (the copy already in the process, else the loader's librccl.so.1):
+ * buf <- what was loaded, or why nothing was (PGPS_E_COMM).  A context without a communicator never needs RCCL. */
+int pgps_comm_library(char* buf, size_t n);
 int pgps_comm_allgather_dev(pgps_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
 int pgps_pkfs_seg_dev_f64(pgps_ctx*, long N, int d, const double* P0, const double* Fs, const double* Qs, const double* H,
                           double R, const double* ys, double* fms, double* fPs, double* sms, double* sPs, double* ll);

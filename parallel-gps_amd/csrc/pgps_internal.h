@@ -4,12 +4,12 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <string>
 #include <vector>
 
 #include "../../include/pgps.h"
+#include "pgps_dyn.h"
 
 struct DevBuf {
     void* p = nullptr;
@@ -58,8 +58,8 @@ struct pgps_ctx {
 // roctx range named after the reference's tf.name_scope of the same work (pssgp/kalman/parallel.py:122 "parallel_filter",
 // pssgp/model.py:35 "merge_sorted", model.py:87 "make_model"): visible in `rocprofv3 --marker-trace`, a no-op otherwise
 struct RoctxRange {
-    explicit RoctxRange(const char* name) { roctxRangePushA(name); }
-    ~RoctxRange() { roctxRangePop(); }
+    explicit RoctxRange(const char* name) { pgps::dyn::range_push(name); }
+    ~RoctxRange() { pgps::dyn::range_pop(); }
     RoctxRange(const RoctxRange&) = delete;
     RoctxRange& operator=(const RoctxRange&) = delete;
 };

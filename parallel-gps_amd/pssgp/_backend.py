@@ -73,6 +73,8 @@ def _declare(lib):
     lib.pgps_comm_info.argtypes = [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     if hasattr(lib, "pgps_comm_count"):         # (absent from libraries built before round 3: A/B runs load those)
         lib.pgps_comm_count.argtypes = [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    if hasattr(lib, "pgps_comm_library"):
+        lib.pgps_comm_library.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.pgps_comm_allgather_dev.argtypes = [P, P, P, ctypes.c_size_t]
     for suf, real in (("f64", c_double), ("f32", c_float)):
         for dev in ("", "_dev"):
@@ -257,6 +259,19 @@ class Context:
                   "pgps_memcpy_d2h")
 
     # -- the communicator of a series sharded over GPUs (RCCL, owned by the context) -------------
+    @staticmethod
+    def comm_library():
+        """Which RCCL libpgps uses -- loaded on first use: the copy already in the process (torch's, when
+        torch.distributed's nccl backend is there) or the loader's librccl.so.1 -- or, prefixed with "unavailable: ", why
+        there is none."""
+        lib = load_library()
+        if not hasattr(lib, "pgps_comm_library"):
+            return "linked at build time"
+        buf = ctypes.create_string_buffer(512)
+        code = lib.pgps_comm_library(buf, 512)
+        text = buf.value.decode(errors="replace")
+        return text if code == 0 else "unavailable: " + text
+
     @staticmethod
     def comm_unique_id():
         """128 opaque bytes from one rank, to be handed to every rank's comm_init (any transport: a file, MPI, a

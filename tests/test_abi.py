@@ -104,3 +104,24 @@ def test_generated_asm_header_is_current():
             # elimination's own accumulator (read and written by the same instruction, after its last DPP use)
             assert src0 not in written or src0 == dst, ln
             written.add(dst)
+
+
+def test_rccl_and_roctx_are_loaded_on_first_use_not_linked():
+    """libpgps.so must load where neither RCCL nor roctx is installed (a single-GPU user), and a process that already
+    carries a copy of RCCL (torch.distributed's nccl backend bundles one) must keep using that one: no DT_NEEDED entry
+    for either library, and pgps_comm_library says which copy the loader picked."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "parallel-gps_amd", "pssgp", "libpgps.so")
+    needed = subprocess.run(["readelf", "-d", so], stdout=subprocess.PIPE, text=True, check=True).stdout
+    needed = [ln for ln in needed.splitlines() if "NEEDED" in ln]
+    assert needed and not any("rccl" in ln or "roctx" in ln for ln in needed), needed
+    code = ("import sys; sys.path.insert(0, %r); from pssgp import _backend as B; print(B.Context.comm_library())"
+            % os.path.join(root, "parallel-gps_amd"))
+    alone = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+    assert alone.startswith("librccl") or alone.startswith("/opt/rocm") or alone.startswith("unavailable"), alone
+    with_torch = subprocess.run([sys.executable, "-c", "import torch, torch.distributed; " + code], stdout=subprocess.PIPE,
+                                text=True, check=True).stdout.strip()
+    assert "already in the process" in with_torch, with_torch         # torch's bundled librccl.so.1, not a second copy
