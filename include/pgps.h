@@ -86,8 +86,14 @@ int pgps_set_dma(pgps_ctx* ctx, int mode);
 int pgps_set_rc_scan(pgps_ctx* ctx, int mode);
 /* Fused (pgps_gp_*) calls of short series -- the reference's own lengths, N = 200 .. 10^4 per evaluation
  * (pssgp/experiments/toy_models/mcmc.py:55) -- run as ONE workgroup in ONE launch (reduce, scan, Kalman pass, smoother,
- * projection) up to max_steps steps: -1 = automatic (8192), 0 = never, n > 0 = up to n steps. */
+ * projection) up to max_steps steps: -1 = automatic (2048: at 4096 + 1024 steps the three launches are ahead again), 0 = never,
+ * n > 0 = up to n steps. */
 int pgps_set_one_launch(pgps_ctx* ctx, int max_steps);
+/* pgps_gp_ll_grad_* at d <= 2: series up to max_steps take ONE derivative direction per model, the directions side by side
+ * in the same launches (a Dual<1> scan tree is less than half of a Dual<3> one, and for a short series the tree's latency
+ * is the whole cost); longer ones carry all directions in one dual number (the primal arithmetic is shared).
+ * -1 = automatic (32768 steps), 0 = never.  d = 3 always runs one direction per model. */
+int pgps_set_grad_pack(pgps_ctx* ctx, long max_steps);
 /* What a lane-chunk call (or one rank's segment) of N steps at state dimension d <= PGPS_MAX_DIM_LANE runs with: lanes per
  * workgroup (128 / 256), steps per lane, workgroups -- after pgps_set_block / pgps_set_chunk. */
 int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* steps_per_lane, int* workgroups);

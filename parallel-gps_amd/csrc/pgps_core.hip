@@ -170,6 +170,12 @@ extern "C" int pgps_set_one_launch(pgps_ctx* ctx, int max_steps) {
     return PGPS_OK;
 }
 
+extern "C" int pgps_set_grad_pack(pgps_ctx* ctx, long max_steps) {
+    if (!ctx || max_steps < -1) return PGPS_E_INVALID;
+    ctx->grad_pack = max_steps;
+    return PGPS_OK;
+}
+
 extern "C" int pgps_set_rc_scan(pgps_ctx* ctx, int mode) {
     if (!ctx || mode < -1 || mode > 1) return PGPS_E_INVALID;
     ctx->rc_scan = mode;

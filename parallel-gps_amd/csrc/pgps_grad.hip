@@ -59,47 +59,64 @@ static GradModel<NP> make_model(int d, int np, int p0, const double* model, long
     return m;
 }
 
-// model: (1 + np) consecutive blocks, block 0 = values, block p = d/dtheta_p, each
-//   [lam | N1 (d*d) | Pinf (d*d) | H (d) | R]
-// out_dev: 1 + np doubles (d <= 2) -- for d = 3, 2 * np doubles of scratch follow: pass p writes
-// (ll, d ll / d theta_p) at out_dev[2 p] and a last tiny kernel compacts them.
-int launch_grad(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts, double t0,
-                const double* ys, double* out_dev) {
-    if (np < 1 || np > kNP) return PGPS_E_INVALID;
-    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
-    if (d == 1) return launch_grad_d<kNP, 1>(ctx, make_model<kNP>(d, np, 0, model, N, ts, t0, ys, out_dev));
-    if (d == 2) return launch_grad_d<kNP, 2>(ctx, make_model<kNP>(d, np, 0, model, N, ts, t0, ys, out_dev));
-    // d = 3: one direction per model, the np models side by side in the same three launches (grid.y): at the
-    // reference's series lengths one workgroup's scan tree on duals is the whole cost (64 us), not its length
+// One direction per model, the np models side by side in the same three launches (grid.y): where a series is short, one
+// workgroup's scan tree on duals is the whole cost -- its latency, not its length -- and a Dual<1> tree is less than half
+// of a Dual<3> one.  Pass p writes (ll, d ll / d theta_p) into context scratch; a last tiny kernel compacts them.
+template <int D>
+static int launch_grad_pack(pgps_ctx* ctx, long N, int np, const double* model, const double* ts, double t0, const double* ys,
+                            double* out_dev) {
     using T = Dual<1>;
-    double* scratch = out_dev + 1 + np;
     GradPack<1> pack{};
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int p = 0; p < 3; ++p) pack.m[p] = make_model<1>(d, np, p < np ? p : 0, model, N, ts, t0, ys, scratch + 2 * (p < np ? p : 0));
-    GradModel<1>& m0 = pack.m[0];
-    geometry(ctx, m0.N, &m0.Lc, &m0.nblocks);
-    m0.nlanes = (long)m0.nblocks * kBlock;
-    const size_t nb = (size_t)m0.nblocks, nl = (size_t)m0.nlanes;
+    long nlanes = 0;
+    int Lc = 0, nblocks = 0;
+    geometry(ctx, N, &Lc, &nblocks);
+    nlanes = (long)nblocks * kBlock;
+    const size_t nb = (size_t)nblocks, nl = (size_t)nlanes;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t s_spine = up(nb * Dim<3>::NFILT * sizeof(T)), s_lpre = up(nl * Dim<3>::NFILT * sizeof(T)), s_ll = up(nb * sizeof(T));
+    const size_t s_spine = up(nb * Dim<D>::NFILT * sizeof(T)), s_lpre = up(nl * Dim<D>::NFILT * sizeof(T)), s_ll = up(nb * sizeof(T));
     const size_t per = s_spine + s_lpre + s_ll;
-    int rc = ensure(ctx, ctx->ws, per * (size_t)np);
+    int rc = ensure(ctx, ctx->ws, per * (size_t)np + 256);
     if (rc) return rc;
     char* base = (char*)ctx->ws.p;
+    double* scratch = (double*)(base + per * (size_t)np);
+    for (int p = 0; p < 3; ++p) pack.m[p] = make_model<1>(D, np, p < np ? p : 0, model, N, ts, t0, ys, scratch + 2 * (p < np ? p : 0));
     for (int p = 0; p < np; ++p) {
         GradModel<1>& m = pack.m[p];
-        m.Lc = m0.Lc; m.nblocks = m0.nblocks; m.nlanes = m0.nlanes;
+        m.Lc = Lc; m.nblocks = nblocks; m.nlanes = nlanes;
         m.spine = (T*)(base + per * p);
         m.lpre = (T*)(base + per * p + s_spine);
         m.llpart = (T*)(base + per * p + s_spine + s_lpre);
     }
-    const dim3 grid(m0.nblocks, np), block(kBlock);
-    timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_grad_reduce_pack<1, 3>, grid, block, 0, pack);
-    timed_launch(ctx, PGPS_K_FILTER_APPLY, k_grad_apply_pack<1, 3>, grid, block, 0, pack);
+    const dim3 grid(nblocks, np), block(kBlock);
+    timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_grad_reduce_pack<1, D>, grid, block, 0, pack);
+    timed_launch(ctx, PGPS_K_FILTER_APPLY, k_grad_apply_pack<1, D>, grid, block, 0, pack);
     timed_launch(ctx, PGPS_K_LL_FINALIZE, k_grad_finalize_pack<1>, dim3(1, np), block, 0, pack);
     k_grad_compact<<<1, 64, 0, ctx->stream>>>(scratch, np, out_dev);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
+}
+
+// Series up to this many steps take one direction per model at d <= 2 as well (PGPS_GRAD_PACK_MAX; d = 3 always does)
+#ifndef PGPS_GRAD_PACK_MAX
+#define PGPS_GRAD_PACK_MAX (1L << 15)
+#endif
+
+// model: (1 + np) consecutive blocks, block 0 = values, block p = d/dtheta_p, each
+//   [lam | N1 (d*d) | Pinf (d*d) | H (d) | R]
+// out_dev: 1 + np doubles
+int launch_grad(pgps_ctx* ctx, long N, int d, int np, const double* model, const double* ts, double t0,
+                const double* ys, double* out_dev) {
+    if (np < 1 || np > kNP) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    const long pack_max = ctx->grad_pack >= 0 ? ctx->grad_pack : PGPS_GRAD_PACK_MAX;
+    if (d == 3) return launch_grad_pack<3>(ctx, N, np, model, ts, t0, ys, out_dev);
+    if (N <= pack_max) {
+        if (d == 1) return launch_grad_pack<1>(ctx, N, np, model, ts, t0, ys, out_dev);
+        return launch_grad_pack<2>(ctx, N, np, model, ts, t0, ys, out_dev);
+    }
+    if (d == 1) return launch_grad_d<kNP, 1>(ctx, make_model<kNP>(d, np, 0, model, N, ts, t0, ys, out_dev));
+    return launch_grad_d<kNP, 2>(ctx, make_model<kNP>(d, np, 0, model, N, ts, t0, ys, out_dev));
 }
 
 }  // namespace pgps

@@ -27,6 +27,7 @@ struct pgps_ctx {
     int lookback_window = 256;          // tiles per look-back window (<= 256; small values are for tests)
     int block = 0;                      // lane-chunk workgroups: 0 = auto, 128 / 256 lanes (pgps_set_block)
     int one_launch = -1;                // fused (pgps_gp_*) calls of short series in ONE launch: -1 = auto (N <= kOneLaunchAuto), 0 = never, n > 0 = up to n steps
+    long grad_pack = -1;                // gradient at d <= 2: one direction per model up to this many steps (-1 = automatic, 0 = never)
     int rc_scan = -1;                   // scans of the chain totals (row- / quad-cooperative families): -1 = auto, 0 = one launch per Kogge-Stone level, 1 = blocked (pgps_set_rc_scan)
     int dma = -1;                       // LDS-DMA ring in the Kalman pass (d = 2 fp64, 128-lane build): -1 = auto, 0 = off, 1 = on
     int family = 0;                     // 0 = auto (lane-chunk d <= 6; row-cooperative fp64 d <= 16; else wave-cooperative), 1 = lane, 2 = wave, 3 = row
@@ -81,7 +82,10 @@ namespace pgps {
 constexpr int kBlock = PGPS_BLOCK;      // lanes per workgroup (experiments: make EXTRA=-DPGPS_BLOCK=128 ...)
 constexpr int kWave = 64;
 constexpr int kWaves = kBlock / kWave;
-constexpr int kOneLaunchAuto = 8192;    // fused path: series up to this length run as one workgroup, one launch (pgps_set_one_launch)
+// fused path: series up to this length run as one workgroup, one launch (pgps_set_one_launch).  c1 (4096 + 1024 steps):
+// one launch 82 us per predict_f against 61 us for the three launches, 40 against 38 us for the log-likelihood; N = 1000:
+// 57 against 89 us -- profiles/r03_small_n_latency.txt
+constexpr int kOneLaunchAuto = 2048;
 
 int ensure(pgps_ctx* ctx, DevBuf& b, size_t bytes);
 // all-gather of `bytes` per rank on the context's stream through the context's RCCL communicator (pgps_comm.hip)

@@ -73,6 +73,8 @@ def _declare(lib):
     lib.pgps_comm_info.argtypes = [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     if hasattr(lib, "pgps_comm_count"):         # (absent from libraries built before round 3: A/B runs load those)
         lib.pgps_comm_count.argtypes = [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    if hasattr(lib, "pgps_set_grad_pack"):
+        lib.pgps_set_grad_pack.argtypes = [P, c_long]
     if hasattr(lib, "pgps_comm_library"):
         lib.pgps_comm_library.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.pgps_comm_allgather_dev.argtypes = [P, P, P, ctypes.c_size_t]
@@ -180,6 +182,11 @@ class Context:
         """Fused calls of short series in ONE launch up to max_steps steps: -1 automatic (8192), 0 never."""
         if hasattr(self.lib, "pgps_set_one_launch"):
             check(self, self.lib.pgps_set_one_launch(self.handle, int(max_steps)), "pgps_set_one_launch")
+
+    def set_grad_pack(self, max_steps):
+        """Gradient calls at d <= 2: one derivative direction per model up to this many steps (-1 automatic, 0 never)."""
+        if hasattr(self.lib, "pgps_set_grad_pack"):
+            check(self, self.lib.pgps_set_grad_pack(self.handle, int(max_steps)), "pgps_set_grad_pack")
 
     def set_rc_scan(self, mode):
         """Scans of the chain totals (row- / quad-cooperative families): -1 automatic, 0 one launch per level, 1 blocked."""
@@ -678,8 +685,10 @@ class Series:
         """The fused model as the contiguous float64 arrays the calls take: (lam, N1, N2, Pinf, H, d)."""
         lam, N1, N2 = form
         d = N1.shape[0]
-        return (float(lam), _prep(N1, np.float64), _prep(N2, np.float64), _prep(Pinf, np.float64, (d, d)),
-                _prep(H, np.float64, (d,)), d)
+        c = lambda a, shape: a if (type(a) is np.ndarray and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == shape) \
+            else _prep(a, np.float64, shape)
+        Hv = np.asarray(H, np.float64).reshape(-1)
+        return (float(lam), c(N1, (d, d)), c(N2, (d, d)), c(Pinf, (d, d)), c(Hv, (d,)), d)
 
     def gp_ll(self, packed, R):
         lam, N1, N2, Pinf, H, d = packed
@@ -771,14 +780,15 @@ def gp_ll_batch(models, ts, ys, t0=0.0, device=0):
 def pack_grad_model(blocks):
     """(1 + np, 1 + 2 d^2 + d + 1) array [lam | N1 | Pinf | H | R] per block, as pgps_gp_ll_grad_* reads it."""
     d = np.asarray(blocks[0][1]).shape[0]
-    rows = []
-    for lam, N1, Pinf, H, R in blocks:
-        rows.append(np.concatenate([[float(lam)], np.asarray(N1, np.float64).reshape(-1),
-                                    np.asarray(Pinf, np.float64).reshape(-1), np.asarray(H, np.float64).reshape(-1),
-                                    [float(R)]]))
-    model = np.ascontiguousarray(np.stack(rows), dtype=np.float64)
-    if model.shape[1] != 1 + 2 * d * d + d + 1:
-        raise ValueError("malformed model block")
+    dd = d * d
+    model = np.empty((len(blocks), 2 + 2 * dd + d), np.float64)
+    for r, (lam, N1, Pinf, H, R) in enumerate(blocks):
+        row = model[r]
+        row[0] = lam
+        row[1:1 + dd] = np.asarray(N1, np.float64).reshape(-1)          # (a shape mismatch raises here)
+        row[1 + dd:1 + 2 * dd] = np.asarray(Pinf, np.float64).reshape(-1)
+        row[1 + 2 * dd:1 + 2 * dd + d] = np.asarray(H, np.float64).reshape(-1)
+        row[-1] = R
     return model, d, len(blocks) - 1
 
 

@@ -122,6 +122,60 @@ class StateSpaceGP:
         self._packed_memo = (fused, packed)
         return packed
 
+    def _matern_forms(self):
+        """(sde-like, (lam, N1, N2)) of a SINGLE Matern-1/2, -3/2 or -5/2 kernel without building its SDE: what a new
+        hyper-parameter setting costs on the host in an optimiser loop (get_sde + stationarity check + nilpotent form:
+        ~55 us for Matern-3/2, ~130 us for Matern-5/2 with its balancing sweep and Lyapunov solve) becomes a few scalar
+        operations.  With lam = sqrt(2 nu) / l:
+          Matern-1/2:  F = -lam, Pinf = s2, H = 1;
+          Matern-3/2:  the companion form itself (matern32.py:10-28): N = [[lam, 1], [-lam^2, -lam]], N^2 = 0,
+                       Pinf = diag(s2, lam^2 s2), H = (1, 0);
+          Matern-5/2:  balanced (matern52.py): the balancing iteration commutes with the lengthscale's time scaling, so
+                       F = lam F1, Pinf = s2 P1, H = H1 with (F1, P1, H1) the SDE at lam = 1, s2 = 1 -- built ONCE per model
+                       by get_sde() and checked against get_sde() at the first setting it is used for (1e-10); a kernel
+                       for which that check fails keeps the general path.
+        None for anything else."""
+        k = self.kernel
+        name = type(k).__name__
+        if name not in ("Matern12", "Matern32", "Matern52") or getattr(k, "kernels", None):
+            return None
+        if getattr(self, "_matern_fast", None) is False:
+            return None
+        s2, ell = float(k.variance), float(k.lengthscales)
+        if not (s2 > 0.0 and ell > 0.0):
+            return None
+        from types import SimpleNamespace
+        if name == "Matern12":
+            lam = 1.0 / ell
+            return (SimpleNamespace(P0=np.array([[s2]]), H=np.array([[1.0]])), (lam, np.zeros((1, 1)), np.zeros((1, 1))))
+        if name == "Matern32":
+            lam = np.sqrt(3.0) / ell
+            return (SimpleNamespace(P0=np.array([[s2, 0.0], [0.0, lam * lam * s2]]), H=np.array([[1.0, 0.0]])),
+                    (lam, np.array([[lam, 1.0], [-lam * lam, -lam]]), np.zeros((2, 2))))
+        unit = getattr(self, "_matern52_unit", None)
+        if unit is None:
+            from . import _backend
+            sde1 = type(k)(1.0, np.sqrt(5.0), **({"balancing_iter": k._balancing_iter} if hasattr(k, "_balancing_iter") else {})).get_sde()
+            form1 = _backend.nilpotent_form(sde1.F)
+            if form1 is None or abs(form1[0] - 1.0) > 1e-12:
+                self._matern_fast = False
+                return None
+            unit = self._matern52_unit = (np.asarray(sde1.P0, np.float64), np.asarray(sde1.H, np.float64).reshape(1, -1),
+                                          np.asarray(form1[1], np.float64), np.asarray(form1[2], np.float64))
+        lam = np.sqrt(5.0) / ell
+        out = (SimpleNamespace(P0=s2 * unit[0], H=unit[1]), (lam, lam * unit[2], (lam * lam) * unit[3]))
+        if getattr(self, "_matern_fast", None) is None:            # first use: against the kernel's own get_sde()
+            from . import _backend
+            sde = k.get_sde()
+            form = _backend.nilpotent_form(sde.F)
+            close = lambda a, b: np.max(np.abs(np.asarray(a) - np.asarray(b))) <= 1e-10 * (1.0 + np.max(np.abs(np.asarray(b))))
+            self._matern_fast = bool(form is not None and close(out[1][0], form[0]) and close(out[1][1], form[1])
+                                     and close(out[1][2], form[2]) and close(out[0].P0, sde.P0)
+                                     and close(out[0].H, np.asarray(sde.H).reshape(1, -1)))
+            if not self._matern_fast:
+                return None
+        return out
+
     def _device_forms_uncached(self):
         """(fused, lti) from ONE get_sde() (for composite kernels that call is the host cost of an evaluation):
         `fused` = (sde, (lam, N1, N2)) when the SDE has the closed-form discretisation of the fused HIP path
@@ -132,6 +186,9 @@ class StateSpaceGP:
         arithmetic than fp32 (N, d, d) arrays."""
         if not self.parallel:
             return None, None
+        fast = self._matern_forms()
+        if fast is not None:
+            return fast, None
         from . import _backend
         sde = self.kernel.get_sde()
         F, P0 = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64)

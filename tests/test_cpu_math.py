@@ -219,3 +219,28 @@ def test_composite_gradient_rows_give_way_when_the_block_structure_moves(monkeyp
     monkeypatch.setattr(_backend, "nilpotent_blocks", moving)
     assert m._grad_rows_composite() == (None, None)
     assert m.kernel.kernels[0].variance == 1.0 and m.kernel.kernels[1].lengthscales == 2.0     # parameters restored
+
+
+@pytest.mark.parametrize("kname", ["m12", "m32", "m52"])
+def test_matern_forms_without_building_the_sde(kname):
+    """The model's fast path for a single Matern kernel (a new hyper-parameter setting in an optimiser loop: scalar
+    formulas instead of get_sde + stationarity check + nilpotent form) gives what the general path gives."""
+    from pssgp import _backend
+    from pssgp.kernels import Matern12, Matern32, Matern52
+    from pssgp.model import StateSpaceGP
+    cls = {"m12": Matern12, "m32": Matern32, "m52": Matern52}[kname]
+    rng = np.random.default_rng(5)
+    m = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), cls(1.0, 1.0), noise_variance=0.1, parallel=True)
+    for _ in range(5):
+        m.kernel.variance, m.kernel.lengthscales = float(rng.uniform(0.1, 5.0)), float(rng.uniform(0.02, 3.0))
+        fast = m._matern_forms()
+        assert fast is not None
+        sde = m.kernel.get_sde()
+        form = _backend.nilpotent_form(sde.F)
+        for a, b in ((fast[1][0], form[0]), (fast[1][1], form[1]), (fast[1][2], form[2]), (fast[0].P0, sde.P0),
+                     (np.asarray(fast[0].H).reshape(-1), np.asarray(sde.H).reshape(-1))):
+            a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+            assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-11 * (1.0 + np.max(np.abs(b)))
+        assert m._device_forms()[0][1][0] == fast[1][0]             # and it is what the model uses
+    both = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), Matern32(1.0, 1.0) + Matern52(1.0, 1.0), parallel=True)
+    assert both._matern_forms() is None
