@@ -176,6 +176,35 @@ class StateSpaceGP:
                 return None
         return out
 
+    def _rbf_scaled_sde(self):
+        """A single RBF kernel near a setting whose SDE is already built: the lengthscale is a scaling of time and the
+        variance a scaling of Pinf, so the model at (s2, l) is the reference one at (s2_0, l_0) with F l_0 / l and
+        Pinf s2 / s2_0 -- the same likelihood as get_sde()'s realisation gives, to rounding (they differ by a diagonal
+        similarity where the balancing sweeps have not converged; tests/test_gpu_lti.py) -- without the 0.2 - 0.4 ms of
+        get_sde() (polynomial roots, balancing, Lyapunov solve at d = 6) per step of an optimiser.  The reference setting
+        is renewed whenever the lengthscale has drifted by more than 25 % from it.  None for other kernels."""
+        from .kernels import RBF
+        k = self.kernel
+        if not isinstance(k, RBF) or getattr(k, "kernels", None):
+            return None
+        s2, ell = float(k.variance), float(k.lengthscales)
+        if not (s2 > 0.0 and ell > 0.0):
+            return None
+        from . import _backend
+        ref = getattr(self, "_rbf_ref", None)
+        if ref is None or not (0.8 <= ell / ref[1] <= 1.25):
+            sde = k.get_sde()
+            F, P0 = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64)
+            if not (_backend.LTI_DIM_MIN <= F.shape[0] <= _backend.LTI_DIM_MAX):
+                return None
+            L = np.asarray(sde.L, np.float64)
+            LQL = L @ np.atleast_2d(np.asarray(sde.Q, np.float64)) @ L.T
+            if np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) > 1e-8 * max(1.0, float(np.max(np.abs(LQL)))):
+                return None
+            ref = self._rbf_ref = (s2, ell, F, P0, np.asarray(sde.H, np.float64))
+        from types import SimpleNamespace
+        return SimpleNamespace(F=ref[2] * (ref[1] / ell), P0=ref[3] * (s2 / ref[0]), H=ref[4])
+
     def _device_forms_uncached(self):
         """(fused, lti) from ONE get_sde() (for composite kernels that call is the host cost of an evaluation):
         `fused` = (sde, (lam, N1, N2)) when the SDE has the closed-form discretisation of the fused HIP path
@@ -190,6 +219,9 @@ class StateSpaceGP:
         if fast is not None:
             return fast, None
         from . import _backend
+        scaled = self._rbf_scaled_sde()
+        if scaled is not None:
+            return None, scaled
         sde = self.kernel.get_sde()
         F, P0 = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64)
         L = np.asarray(sde.L, np.float64)
@@ -418,6 +450,7 @@ class StateSpaceGP:
         base, sizes = row()
         d = None if base is None else base[1].shape[0]
         if base is None or not (2 <= d <= _backend.GRAD_BLOCKS_DIM_MAX) or len(sizes) > _backend.GRAD_BLOCKS_MAX:
+            self._no_composite = True          # (a property of the kernel's structure: not asked again)
             return None, None
         rows = [tuple(base)]
         for owner, name in self.trainable_parameters():
@@ -458,7 +491,7 @@ class StateSpaceGP:
         if fused is None:
             # sums / products of Matern kernels (block-nilpotent drift, d <= 6): exact, dual numbers through the scan
             rows, sizes = (None, None)
-            if lti is not None and lti.F.shape[0] <= _backend.GRAD_BLOCKS_DIM_MAX:
+            if lti is not None and lti.F.shape[0] <= _backend.GRAD_BLOCKS_DIM_MAX and not getattr(self, "_no_composite", False):
                 rows, sizes = self._grad_rows_composite()
             if rows is not None:
                 ll, g = _backend.gp_ll_grad_blocks(rows, sizes, ts.reshape(-1), Y.reshape(-1))
@@ -544,6 +577,19 @@ class StateSpaceGP:
                     for other, (fo, Fo, Po, Ho) in list(memo.items()):
                         if other[1:] == key[1:] and other[0] != 0.0:
                             memo[key] = (fo, Fo, Po * (key[0] / other[0]), Ho)
+                            break
+                if key not in memo and leaf_variance and key[0] != 0.0 and len(key) == 2 and key[1] > 0.0:
+                    # ... and its lengthscale is a scaling of time: k(tau / l).  The state-space model at lengthscale l is
+                    # the one at l0 with F multiplied by l0 / l (same Pinf / variance, same H) -- the same model as
+                    # get_sde() builds, in a realisation that differs from it by a diagonal similarity where the
+                    # balancing sweeps have not converged (RBF), i.e. the same likelihood up to rounding.  Used for nearby
+                    # lengthscales only (the perturbations of a difference quotient, the steps of a sampler): one SDE
+                    # construction (0.2 - 0.4 ms for RBF order 6) instead of one per row.
+                    for other, (fo, Fo, Po, Ho) in list(memo.items()):
+                        if other[0] != 0.0 and other[1] > 0.0 and 0.8 <= key[1] / other[1] <= 1.25:
+                            r = other[1] / key[1]
+                            form = None if fo is None else (fo[0] * r, fo[1] * r, fo[2] * (r * r))
+                            memo[key] = (form, Fo * r, Po * (key[0] / other[0]), Ho)
                             break
                 if key not in memo:
                     sde = self.kernel.get_sde()

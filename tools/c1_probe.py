@@ -38,3 +38,23 @@ print("python: ser.gp_ll only", bench(lambda: ser.gp_ll(packed, 0.1)), "us")
 ser.set_queries(tq.reshape(-1))
 print("python: ser.gp_predict only", bench(lambda: ser.gp_predict(packed, 0.1)), "us")
 print("python: set_queries (same grid)", bench(lambda: ser.set_queries(tq.reshape(-1))), "us")
+
+# RBF order 6 (general-LTI path): same setting vs a new setting every call
+from pssgp.kernels import RBF
+n = 1000
+t = np.sort(rng.uniform(0, 10, n)); y = np.sin(t) + 0.3 * rng.standard_normal(n)
+gp = StateSpaceGP((t[:, None], y[:, None]), RBF(1., 0.5, order=6, balancing_iter=5), noise_variance=0.1, parallel=True)
+state = {"i": 0}
+def fresh(fn):
+    def run():
+        state["i"] += 1
+        gp.kernel.lengthscales = 0.5 * (1.0 + 1e-6 * state["i"])
+        return fn()
+    return run
+print(f"RBF6 N={n}: same setting  ll {bench(gp.maximum_log_likelihood_objective, 100):7.1f}   ll+grad {bench(gp.log_likelihood_and_grad, 50):7.1f} us")
+print(f"RBF6 N={n}: new setting   ll {bench(fresh(gp.maximum_log_likelihood_objective), 100):7.1f}   ll+grad {bench(fresh(gp.log_likelihood_and_grad), 50):7.1f} us")
+gp._rbf_ref = None
+ll_scaled = float(gp.maximum_log_likelihood_objective())
+sde = gp.kernel.get_sde()
+ll_direct = B.lti_ll(sde.F, sde.P0, sde.H, gp.noise_variance, t, y)
+print("RBF6 ll through the scaled realisation vs get_sde's:", ll_scaled, ll_direct, abs(ll_scaled - ll_direct) / abs(ll_direct))
