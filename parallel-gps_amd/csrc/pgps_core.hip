@@ -1168,6 +1168,10 @@ struct pgps_series {
     double *ts_m = nullptr, *ys_m = nullptr, *fms = nullptr, *fPs = nullptr, *pm = nullptr, *pv = nullptr, *res = nullptr;
     int* qslot = nullptr;
     double* host = nullptr;             // pinned: 2 K + 32 doubles
+    double* hdev = nullptr;             // the same buffer as the device sees it: the last kernel of a call writes its results
+                                        // straight into it (a D2H copy is a blit kernel of its own: ~5 us each, three per
+                                        // predict_f; PGPS_SERIES_ZERO_COPY=0 in the environment brings the copies back)
+    bool zero_copy = true;
     size_t host_cap = 0;
 };
 
@@ -1184,6 +1188,10 @@ static int series_host(pgps_series* s, size_t doubles) {
     s->host = nullptr; s->host_cap = 0;
     if (hipHostMalloc((void**)&s->host, doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) return PGPS_E_NOMEM;
     s->host_cap = doubles;
+    const char* env = std::getenv("PGPS_SERIES_ZERO_COPY");
+    s->zero_copy = !(env && env[0] == '0');
+    s->hdev = nullptr;
+    if (s->zero_copy && hipHostGetDevicePointer((void**)&s->hdev, s->host, 0) != hipSuccess) { s->hdev = nullptr; s->zero_copy = false; }
     return PGPS_OK;
 }
 
@@ -1258,8 +1266,9 @@ extern "C" int pgps_series_gp_ll_f64(pgps_series* s, int d, double lam, const do
                                      const double* H, double R, double* ll) {
     if (!s || !ll) return PGPS_E_INVALID;
     pgps_ctx* ctx = s->ctx;
-    TRY(gp_dev<double>(ctx, s->N, d, lam, N1, N2, Pinf, H, R, s->ts, s->t0, s->ys, nullptr, nullptr, nullptr, nullptr, s->res));
-    HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double* const res = s->zero_copy ? s->hdev : s->res;
+    TRY(gp_dev<double>(ctx, s->N, d, lam, N1, N2, Pinf, H, R, s->ts, s->t0, s->ys, nullptr, nullptr, nullptr, nullptr, res));
+    if (!s->zero_copy) HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *ll = s->host[0];
     return std::isfinite(*ll) ? PGPS_OK : PGPS_E_NUMERIC;
@@ -1269,8 +1278,8 @@ extern "C" int pgps_series_gp_ll_f64(pgps_series* s, int d, double lam, const do
 extern "C" int pgps_series_gp_ll_grad_f64(pgps_series* s, int d, int np, const double* model, double* out) {
     if (!s || !model || !out || np < 1 || np > 16) return PGPS_E_INVALID;
     pgps_ctx* ctx = s->ctx;
-    TRY(launch_grad(ctx, s->N, d, np, model, s->ts, s->t0, s->ys, s->res));
-    HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, (size_t)(1 + np) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TRY(launch_grad(ctx, s->N, d, np, model, s->ts, s->t0, s->ys, s->zero_copy ? s->hdev : s->res));
+    if (!s->zero_copy) HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, (size_t)(1 + np) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i <= np; ++i) out[i] = s->host[i];
     return std::isfinite(out[0]) ? PGPS_OK : PGPS_E_NUMERIC;
@@ -1289,7 +1298,8 @@ extern "C" int pgps_series_gp_predict_f64(pgps_series* s, int d, double lam, con
     g.s.R = R;
     g.s.ys = s->ys_m;
     g.s.fms = s->fms; g.s.fPs = s->fPs; g.s.sms = nullptr; g.s.sPs = nullptr;
-    g.s.ll = s->res;
+    const size_t K = (size_t)s->K;
+    g.s.ll = s->zero_copy ? s->hdev + 2 * K : s->res;
     g.m.lam = lam;
     for (int i = 0; i < 9; ++i) { g.m.N1[i] = 0; g.m.N2[i] = 0; g.m.Pinf[i] = 0; }
     for (int i = 0; i < d * d; ++i) { g.m.N1[i] = N1[i]; g.m.N2[i] = N2 ? N2[i] : 0.0; g.m.Pinf[i] = Pinf[i]; }
@@ -1297,8 +1307,8 @@ extern "C" int pgps_series_gp_predict_f64(pgps_series* s, int d, double lam, con
     g.m.ts = s->ts_m;
     g.m.t_prev = s->t0;
     g.qslot = s->qslot;
-    g.pmean = s->pm;
-    g.pvar = s->pv;
+    g.pmean = s->zero_copy ? s->hdev : s->pm;
+    g.pvar = s->zero_copy ? s->hdev + K : s->pv;
     int rc;
     switch (d) {
         case 1: rc = launch_gp<double, 1>(ctx, g, 1, 1); break;
@@ -1306,10 +1316,11 @@ extern "C" int pgps_series_gp_predict_f64(pgps_series* s, int d, double lam, con
         default: rc = launch_gp<double, 3>(ctx, g, 1, 1); break;
     }
     if (rc) return rc;
-    const size_t K = (size_t)s->K;
-    HIPCHK(ctx, hipMemcpyAsync(s->host, s->pm, K * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(s->host + K, s->pv, K * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(s->host + 2 * K, s->res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!s->zero_copy) {
+        HIPCHK(ctx, hipMemcpyAsync(s->host, s->pm, K * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(s->host + K, s->pv, K * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(s->host + 2 * K, s->res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(mean, s->host, K * 8);
     std::memcpy(var, s->host + K, K * 8);
