@@ -4,6 +4,7 @@
 namespace pgps {
 
 constexpr int kNP = 3;          // hyper-parameters differentiated per pass for d <= 2 (d = 3: one per pass)
+constexpr long kGradOneLaunch = 2048;   // series up to this length: one workgroup per direction, one launch
 
 template <int NP, int D>
 static int launch_grad_d(pgps_ctx* ctx, GradModel<NP> m) {
@@ -71,6 +72,8 @@ static int launch_grad_pack(pgps_ctx* ctx, long N, int np, const double* model, 
     long nlanes = 0;
     int Lc = 0, nblocks = 0;
     geometry(ctx, N, &Lc, &nblocks);
+    // up to kGradOneLaunch steps: one workgroup per direction, everything in one launch (k_grad_one_pack)
+    if (ctx->chunk <= 0 && N <= kGradOneLaunch && nblocks > 1) { Lc = (int)((N + kBlock - 1) / kBlock); nblocks = 1; }
     nlanes = (long)nblocks * kBlock;
     const size_t nb = (size_t)nblocks, nl = (size_t)nlanes;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -89,6 +92,11 @@ static int launch_grad_pack(pgps_ctx* ctx, long N, int np, const double* model, 
         m.llpart = (T*)(base + per * p + s_spine + s_lpre);
     }
     const dim3 grid(nblocks, np), block(kBlock);
+    if (nblocks == 1) {
+        timed_launch(ctx, PGPS_K_FILTER_APPLY, k_grad_one_pack<D>, grid, block, 0, pack, out_dev);
+        HIPCHK(ctx, hipGetLastError());
+        return PGPS_OK;
+    }
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_grad_reduce_pack<1, D>, grid, block, 0, pack);
     timed_launch(ctx, PGPS_K_FILTER_APPLY, k_grad_apply_pack<1, D>, grid, block, 0, pack);
     timed_launch(ctx, PGPS_K_LL_FINALIZE, k_grad_finalize_pack<1>, dim3(1, np), block, 0, pack);

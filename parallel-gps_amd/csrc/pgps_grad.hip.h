@@ -105,7 +105,7 @@ template <int NP, int D>
 __global__ __launch_bounds__(kBlock) void k_grad_reduce_pack(const GradPack<NP> p) { grad_reduce_body<NP, D>(p.m[blockIdx.y]); }
 
 template <int NP, int D>
-__device__ __forceinline__ void grad_apply_body(const GradModel<NP>& m) {
+__device__ __forceinline__ void grad_apply_body(const GradModel<NP>& m, Dual<NP>* block_total = nullptr) {
     using T = Dual<NP>;
     constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT;
     using FE = FiltElem<T, D>;
@@ -149,11 +149,29 @@ __device__ __forceinline__ void grad_apply_body(const GradModel<NP>& m) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) tot.d[i] = block_sum_double(v.d[i], lds_ll);
     if (threadIdx.x == 0) m.llpart[blockIdx.x] = tot;
+    if (block_total) *block_total = tot;
 }
 template <int NP, int D>
 __global__ __launch_bounds__(kBlock) void k_grad_apply(const GradModel<NP> m) { grad_apply_body<NP, D>(m); }
 template <int NP, int D>
 __global__ __launch_bounds__(kBlock) void k_grad_apply_pack(const GradPack<NP> p) { grad_apply_body<NP, D>(p.m[blockIdx.y]); }
+
+// A series that fits ONE workgroup (the reference's own lengths): reduce, Kalman pass and the sum in one launch, one
+// derivative direction per workgroup (blockIdx.y); direction p's workgroup writes d ll / d theta_p -- and direction 0's
+// the log-likelihood -- where the caller wants them.  Three launch boundaries and the compaction kernel less.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_grad_one_pack(const GradPack<1> p, double* out) {
+    const GradModel<1>& m = p.m[blockIdx.y];
+    grad_reduce_body<1, D>(m);
+    __builtin_amdgcn_s_waitcnt(0);              // this lane's scan record is in memory before it is read back
+    __syncthreads();
+    Dual<1> tot;
+    grad_apply_body<1, D>(m, &tot);
+    if (threadIdx.x == 0) {
+        if (blockIdx.y == 0) out[0] = tot.v;
+        out[1 + blockIdx.y] = tot.d[0];
+    }
+}
 
 template <int NP>
 __device__ __forceinline__ void grad_finalize_body(const Dual<NP>* llpart, int nblocks, double* out) {
