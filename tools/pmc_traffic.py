@@ -21,7 +21,9 @@ import sys
 SLOT_OF = [("k_filter_reduce", "k_filter_reduce"), ("k_filter_apply", "k_filter_apply"), ("k_filter_single", "k_filter_apply"),
            ("k_smoother_apply", "k_smoother_apply"), ("k_smoother_reduce", "k_smoother_reduce"),
            ("rc_reduce1", "k_filter_reduce"), ("rc_ks_filter", "k_filter_reduce"), ("rc_apply1", "k_filter_apply"),
-           ("rc_ks_smoother", "k_smoother_reduce"), ("rc_selem1", "k_smoother_reduce"), ("rc_smooth1", "k_smoother_apply")]
+           ("rc_ks_smoother", "k_smoother_reduce"), ("rc_selem1", "k_smoother_reduce"), ("rc_smooth1", "k_smoother_apply"),
+           ("rc_scan_blk_f", "k_filter_reduce"), ("rc_scan_blk_s", "k_smoother_reduce"), ("q_reduce1", "k_filter_reduce"),
+           ("q_apply1", "k_filter_apply"), ("q_smooth1", "k_smoother_apply")]
 
 
 def main():
