@@ -309,6 +309,9 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 #ifndef PGPS_RC_DMA
 #define PGPS_RC_DMA 1
 #endif
+#ifndef PGPS_RC_EDGE_FAST
+#define PGPS_RC_EDGE_FAST 1                  // the first and the last workgroup of a series on the FAST road (rc_reduce1)
+#endif
 
 template <int D, typename Real>
 struct Io {
@@ -493,8 +496,23 @@ struct Io {
 #pragma unroll
         for (int v = 0; v < NVW; ++v) r[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wg[v], 0, 0);
     }
+    // (descriptor cut `left` records after base's: see wide_dma_cut)
+    __device__ __forceinline__ void wide_load_cut(const Real* base, V4* r, long left) const {
+        const long bytes = left * (long)REC;
+        const unsigned lim = bytes <= 0 ? 0u : (bytes < (long)(span_m + 16u) ? (unsigned)bytes : span_m + 16u);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, lim);
+#pragma unroll
+        for (int v = 0; v < NVW; ++v) r[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wg[v], 0, 0);
+    }
     __device__ __forceinline__ void wide_dma(const Real* base, const char* slot) const {
         dma_pieces<NVW>(make_rsrc(base, span_m + 16u), wg, (unsigned)(size_t)slot);
+    }
+    // the same with the descriptor cut `left` records after base's (the end of the array): what lies beyond lands as zeros
+    // (the range check is per dword -- tools/micro/buf_range.hip -- so a record that is not whole pieces is still exact)
+    __device__ __forceinline__ void wide_dma_cut(const Real* base, const char* slot, long left) const {
+        const long bytes = left * (long)REC;
+        const unsigned lim = bytes <= 0 ? 0u : (bytes < (long)(span_m + 16u) ? (unsigned)bytes : span_m + 16u);
+        dma_pieces<NVW>(make_rsrc(base, lim), wg, (unsigned)(size_t)slot);
     }
     __device__ __forceinline__ void wide_commit(char* slot, const V4* r) const {
 #pragma unroll
@@ -606,8 +624,13 @@ __device__ __forceinline__ RcArgsT<Real> model_view(const RcArgsT<Real>& a) {
 // ====================================================================================================
 // level 1: reduce -- filt_extend over the chunk (pgps_math.h filt_extend, parallel.py:46-72,100-118)
 // ====================================================================================================
-template <typename Real, int D, bool FAST>
+// FAST: the four chains are complete and nothing is predicated; EDGE (with FAST): the workgroup holds the series' first
+// step (F = I, Q = 0 there) and / or its last one (the fetch a step ahead runs off the end of the arrays: descriptor cut,
+// index clamped) -- the same road, a handful of selects.  The general body is for ragged ends only: it is slower, and in a
+// one-round grid its wave is what the kernel waits for (c5: 563 against 511 us with the edge waves switched off).
+template <typename Real, int D, bool FAST, bool EDGE = false>
 __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
+    static_assert(FAST || !EDGE, "EDGE is a flavour of the FAST body");
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;        // row 0's first step
     const long c = (long)blockIdx.x * 4 + row;
@@ -655,14 +678,17 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
     // read out of them (lgkmcnt(0): the reads are in registers) -- the whole step's arithmetic is still ahead of them
     constexpr int SL = IOT::SLOT + 16;
     auto prefetch = [&](int s) {
-        if constexpr (DMA) {
+        if constexpr (DMA && EDGE) {
+            io.wide_dma_cut(a.Fs + (kw + s) * dd, wslots, a.N - (kw + s));
+            if (!impq) io.wide_dma_cut(a.Qs + (kw + s) * dd, wslots + SL, a.N - (kw + s));
+        } else if constexpr (DMA) {
             io.wide_dma(a.Fs + (kw + s) * dd, wslots);
             if (!impq) io.wide_dma(a.Qs + (kw + s) * dd, wslots + SL);
         } else {
             io.wide_load(a.Fs + (kw + s) * dd, pF);
             if (!impq) io.wide_load(a.Qs + (kw + s) * dd, pQ);
         }
-        ny = a.ys[k0 + s];
+        ny = a.ys[EDGE ? min(k0 + s, a.N - 1) : k0 + s];
     };
     auto take = [&](int s) {                    // step s's pieces into LDS, step s + 1's on their way, both layouts out
         char* slotF = wslots;
@@ -678,6 +704,16 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
             PGPS_RC_PIN();
             prefetch(s + 1);                    // (one step beyond the chunk at the end: inside the series for a FAST wave)
             PGPS_RC_PIN();
+            if constexpr (EDGE) {
+                if (s == 0 && k0 == 0 && a.seg_first) {             // the series' first step: F = I, Q = 0 (filt_first)
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        Fc[i] = (i == lane && lv) ? Real(1.0) : Real(0.0);
+                        Fr[i] = Fc[i];
+                        Q[i] = Real(0.0);
+                    }
+                }
+            }
         } else {
             sync();
             io.wide_commit(slotF, pF);
@@ -746,10 +782,13 @@ __global__ __launch_bounds__(64, PGPS_RC_WAVES_R) void rc_reduce1(const RcArgsT<
 #ifdef PGPS_RC_FAST_ONLY              // (diagnostic: the FAST body's registers alone)
     reduce1_body<Real, D, true>(a, patch, wslots, lane, row);
 #else
+    // (EDGE needs the LDS-DMA fetch -- its descriptor is what gets cut -- and whole chains: ragged ends take the general body)
+    const bool full = ((long)blockIdx.x + 1) * 4 * a.Lw <= a.N;
     if (blockIdx.x >= 1 && blockIdx.x < a.wfast) reduce1_body<Real, D, true>(a, patch, wslots, lane, row);
 #ifdef PGPS_RC_SKIP_EDGE               // (timing experiment: what the kernel costs without its edge waves; results are wrong)
     else return;
 #else
+    else if (PGPS_RC_DMA != 0 && PGPS_RC_EDGE_FAST != 0 && full) reduce1_body<Real, D, true, true>(a, patch, wslots, lane, row);
     else reduce1_body<Real, D, false>(a, patch, wslots, lane, row);
 #endif
 #endif
@@ -759,8 +798,11 @@ __global__ __launch_bounds__(64, PGPS_RC_WAVES_R) void rc_reduce1(const RcArgsT<
 // level 1: apply -- Kalman pass, log-likelihood, smoothing elements and the chunk's smoothing total
 // (kf_step / smth_element / smth_combine of pgps_math.h; parallel.py:135-151, 155-184)
 // ====================================================================================================
-template <typename Real, int D, bool SMOOTH, bool FAST, bool IMPQS, bool STORE>
+// (FAST / EDGE as in reduce1_body; EDGE here also runs the series' first update from the prior itself and, in the step
+// after the last chain of the series, takes Q = I for the F = 0 the cut descriptor delivers)
+template <typename Real, int D, bool SMOOTH, bool FAST, bool IMPQS, bool STORE, bool EDGE = false>
 __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
+    static_assert(FAST || !EDGE, "EDGE is a flavour of the FAST body");
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
@@ -830,9 +872,15 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
     char* slotL = wslots + (BATCH ? 3 : 2) * (IOT::SLOT + 16);
     char* slotP = wslots + (BATCH ? 4 : 2) * (IOT::SLOT + 16);
     auto prefetch = [&](int s) {
-        io.wide_load(a.Fs + (kw + s) * dd, pF);
-        if (!impq) io.wide_load(a.Qs + (kw + s) * dd, pQ);
-        ny = a.ys[k0 + s];
+        if constexpr (EDGE) {
+            io.wide_load_cut(a.Fs + (kw + s) * dd, pF, a.N - (kw + s));
+            if (!impq) io.wide_load_cut(a.Qs + (kw + s) * dd, pQ, a.N - (kw + s));
+            ny = a.ys[min(k0 + s, a.N - 1)];
+        } else {
+            io.wide_load(a.Fs + (kw + s) * dd, pF);
+            if (!impq) io.wide_load(a.Qs + (kw + s) * dd, pQ);
+            ny = a.ys[k0 + s];
+        }
     };
     auto take = [&](auto more_c, int s) {       // step s's pieces into LDS, step s + 1's on their way, both layouts out
         sync();
@@ -844,6 +892,14 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
         io.template lds_get<false>(slotF, Fc);
         io.template lds_get<true>(slotF, Fr);
         if (!impq) io.template lds_get<false>(slotQ, Q);
+        if constexpr (EDGE && !decltype(more_c)::value) {
+            // the step after the last chain of the series: F = 0 came out of the cut descriptor, Q = I by hand
+            // (parallel.py:155-156: the last element is (0, m, P))
+            if (k0 + s >= a.N) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) Q[i] = (i == lane && lv) ? Real(1.0) : Real(0.0);
+            }
+        }
     };
     // a matrix result of step `ku`: FAST into its output slot (drained at the end of the step), otherwise predicated
     // per-register stores
@@ -941,7 +997,7 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
             Real S = rowsum<D>(hl * u, a.R), mu = rowsum<D>(hl * mp, Real(0.0));
             if (obs) ll.add((double)yk - (double)mu, (double)S);
             Real mb = mp;
-            if (!FAST && blockIdx.x == 0 && s == 0) {
+            if ((!FAST || EDGE) && blockIdx.x == 0 && s == 0) {
                 // first step of the series (chain 0 only): the update uses the prior itself (parallel.py:24-30),
                 // the likelihood term above used F0 P0 F0^T + Q0 (parallel.py:136-141)
                 const bool first = (c == 0 && a.seg_first);
@@ -1004,10 +1060,17 @@ __global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_apply1(const RcArgsT<Rea
 #ifdef PGPS_RC_FAST_ONLY
     apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, wslots, lane, row);
 #else
+    // EDGE: whole chains; the workgroup that ends the series only when nothing follows it (a segment that is not the last of
+    // its series takes the first step of the next rank from the halo record: general body)
+    const long end4 = ((long)blockIdx.x + 1) * 4 * a.Lw;
+    // (the filter + smoothing-element kernels only: the filter-only ones fit two waves per SIMD and a third body would cost
+    // them that)
+    const bool edge_ok = SMOOTH && PGPS_RC_EDGE_FAST != 0 && end4 <= a.N && !(end4 == a.N && (a.halo_F != nullptr || !a.seg_last));
     if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, wslots, lane, row);
 #ifdef PGPS_RC_SKIP_EDGE               // (timing experiment: what the kernel costs without its edge waves; results are wrong)
     else return;
 #else
+    else if (edge_ok) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE, SMOOTH>(a, patch, wslots, lane, row);
     else apply1_body<Real, D, SMOOTH, false, IMPQS, STORE>(a, patch, wslots, lane, row);
 #endif
 #endif
@@ -1161,11 +1224,14 @@ __device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch
     char* slotE = wslots;
     char* slotL = wslots + (IOT::SLOT + 16);
     char* slotO = wslots + 2 * (IOT::SLOT + 16);
-    auto prefetch = [&](int s) {                // (s = -1 at the end: the step before the chunk, >= 0 for a FAST wave)
-        io.wide_load(a.Es + (kw + s) * dd, pE);
-        io.wide_load_sym(IOT::sym_at(a.Lws, kw + s), pL);
-        io.vec_fast(a.gs + (kw + s) * D, ng);
-        if (PROJ) nq = a.qslot[k0 + s];
+    auto prefetch = [&](int s) {                // (s = -1 at the end: the step before the chunk; the series' first
+        const long kp = kw + s < 0 ? 0 : kw + s;    // workgroup has none and fetches its step 0 again, unused)
+        // (whole-series calls keep E in the caller's sPs array until this pass overwrites it: the descriptor ends where
+        // that array ends -- the 16 bytes of slack a record's last piece is given elsewhere would be read beyond it)
+        io.wide_load_cut(a.Es + kp * dd, pE, a.N - kp);
+        io.wide_load_sym(IOT::sym_at(a.Lws, kp), pL);
+        io.vec_fast(a.gs + kp * D, ng);
+        if (PROJ) nq = a.qslot[k0 + s < 0 ? 0 : k0 + s];
     };
     auto take = [&](int s) {
         sync();
@@ -1218,7 +1284,10 @@ __global__ __launch_bounds__(64) void rc_smooth1(const RcArgsT<Real> a) {
     __shared__ __attribute__((aligned(16))) char wslots[3 * (Io<D, Real>::SLOT + 16)];
     lds_clear(wslots, (int)sizeof(wslots));
     Real* patch = patch_init(tl, row);
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) smooth1_body<Real, D, true, PROJ>(a, patch, wslots, lane, row);
+    // FAST: the four chains are complete (the smoother reads nothing beyond its chains: the first and the last workgroup of
+    // a series qualify like any other -- until round 3 they took the general body, whose wave a one-round grid waits for)
+    const bool full = ((long)blockIdx.x + 1) * 4 * a.Lw <= a.N;
+    if (PGPS_RC_EDGE_FAST != 0 ? full : (blockIdx.x >= 1 && blockIdx.x < a.wfast)) smooth1_body<Real, D, true, PROJ>(a, patch, wslots, lane, row);
 #ifdef PGPS_RC_SKIP_EDGE               // (timing experiment: what the kernel costs without its edge waves; results are wrong)
     else return;
 #else

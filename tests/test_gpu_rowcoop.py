@@ -247,3 +247,58 @@ def test_golden_large_d(name):
     miss = np.isnan(g["y"][100:900:7])
     assert np.max(np.abs(mean[miss] - g[name + "/smean"][100:900:7][miss])) < 1e-6 * max(1.0, float(np.max(np.abs(g[name + "/smean"]))))
     assert np.max(np.abs(var[miss] - g[name + "/svar"][100:900:7][miss])) < 1e-6 * max(1.0, float(np.max(g[name + "/svar"])))
+
+
+@pytest.mark.parametrize("dtype,kname,n", [(np.float64, "c5_qp_m52", 1 << 18), (np.float32, "rbf8", 1 << 15),
+                                           (np.float32, "rbf6", 1 << 17), (np.float64, "m32", 1 << 18)])
+def test_device_arrays_that_end_on_a_page_boundary(dtype, kname, n):
+    """The device entry points on arrays of EXACTLY N records whose size is a multiple of 2 MiB -- what a framework's
+    allocator hands out (bench.py's torch tensors) -- so that a single byte read or written beyond an array faults
+    instead of landing in the slack of libpgps' own staging buffers (which is where every host-array test runs).  Round 3's
+    first attempt to send the last workgroup of a series down the wide-load road read 8 bytes beyond the smoothed
+    covariances at d = 11 -- the caller's array, where the smoothing elements wait -- and only bench.py noticed."""
+    import ctypes
+    from pssgp import _backend as B
+    from pssgp.kernels import Matern32, RBF
+    ks = dict(_kernels(), rbf6=lambda: RBF(1., 0.8, order=6, balancing_iter=10), m32=lambda: Matern32(1., 1.))
+    sde = ks[kname]().get_sde()
+    d = np.asarray(sde.F).shape[0]
+    w = np.dtype(dtype).itemsize
+    assert (n * d * d * w) % (1 << 21) == 0 and (n * w) % 4096 == 0
+    suf = "f64" if dtype == np.float64 else "f32"
+    t = make_times(n, seed=3)
+    Fs, Qs = B.discretise(sde.F, sde.P0, t, 0.0)
+    ssm = (np.asarray(sde.P0, np.float64), Fs, Qs, np.asarray(sde.H, np.float64).reshape(1, -1), np.array([[0.1]]))
+    from tests.conftest import sample_series_fast
+    y = sample_series_fast(ssm, seed=4, nan_frac=0.1)
+    ctx = B.Context(0)
+    host = dict(P0=ssm[0], Fs=Fs, Qs=Qs, H=ssm[3].reshape(-1), ys=y.reshape(-1))
+    bufs, ptr = {}, {}
+    try:
+        for name, arr in host.items():
+            a = np.ascontiguousarray(arr, dtype)
+            ptr[name] = ctx.malloc(a.nbytes)            # one allocation per array, no slack
+            ctx.h2d(ptr[name], a)
+        for name, shape in (("fms", (n, d)), ("fPs", (n, d, d)), ("sms", (n, d)), ("sPs", (n, d, d))):
+            bufs[name] = np.empty(shape, dtype)
+            ptr[name] = ctx.malloc(bufs[name].nbytes)
+        ptr["ll"] = ctx.malloc(16)
+        P, L, I = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+        R = (ctypes.c_double if dtype == np.float64 else ctypes.c_float)(0.1)
+        ctx.call(f"pgps_pkfs_dev_{suf}", L(n), I(d), P(ptr["P0"]), P(ptr["Fs"]), P(ptr["Qs"]), P(ptr["H"]), R, P(ptr["ys"]),
+                 P(ptr["fms"]), P(ptr["fPs"]), P(ptr["sms"]), P(ptr["sPs"]), P(ptr["ll"]))
+        ctx.synchronize()
+        for name in bufs:
+            ctx.d2h(bufs[name], ptr[name])
+        ll = np.empty(2, np.float64)
+        ctx.d2h(ll, ptr["ll"])
+    finally:
+        for p in ptr.values():
+            ctx.free(p)
+        ctx.close()
+    ssm_t = tuple(np.asarray(a, dtype) for a in ssm)
+    sms, sPs, fms, fPs, ll_h = B.pkfs(ssm_t, np.asarray(y, dtype), return_filtered=True, return_loglikelihood=True)
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    for name, ref in (("fms", fms), ("fPs", fPs), ("sms", sms), ("sPs", sPs)):
+        assert relerr(bufs[name], ref) < tol, name
+    assert abs(ll[0] - float(ll_h)) <= tol * abs(float(ll_h))
