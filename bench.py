@@ -343,6 +343,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # stdout carries the ONE JSON line and nothing else: whatever a library writes to file descriptor 1 on the way (RCCL
+    # prints a version banner there when a communicator is created) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if os.environ.get("PGPS_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["PGPS_BENCH_WATCHDOG"]), exit=True)
@@ -805,7 +810,7 @@ def main():
                 "smoothed_mean_rel": float(np.max(np.abs(sms.cpu().numpy() - cs)) / np.max(np.abs(cs))),
                 "smoothed_cov_rel": float(np.max(np.abs(sPs.cpu().numpy() - csP)) / np.max(np.abs(csP)))})
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if use_lib_exchange and (world > 1 or args.force_segments) and args.path == "lgssm":
         ctx.synchronize()
         seg.close()
