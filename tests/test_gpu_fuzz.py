@@ -112,6 +112,55 @@ def test_random_models_fp32_row_cooperative(seed):
         ctx.set_chunk(0)
 
 
+def random_quad_case(seed, cases=6):
+    """Random stable SDEs of state dimension 5..8 in float32 on the quad-cooperative kernels (family 4; pgps_qc.hip.h):
+    ragged lengths against random chain lengths (sixteen chains per wave: partially filled waves, chains beyond the end,
+    the whole-record LDS road and -- at odd d -- the lane-by-lane one), missing observations; filter, smoother and
+    log-likelihood against the fp64 oracle, and whole series against two random segments of the same series."""
+    from pssgp import _backend as B
+    from tests.test_segments import run_segments_on_one_gpu
+    rng = np.random.default_rng(11000 + seed)
+    ctx = B.get_context()
+    tags = []
+    try:
+        for case in range(cases):
+            d = int(rng.integers(5, 9))
+            n = int(rng.choice([1, 2, 15, 16, 17, 63, 65, 255, 257, 700, 1500, 2600, 6000, 20000]))
+            chunk = int(rng.choice([0, 0, 1, 3, 8, 13, 32, 64]))
+            F, P, H = _random_model(rng, d)
+            t = make_times(n, seed=seed * 100 + case)
+            ssm = _ssm(F, P, H, t, 0.2)
+            y = sample_series(ssm, seed=case, nan_frac=float(rng.choice([0.0, 0.2, 0.6])) if n > 3 else 0.0)
+            ssm32 = tuple(np.asarray(a, np.float32) for a in ssm)
+            tag = f"seed={seed} d={d} n={n} chunk={chunk}"
+            ctx.set_family(4)
+            ctx.set_chunk(chunk)
+            sms, sPs, fms, fPs, ll = B.pkfs(ssm32, y.astype(np.float32), return_filtered=True, return_loglikelihood=True)
+            ctx.set_chunk(0)
+            ctx.set_family(0)
+            of, oP, oll = O.kf(ssm, y, True)
+            os_, osP = O.kfs(ssm, y)
+            tol = 3e-3
+            assert relerr(fms, of) < tol and relerr(fPs, oP) < tol, tag
+            assert relerr(sms, os_) < tol and relerr(sPs, osP) < tol, tag
+            assert abs(float(ll) - oll) <= 1e-3 * abs(oll) + 1e-3, tag
+            if n >= 4:
+                cut = int(rng.integers(1, n))
+                got, lls, _, _ = run_segments_on_one_gpu(ssm, y, [(0, cut), (cut, n)], np.float32, 4)
+                assert relerr(got["sms"], os_) < 5e-3 and relerr(got["sPs"], osP) < 5e-3, tag + f" cut={cut}"
+                assert all(abs(v - oll) <= 2e-3 * abs(oll) + 1e-2 for v in lls), tag + f" cut={cut}"
+            tags.append(tag)
+    finally:
+        ctx.set_family(0)
+        ctx.set_chunk(0)
+    return tags
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_models_fp32_quad_cooperative(seed):
+    random_quad_case(seed)
+
+
 def random_segments_case(seed):
     """One random sharded series: state dimension 1..24 (all three kernel families: lane-chunk up to 6, row-cooperative
     up to 16, wave-cooperative above -- or forced), 1..6 ranks with ragged boundaries (segments down to a single step),

@@ -69,7 +69,7 @@ def main():
     bad = 0
     for seed in range(first, first + count):
         for name, fn in (("rc", T.test_random_models_sizes_and_chains), ("rc_fp32", T.test_random_models_fp32_row_cooperative),
-                         ("large_d", large_d_case), ("segments", T.random_segments_case)):
+                         ("quad_fp32", T.random_quad_case), ("large_d", large_d_case), ("segments", T.random_segments_case)):
             try:
                 fn(seed)
             except Exception:
