@@ -19,7 +19,9 @@
  *   - one call in flight per context; contexts are independent (one per GPU / per thread).
  *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels (one lane owns whole d x d operands), fp64
  *     series with 5 <= d <= 16 and fp32 series with 7 <= d <= 16 the row-cooperative ones (built natively in both
- *     precisions for 2 <= d <= 16), up to PGPS_MAX_DIM the wave-cooperative ones; pgps_set_family overrides.
+ *     precisions for 2 <= d <= 16), fp32 series at d = 8 -- and at d = 6 away from 2^19 .. 2^20 steps -- the
+ *     quad-cooperative level-1 kernels under the row-cooperative driver, up to PGPS_MAX_DIM the wave-cooperative ones;
+ *     pgps_set_family overrides.
  *     Every call takes every d <= PGPS_MAX_DIM, the segment calls (pgps_seg_*, pgps_pkfs_seg_*) included.
  *   - NaN in `ys` marks a missing observation (parallel.py:42,86-95).
  */
@@ -66,8 +68,8 @@ int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
  * 0 = off (three-launch reduce-then-scan), 1 = on; window = tiles per look-back window (1..256, 0 = keep). */
 int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
 /* Kernel family: 0 = automatic (lane-chunk for d <= 4 and for fp32 up to PGPS_MAX_DIM_LANE; row-cooperative for
- * fp64 with 5 <= d <= 16 and fp32 with 7 <= d <= 16, segments use it above d = 6; wave-cooperative otherwise,
- * d <= 32),
+ * fp64 with 5 <= d <= 16 and fp32 with 7 <= d <= 16, segments use it above d = 6; quad-cooperative for whole fp32
+ * series at d = 8 and, up to 3 * 2^17 and from 3 * 2^19 steps, at d = 6; wave-cooperative otherwise, d <= 32),
  * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64 and fp32, 2 <= d <= 16),
  * 4 = quad-cooperative level-1 kernels under the row-cooperative driver (fp32 only, 5 <= d <= 8; pkf / pkfs / segments). */
 int pgps_set_family(pgps_ctx* ctx, int family);
