@@ -670,7 +670,7 @@ def main():
         "chunk": ctx.get_chunk(n_local),
         # lane-chunk kernels (d <= 6): lanes per workgroup, steps per lane, workgroups of the pass that was timed
         "lane_geometry": (list(ctx.get_geometry(n_local, d)) if d <= 6 and args.family in (0, 1)
-                          and "rc::" not in dominant_symbol(dominant, d, suf, args.family, world > 1 or args.force_segments, n_local)
+                          and not any(t in dominant_symbol(dominant, d, suf, args.family, world > 1 or args.force_segments, n_local) for t in ("rc::", "qc::"))
                           else None),
     }
 
