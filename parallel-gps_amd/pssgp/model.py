@@ -74,7 +74,9 @@ class StateSpaceGP:
     def _param_key(self):
         """The kernel's hyper-parameters as a tuple (the memo key of _device_forms: an evaluation repeated at the same
         setting -- predict_f after the objective, a benchmark loop -- does not rebuild the SDE)."""
-        return tuple(getattr(o, n) for o, n in self.trainable_parameters()[:-1])
+        # (the kernel object itself is part of the key: replacing `model.kernel` by another kernel with the same numbers in
+        # it must not find the old one's forms)
+        return (id(self.kernel),) + tuple(getattr(o, n) for o, n in self.trainable_parameters()[:-1])
 
     def _device_series(self):
         """The training series resident on the device (pgps_series_*, fp64 fused path): created at the first call, kept
@@ -192,6 +194,9 @@ class StateSpaceGP:
             return None
         from . import _backend
         ref = getattr(self, "_rbf_ref", None)
+        tag = (id(k), getattr(k, "_order", None), getattr(k, "_balancing_iter", None))
+        if ref is not None and ref[5] != tag:
+            ref = None                              # another kernel object (or order / balancing) than the reference's
         if ref is None or not (0.8 <= ell / ref[1] <= 1.25):
             sde = k.get_sde()
             F, P0 = np.asarray(sde.F, np.float64), np.asarray(sde.P0, np.float64)
@@ -201,7 +206,7 @@ class StateSpaceGP:
             LQL = L @ np.atleast_2d(np.asarray(sde.Q, np.float64)) @ L.T
             if np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) > 1e-8 * max(1.0, float(np.max(np.abs(LQL)))):
                 return None
-            ref = self._rbf_ref = (s2, ell, F, P0, np.asarray(sde.H, np.float64))
+            ref = self._rbf_ref = (s2, ell, F, P0, np.asarray(sde.H, np.float64), tag)
         from types import SimpleNamespace
         return SimpleNamespace(F=ref[2] * (ref[1] / ell), P0=ref[3] * (s2 / ref[0]), H=ref[4])
 

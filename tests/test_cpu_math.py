@@ -244,3 +244,25 @@ def test_matern_forms_without_building_the_sde(kname):
         assert m._device_forms()[0][1][0] == fast[1][0]             # and it is what the model uses
     both = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), Matern32(1.0, 1.0) + Matern52(1.0, 1.0), parallel=True)
     assert both._matern_forms() is None
+
+
+def test_form_memos_follow_the_kernel_object():
+    """The memoised forms are keyed on the kernel OBJECT and its numbers: a model whose kernel is replaced by another
+    class with the same hyper-parameters (or whose RBF changes order) must not find the old forms."""
+    from pssgp.kernels import Matern32, Matern52, RBF
+    from pssgp.model import StateSpaceGP
+    m = StateSpaceGP((np.zeros((1, 1)), np.zeros((1, 1))), Matern32(1.3, 0.7), noise_variance=0.1, parallel=True)
+    f32 = m._device_forms()[0][1]
+    assert m._device_forms()[0][1] is f32                        # memo hit
+    m.kernel = Matern52(1.3, 0.7)
+    f52 = m._device_forms()[0][1]
+    assert f52[1].shape == (3, 3) and f32[1].shape == (2, 2)
+    m.kernel = RBF(1.0, 0.5, order=4, balancing_iter=5)
+    a = m._device_forms()[1]
+    m.kernel = RBF(1.0, 0.5, order=6, balancing_iter=5)
+    b = m._device_forms()[1]
+    assert a.F.shape == (4, 4) and b.F.shape == (6, 6)
+    m.kernel.lengthscales = 0.5 * 1.1                            # nearby: scaled from the reference setting, same object
+    c = m._device_forms()[1]
+    ref = m.kernel.get_sde()
+    assert c.F.shape == (6, 6) and np.allclose(np.linalg.eigvals(c.F), np.linalg.eigvals(np.asarray(ref.F)), rtol=1e-6)
