@@ -1915,7 +1915,9 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode, int
                       d >= qc::kDimMin && d <= qc::kDimMax && mode != MODE_PKS && batch <= 1 && bs_model == 0 && !qslot;
     a.quad = quad ? 1 : 0;
     if (ctx->chunk > 0) {
-        a.Lw = ctx->chunk;
+        // (the wide accesses address a workgroup's chains with 32-bit offsets: 4096 steps per chain keep the span of
+        // sixteen d = 8 fp32 records, or of four d = 16 fp64 ones, far below 2^31 bytes)
+        a.Lw = ctx->chunk > 4096 ? 4096 : ctx->chunk;
     } else if (quad) {
         // sixteen chains per wave: 64 steps per chain put one wave on every SIMD at 2^20 steps
         long lw = (sa.N + 16383) / 16384;
