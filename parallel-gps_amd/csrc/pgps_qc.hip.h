@@ -80,7 +80,8 @@ __device__ __forceinline__ float comp(V2 v, int j) { return j ? v.y : v.x; }
 //   LT = true : the operand is x^T             (X(i, k) = component i & 1 of x[k] in lane i / 2)
 // yk[k] = the right operand's elements (k, own columns): its column layout, or -- for a product with the right operand
 // transposed -- that operand's ROW layout.  d^2 quad broadcasts + d^2 v_pk_fma_f32 per lane.
-template <int D, bool LT>
+// INIT: z = X Y instead of z += X Y (the first term is a v_pk_mul_f32: no zeroing of the accumulators)
+template <int D, bool LT, bool INIT = false>
 __device__ __forceinline__ void mm(V2 (&z)[D], const V2 (&x)[D], const V2 (&yk)[D]) {
     auto X = [&](int i, int k) { return LT ? qbi(comp(x[k], i & 1), i >> 1) : qbi(comp(x[i], k & 1), k >> 1); };
 #pragma unroll
@@ -90,10 +91,18 @@ __device__ __forceinline__ void mm(V2 (&z)[D], const V2 (&x)[D], const V2 (&yk)[
 #pragma unroll
         for (int i = 0; i + 1 < D; i += 2) {
             const V2 xp = V2{X(i, k), X(i + 1, k)};
-            z[i] = __builtin_elementwise_fma(V2{xp.x, xp.x}, yk[k], z[i]);
-            z[i + 1] = __builtin_elementwise_fma(V2{xp.y, xp.y}, yk[k], z[i + 1]);
+            if (INIT && k == 0) {
+                z[i] = V2{xp.x, xp.x} * yk[k];
+                z[i + 1] = V2{xp.y, xp.y} * yk[k];
+            } else {
+                z[i] = __builtin_elementwise_fma(V2{xp.x, xp.x}, yk[k], z[i]);
+                z[i + 1] = __builtin_elementwise_fma(V2{xp.y, xp.y}, yk[k], z[i + 1]);
+            }
         }
-        if constexpr (D & 1) z[D - 1] = fma2(X(D - 1, k), yk[k], z[D - 1]);
+        if constexpr (D & 1) {
+            const float xl = X(D - 1, k);
+            z[D - 1] = (INIT && k == 0) ? V2{xl, xl} * yk[k] : fma2(xl, yk[k], z[D - 1]);
+        }
         // vector-ALU instructions stay on their side of this line (memory and scalar ones may cross): left alone, the
         // scheduler hoists the d^2 broadcasts of a product far ahead of their use and the kernels need twice the registers
         __builtin_amdgcn_sched_barrier(0x0014 | 0x0380 | 0x0060);
@@ -464,8 +473,8 @@ __device__ __forceinline__ void reduce1_body(const rc::RcArgsT<float>& a, char* 
         }
         V2 Ap[D], FC[D], Cp[D];
         float bp[D];
-        zero2<D>(Ap); mm<D, false>(Ap, Fc, A);
-        zero2<D>(FC); mm<D, false>(FC, Fc, C);
+        mm<D, false, true>(Ap, Fc, A);
+        mm<D, false, true>(FC, Fc, C);
         copy2<D>(Cp, Q); mm<D, false>(Cp, FC, Fr);
         spread<D>(coldot<D>(Fr, b), bp);                 // (F b)[own rows], spread
         const float yk = y;
@@ -598,7 +607,7 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a, char* l
         // ---- phase A: predict; element of step k-1 (W = Pp^-1 F P = E^T, i.e. E in row layout; g = m - E mp; L = P - E F P)
         V2 FP[D], Pp[D];
         float mp[D];
-        zero2<D>(FP); mm<D, false>(FP, Fc, P);
+        mm<D, false, true>(FP, Fc, P);
         copy2<D>(Pp, Q); mm<D, false>(Pp, FP, Fr);
         const V2 mpl = coldot<D>(Fr, m);                // (F m)[own rows]
         spread<D>(mpl, mp);
@@ -614,7 +623,7 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a, char* l
             spd_solve<D>(M, W);
             spread<D>(ml - coldot<D>(W, mp), gn);       // m - E mp
             V2 T[D];
-            zero2<D>(T); mm<D, true>(T, W, FP);         // E (F P)
+            mm<D, true, true>(T, W, FP);         // E (F P)
 #pragma unroll
             for (int i = 0; i < D; ++i) Ln[i] = P[i] - T[i];
             if constexpr (WD) {
@@ -679,7 +688,7 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a, char* l
         if (elem) {
             V2 X[D];
             float g2[D];
-            zero2<D>(X); mm<D, false>(X, Ln, Tt);
+            mm<D, false, true>(X, Ln, Tt);
             spread<D>(coldot<D>(Tt, gn), g2);
             // Beyond the end of a segment that is NOT the last of its series there is nothing to fold: the F = 0 steps
             // would put E = 0 into a total that the ranks after this one still have to extend.  (A whole quad takes the
@@ -688,7 +697,7 @@ __device__ __forceinline__ void apply1_body(const rc::RcArgsT<float>& a, char* l
                 mm<D, true>(Ls, Tt, X);
 #pragma unroll
                 for (int i = 0; i < D; ++i) gt[i] += g2[i];
-                zero2<D>(X); mm<D, false>(X, W, Tt);
+                mm<D, false, true>(X, W, Tt);
                 copy2<D>(Tt, X);
             }
         }
@@ -781,7 +790,7 @@ __device__ __forceinline__ void smooth1_body(const rc::RcArgsT<float>& a, char* 
             __builtin_amdgcn_sched_barrier(0);
         }
         V2 T[D], nP[D];
-        zero2<D>(T); mm<D, true>(T, W, sP);             // E sP
+        mm<D, true, true>(T, W, sP);             // E sP
         copy2<D>(nP, L); mm<D, false>(nP, T, W);        // + (E sP) E^T
         const V2 sl = coldot<D>(W, sm) + gl;            // (E sm + g)[own rows]
         if constexpr (!WD) load(sn);
