@@ -42,9 +42,9 @@ constexpr int kChains = 16;                 // chains (quads) per wavefront
 constexpr bool kPrefetchEarly = PGPS_QC_PREFETCH_EARLY != 0;
 // Waves per SIMD each kernel is compiled for (register budget 512 / waves; PGPS_QC_WAVES forces one value on all).  The
 // filter + smoothing-element pass holds a dozen 2 d-register matrices and spills on 256 registers at every d (d = 6:
-// 100 B a lane inside the step loop, 450 us against 348 us on 512); the reduce pass fits 256 up to d = 6 (95 against
-// 109 us); the smoother and the filter-only pass fit everywhere (d = 6: 131 against 186 us).  Measured at 2^20 steps:
-// profiles/r03_experiments.txt.
+// 100 B a lane inside the step loop, 450 us at 2^20 steps against 240-270 us on 512); the reduce pass fits 256 up to d = 6
+// (232 registers, no spills), the smoother and the filter-only pass fit everywhere (116 / 154 at d = 6) -- a grid of 1024
+// waves puts one on every SIMD either way, so the smaller budgets cost nothing.  profiles/r03_experiments.txt.
 #ifdef PGPS_QC_WAVES
 constexpr int waves_reduce(int) { return PGPS_QC_WAVES; }
 constexpr int waves_apply(int, bool) { return PGPS_QC_WAVES; }
