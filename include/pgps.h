@@ -411,6 +411,13 @@ int pgps_series_gp_ll_f64(pgps_series* s, int d, double lam, const double* N1, c
 int pgps_series_gp_ll_grad_f64(pgps_series* s, int d, int np, const double* model, double* out /* 1 + np */);
 int pgps_series_gp_predict_f64(pgps_series* s, int d, double lam, const double* N1, const double* N2, const double* Pinf,
                                const double* H, double R, double* mean /* K */, double* var /* K */, double* ll /* or NULL */);
+/* ... and for ANY kernel's LTI model (F, Pinf, H: host pointers; fp64, 2 <= d <= PGPS_MAX_DIM): pgps_lti_ll_f64 /
+ * pgps_lti_predict_f64 / pgps_lti_ll_batch_f64 (models: B rows [F | Pinf | H | R], d <= 16) on the resident series and its
+ * merged query grid -- the evaluation loop of an optimiser or sampler over an RBF / Periodic / composite kernel. */
+int pgps_series_lti_ll_f64(pgps_series* s, int d, const double* F, const double* Pinf, const double* H, double R, double* ll);
+int pgps_series_lti_predict_f64(pgps_series* s, int d, const double* F, const double* Pinf, const double* H, double R,
+                                double* mean /* K */, double* var /* K */, double* ll /* or NULL */);
+int pgps_series_lti_ll_batch_f64(pgps_series* s, int B, int d, const double* models, double* ll /* B */);
 
 #ifdef __cplusplus
 }

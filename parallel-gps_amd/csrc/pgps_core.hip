@@ -1490,35 +1490,28 @@ static int lti_dev_wc(pgps_ctx* ctx, size_t m, int d, const double* model, const
     return PGPS_OK;
 }
 
-static int lti_dev(pgps_ctx* ctx, long N, long K, int d, const double* F, const double* Pinf, const double* H, double R,
-                   const double* ts, const double* ys, double t0, const double* tq, double* mean, double* var,
-                   double* ll) {
-    if (!ctx || N < 1 || K < 0 || !F || !Pinf || !H || !ts || !ys) return PGPS_E_INVALID;
-    if (K > 0 && (!tq || !mean || !var)) return PGPS_E_INVALID;
-    if (K == 0 && !ll) return PGPS_E_INVALID;
-    if (d < rc::kDimMin || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
-    if (N + K > 0x7fffffffL) return PGPS_E_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t m = (size_t)(N + K), dd = (size_t)d * d;
-    // the small model: [F | Pinf | H] from host memory
-    double* model;
+// the small model [F | Pinf | H] from host memory, in ONE copy (three pageable copies were 15 us of a short series' call;
+// the source is staged by the runtime before the call returns, so it may change afterwards)
+static int lti_model_in(pgps_ctx* ctx, int d, const double* F, const double* Pinf, const double* H, double** model) {
+    const size_t dd = (size_t)d * d;
     TRY(ensure(ctx, ctx->lti[0], (2 * dd + d) * sizeof(double)));
-    model = (double*)ctx->lti[0].p;
-    HIPCHK(ctx, hipMemcpyAsync(model, F, dd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(model + dd, Pinf, dd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(model + 2 * dd, H, d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    // the pageable host sources may change after return: the copies above are staged by the runtime before it
-    // returns (pageable memcpy semantics), so no synchronisation is needed here
-    const double *ts_m = ts, *ys_m = ys;
-    int* qslot = nullptr;
-    if (K > 0) {
-        double *tsm, *ysm;
-        TRY(stage_in<double>(ctx, ctx->lti[1], nullptr, m, &tsm));
-        TRY(stage_in<double>(ctx, ctx->lti[2], nullptr, m, &ysm));
-        TRY(stage_in<int>(ctx, ctx->lti[3], nullptr, m, &qslot));
-        TRY(launch_merge<double>(ctx, N, K, ts, ys, tq, tsm, ysm, qslot));
-        ts_m = tsm; ys_m = ysm;
-    }
+    *model = (double*)ctx->lti[0].p;
+    double host[2 * PGPS_MAX_DIM * PGPS_MAX_DIM + PGPS_MAX_DIM];
+    std::memcpy(host, F, dd * sizeof(double));
+    std::memcpy(host + dd, Pinf, dd * sizeof(double));
+    std::memcpy(host + 2 * dd, H, (size_t)d * sizeof(double));
+    HIPCHK(ctx, hipMemcpyAsync(*model, host, (2 * dd + d) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return PGPS_OK;
+}
+
+// m steps (training and query rows merged: qslot != nullptr marks the query rows and asks for the posterior there),
+// everything on the device except the model
+static int lti_core(pgps_ctx* ctx, size_t m, int d, const double* F, const double* Pinf, const double* H, double R,
+                    const double* ts_m, const double* ys_m, double t0, const int* qslot, double* mean, double* var,
+                    double* ll) {
+    const size_t dd = (size_t)d * d;
+    double* model;
+    TRY(lti_model_in(ctx, d, F, Pinf, H, &model));
     double *Fs, *Qs = nullptr, *dll;
     TRY(stage_in<double>(ctx, ctx->st[11], nullptr, 2, &dll));
     if (d > rc::kDimMax) return lti_dev_wc(ctx, m, d, model, F, Pinf, R, ts_m, ys_m, t0, qslot, mean, var, ll ? ll : dll);
@@ -1530,11 +1523,34 @@ static int lti_dev(pgps_ctx* ctx, long N, long K, int d, const double* F, const 
     a.N = (long)m; a.seg_first = 1; a.seg_last = 1;
     a.P0 = model + dd; a.H = model + 2 * dd; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys_m;
     a.ll = ll ? ll : dll;
-    if (K == 0) return launch_scan_rc_proj(ctx, a, d, MODE_PKF, nullptr, nullptr, nullptr);
+    if (!qslot) return launch_scan_rc_proj(ctx, a, d, MODE_PKF, nullptr, nullptr, nullptr);
     // scratch for the smoothing elements (E, g) where pkfs would have sPs, sms
     TRY(stage_in<double>(ctx, ctx->lti[6], nullptr, m * dd, &a.sPs));
     TRY(stage_in<double>(ctx, ctx->lti[7], nullptr, m * d, &a.sms));
     return launch_scan_rc_proj(ctx, a, d, MODE_PKFS, qslot, mean, var);
+}
+
+static int lti_dev(pgps_ctx* ctx, long N, long K, int d, const double* F, const double* Pinf, const double* H, double R,
+                   const double* ts, const double* ys, double t0, const double* tq, double* mean, double* var,
+                   double* ll) {
+    if (!ctx || N < 1 || K < 0 || !F || !Pinf || !H || !ts || !ys) return PGPS_E_INVALID;
+    if (K > 0 && (!tq || !mean || !var)) return PGPS_E_INVALID;
+    if (K == 0 && !ll) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
+    if (N + K > 0x7fffffffL) return PGPS_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t m = (size_t)(N + K);
+    const double *ts_m = ts, *ys_m = ys;
+    int* qslot = nullptr;
+    if (K > 0) {
+        double *tsm, *ysm;
+        TRY(stage_in<double>(ctx, ctx->lti[1], nullptr, m, &tsm));
+        TRY(stage_in<double>(ctx, ctx->lti[2], nullptr, m, &ysm));
+        TRY(stage_in<int>(ctx, ctx->lti[3], nullptr, m, &qslot));
+        TRY(launch_merge<double>(ctx, N, K, ts, ys, tq, tsm, ysm, qslot));
+        ts_m = tsm; ys_m = ysm;
+    }
+    return lti_core(ctx, m, d, F, Pinf, H, R, ts_m, ys_m, t0, qslot, mean, var, ll);
 }
 
 static int lti_host(pgps_ctx* ctx, long N, long K, int d, const double* F, const double* Pinf, const double* H, double R,
@@ -1600,6 +1616,63 @@ extern "C" int pgps_lti_ll_batch_f64(pgps_ctx* c, int B, long N, int d, const do
 extern "C" int pgps_lti_ll_batch_dev_f64(pgps_ctx* c, int B, long N, int d, const double* models, const double* ts,
                                          const double* ys, double t0, double* ll) {
     return lti_ll_batch_dev(c, B, N, d, models, ts, ys, t0, ll);
+}
+
+// the same three calls for ANY kernel's LTI model (F, Pinf, H from the host; fp64, 2 <= d <= 32): pgps_lti_ll_* /
+// pgps_lti_predict_* / pgps_lti_ll_batch_* on the resident series and its merged query grid
+extern "C" int pgps_series_lti_ll_f64(pgps_series* s, int d, const double* F, const double* Pinf, const double* H, double R,
+                                      double* ll) {
+    if (!s || !ll || !F || !Pinf || !H) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
+    pgps_ctx* ctx = s->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double* const res = s->zero_copy ? s->hdev : s->res;
+    TRY(lti_core(ctx, (size_t)s->N, d, F, Pinf, H, R, s->ts, s->ys, s->t0, nullptr, nullptr, nullptr, res));
+    if (!s->zero_copy) HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *ll = s->host[0];
+    return std::isfinite(*ll) ? PGPS_OK : PGPS_E_NUMERIC;
+}
+
+extern "C" int pgps_series_lti_predict_f64(pgps_series* s, int d, const double* F, const double* Pinf, const double* H, double R,
+                                           double* mean, double* var, double* ll) {
+    if (!s || s->K < 1 || !mean || !var || !F || !Pinf || !H) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
+    pgps_ctx* ctx = s->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t K = (size_t)s->K;
+    double* const dm = s->zero_copy ? s->hdev : s->pm;
+    double* const dv = s->zero_copy ? s->hdev + K : s->pv;
+    double* const dl = s->zero_copy ? s->hdev + 2 * K : s->res;
+    TRY(lti_core(ctx, (size_t)(s->N + s->K), d, F, Pinf, H, R, s->ts_m, s->ys_m, s->t0, s->qslot, dm, dv, dl));
+    if (!s->zero_copy) {
+        HIPCHK(ctx, hipMemcpyAsync(s->host, s->pm, K * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(s->host + K, s->pv, K * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(s->host + 2 * K, s->res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(mean, s->host, K * 8);
+    std::memcpy(var, s->host + K, K * 8);
+    if (ll) *ll = s->host[2 * K];
+    return std::isfinite(s->host[2 * K]) ? PGPS_OK : PGPS_E_NUMERIC;
+}
+
+extern "C" int pgps_series_lti_ll_batch_f64(pgps_series* s, int B, int d, const double* models, double* ll) {
+    if (!s || B < 1 || !models || !ll) return PGPS_E_INVALID;
+    pgps_ctx* ctx = s->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double* dll;
+    if (s->zero_copy && (size_t)B <= s->host_cap) dll = s->hdev;
+    else TRY(stage_in<double>(ctx, ctx->st[9], nullptr, (size_t)B, &dll));
+    TRY(lti_ll_batch_dev(ctx, B, s->N, d, models, s->ts, s->ys, s->t0, dll));
+    if (dll != s->hdev) {
+        TRY(stage_out(ctx, ll, dll, (size_t)B));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return PGPS_OK;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(ll, s->host, (size_t)B * sizeof(double));
+    return PGPS_OK;
 }
 
 extern "C" int pgps_lti_ll_f64(pgps_ctx* c, long N, int d, const double* F, const double* Pinf, const double* H, double R,

@@ -658,6 +658,11 @@ class Series:
         lib.pgps_series_gp_ll_f64.argtypes = [P, c_int, c_double, P, P, P, P, c_double, P]
         lib.pgps_series_gp_ll_grad_f64.argtypes = [P, c_int, c_int, P, P]
         lib.pgps_series_gp_predict_f64.argtypes = [P, c_int, c_double, P, P, P, P, c_double, P, P, P]
+        self.has_lti = hasattr(lib, "pgps_series_lti_ll_f64")
+        if self.has_lti:
+            lib.pgps_series_lti_ll_f64.argtypes = [P, c_int, P, P, P, c_double, P]
+            lib.pgps_series_lti_predict_f64.argtypes = [P, c_int, P, P, P, c_double, P, P, P]
+            lib.pgps_series_lti_ll_batch_f64.argtypes = [P, c_int, c_int, P, P]
         self.N, self.K = ts_a.shape[0], 0
         self._tq = None
         h = P()
@@ -697,6 +702,32 @@ class Series:
                                                                float(R), self._llp), "pgps_series_gp_ll_f64")
         return self._ll.value
 
+    # -- any kernel's LTI model (F, Pinf, H), fp64, 2 <= d <= 32: pgps_series_lti_* ------------------------------
+    def lti_ll(self, F, Pinf, H, R):
+        F, Pinf, H, d = _lti_model(F, Pinf, H)
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_lti_ll_f64(self.handle, d, _ptr(F), _ptr(Pinf), _ptr(H), float(R), self._llp),
+                  "pgps_series_lti_ll_f64")
+        return self._ll.value
+
+    def lti_predict(self, F, Pinf, H, R):
+        """(mean (K,), var (K,), ll) at the query grid of set_queries()."""
+        F, Pinf, H, d = _lti_model(F, Pinf, H)
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_lti_predict_f64(self.handle, d, _ptr(F), _ptr(Pinf), _ptr(H), float(R),
+                                                                    _ptr(self._mean), _ptr(self._var), self._llp),
+                  "pgps_series_lti_predict_f64")
+        return self._mean.copy(), self._var.copy(), self._ll.value
+
+    def lti_ll_batch(self, models):
+        """B log-likelihoods: models = [(F, Pinf, H, R)] of one state dimension (2 <= d <= 16)."""
+        table, d = _lti_table(models)
+        out = np.empty(table.shape[0], np.float64)
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_lti_ll_batch_f64(self.handle, table.shape[0], d, _ptr(table), _ptr(out)),
+                  "pgps_series_lti_ll_batch_f64")
+        return out
+
     def gp_ll_grad(self, model, d, npar):
         with self.ctx.lock:
             check(self.ctx, self.ctx.lib.pgps_series_gp_ll_grad_f64(self.handle, d, npar, _ptr(model), _ptr(self._gout)),
@@ -726,21 +757,31 @@ class Series:
             pass
 
 
-def lti_ll_batch(models, ts, ys, t0=0.0, device=0):
-    """Log-likelihoods of B general LTI models over one series in one set of launches (pgps_lti_ll_batch_f64).
-
-    `models`: list of (F, Pinf, H, R) -- what lti_ll() takes, once per model; all of one state dimension."""
-    rows, d = [], None
-    for F, Pinf, H, R in models:
+def _lti_table(models):
+    """(B x [F | Pinf | H | R] float64 table, d) of a list of (F, Pinf, H, R), all of one state dimension."""
+    d, table = None, None
+    for b, (F, Pinf, H, R) in enumerate(models):
         F, Pinf, H, dm = _lti_model(F, Pinf, H)
         if dm > LTI_BATCH_DIM_MAX:
             raise ValueError(f"batched general-LTI evaluation covers state dimensions up to {LTI_BATCH_DIM_MAX}, got {dm}")
         if d is None:
             d = dm
+            table = np.empty((len(models), 2 * d * d + d + 1), np.float64)
         if dm != d:
             raise ValueError("all models of a batch must have the same state dimension")
-        rows.append(np.concatenate([F.reshape(-1), Pinf.reshape(-1), H.reshape(-1), [float(R)]]))
-    packed = np.ascontiguousarray(np.stack(rows), dtype=np.float64)
+        row = table[b]
+        row[:d * d] = F.reshape(-1)
+        row[d * d:2 * d * d] = Pinf.reshape(-1)
+        row[2 * d * d:2 * d * d + d] = H.reshape(-1)
+        row[-1] = R
+    return table, d
+
+
+def lti_ll_batch(models, ts, ys, t0=0.0, device=0):
+    """Log-likelihoods of B general LTI models over one series in one set of launches (pgps_lti_ll_batch_f64).
+
+    `models`: list of (F, Pinf, H, R) -- what lti_ll() takes, once per model; all of one state dimension."""
+    packed, d = _lti_table(models)
     ts_a = _prep(ts, np.float64, (-1,))
     ys_a = _prep(ys, np.float64, (-1,))
     if ys_a.shape[0] != ts_a.shape[0]:

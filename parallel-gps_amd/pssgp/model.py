@@ -283,8 +283,14 @@ class StateSpaceGP:
         if (lti is not None and squeezed_Xnew.size > 0 and np.all(np.diff(squeezed_ts) >= 0)
                 and np.all(np.diff(squeezed_Xnew) >= 0)):
             # kernels without the closed-form discretisation (RBF, Periodic, sums, products): merge, discretisation,
-            # filter + smoother and projection on the device as well
+            # filter + smoother and projection on the device as well -- on the resident series where there is one
             from . import _backend
+            ser = self._device_series() if squeezed_ts.dtype == np.float64 else None
+            if ser is not None and ser.has_lti:
+                ser.set_queries(squeezed_Xnew)
+                mean, var, ll = ser.lti_predict(lti.F, lti.P0, lti.H, self.noise_variance)
+                self._ll_memo = (self._param_key(), self.noise_variance, ser, config.default_float()(ll))
+                return mean[:, None].astype(dtype), var[:, None].astype(dtype)
             mean, var, _ = _backend.lti_predict(lti.F, lti.P0, lti.H, self.noise_variance, squeezed_ts, ys.reshape(-1),
                                                 squeezed_Xnew)
             return mean[:, None].astype(dtype), var[:, None].astype(dtype)
@@ -324,6 +330,12 @@ class StateSpaceGP:
             return _backend.gp(form, sde.P0, sde.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))["ll"]
         if lti is not None:
             from . import _backend
+            ser = self._device_series() if ts.dtype == np.float64 else None
+            if ser is not None and ser.has_lti:
+                memo = getattr(self, "_ll_memo", None)
+                if memo is not None and memo[2] is ser and memo[1] == self.noise_variance and memo[0] == self._param_key():
+                    return memo[3]
+                return config.default_float()(ser.lti_ll(lti.F, lti.P0, lti.H, self.noise_variance))
             ll = _backend.lti_ll(lti.F, lti.P0, lti.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))
             return config.default_float()(ll)
         ssm = self._make_model(ts)
@@ -627,6 +639,9 @@ class StateSpaceGP:
             return _backend.gp_ll_batch(models, ts.reshape(-1), Y.reshape(-1))
         d = general[0][0].shape[0]
         if _backend.LTI_DIM_MIN <= d <= _backend.LTI_BATCH_DIM_MAX:
+            ser = self._device_series() if ts.dtype == np.float64 else None
+            if ser is not None and ser.has_lti:
+                return ser.lti_ll_batch(general)
             return _backend.lti_ll_batch(general, ts.reshape(-1), Y.reshape(-1))
         raise NotImplementedError(f"batched evaluation covers the Matern family and state dimensions "
                                   f"{_backend.LTI_DIM_MIN}..{_backend.LTI_DIM_MAX}; this kernel has d = {d}")

@@ -82,9 +82,10 @@ def test_state_space_gp_dispatches_to_the_lti_path(monkeypatch):
     from pssgp.kernels import RBF
     from pssgp.model import StateSpaceGP
     calls = []
-    real_ll, real_pr = B.lti_ll, B.lti_predict
-    monkeypatch.setattr(B, "lti_ll", lambda *a, **k: calls.append("ll") or real_ll(*a, **k))
-    monkeypatch.setattr(B, "lti_predict", lambda *a, **k: calls.append("predict") or real_pr(*a, **k))
+    # (since round 3 the model keeps its series on the device and calls pgps_series_lti_* through _backend.Series)
+    real_ll, real_pr = B.Series.lti_ll, B.Series.lti_predict
+    monkeypatch.setattr(B.Series, "lti_ll", lambda self, *a, **k: calls.append("ll") or real_ll(self, *a, **k))
+    monkeypatch.setattr(B.Series, "lti_predict", lambda self, *a, **k: calls.append("predict") or real_pr(self, *a, **k))
     rng = np.random.RandomState(31415926)
     T, K = 200, 50
     t = np.sort(rng.rand(T))

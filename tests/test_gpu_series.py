@@ -95,3 +95,43 @@ def test_statespacegp_uses_the_resident_series():
     sde = gp.kernel.get_sde()
     assert abs(ll3 - float(B.gp(B.nilpotent_form(sde.F), sde.P0, sde.H, 0.1, t, y)["ll"])) < 1e-10 * abs(ll3)
     assert abs(ll3 - ll) > 1e-3
+
+
+@pytest.mark.parametrize("kname,n", [("rbf6", 700), ("rbf6", 20000), ("c5", 3000), ("periodic7", 900), ("co2_d18", 400)])
+def test_series_lti_calls_match_host_entry_points(kname, n):
+    """pgps_series_lti_* (any kernel's LTI model on the resident series) against pgps_lti_ll_* / _predict_* / _ll_batch_* on
+    host arrays -- row-cooperative (d <= 16) and wave-cooperative (d = 18) paths -- and the model routes through them."""
+    from pssgp import _backend as B
+    from pssgp.kernels import Matern32, Matern52, Periodic, RBF, SquaredExponential
+    from pssgp.model import StateSpaceGP
+    k = {"rbf6": lambda: RBF(1.0, 0.8, order=6, balancing_iter=10),
+         "c5": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.),
+         "periodic7": lambda: Periodic(SquaredExponential(1., 0.5), period=0.5, order=7),
+         "co2_d18": lambda: Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern32(1., 2.) + RBF(1., 1., order=4)}[kname]()
+    sde = k.get_sde()
+    d = np.asarray(sde.F).shape[0]
+    t, y = _data(n, seed=n + d)
+    y[::11] = np.nan
+    tq = np.sort(np.random.default_rng(5).uniform(t[0] - 0.5, t[-1] + 0.5, max(3, n // 5)))
+    ref_ll = B.lti_ll(sde.F, sde.P0, sde.H, 0.1, t, y)
+    ref_mean, ref_var, _ = B.lti_predict(sde.F, sde.P0, sde.H, 0.1, t, y, tq)
+    ser = B.Series(t, y)
+    assert ser.has_lti
+    assert abs(ser.lti_ll(sde.F, sde.P0, sde.H, 0.1) - ref_ll) <= 1e-12 * abs(ref_ll)
+    ser.set_queries(tq)
+    mean, var, ll = ser.lti_predict(sde.F, sde.P0, sde.H, 0.1)
+    assert np.max(np.abs(mean - ref_mean)) < 1e-10 and np.max(np.abs(var - ref_var)) < 1e-10
+    assert abs(ll - ref_ll) <= 1e-11 * abs(ref_ll)
+    if d <= B.LTI_BATCH_DIM_MAX:
+        models = [(sde.F, sde.P0 * s, sde.H, r) for s, r in ((1.0, 0.1), (1.3, 0.2), (0.7, 0.05))]
+        assert np.max(np.abs(ser.lti_ll_batch(models) - B.lti_ll_batch(models, t, y))) <= 1e-11 * abs(ref_ll)
+    ser.close()
+    # the model: objective, prediction (and the objective again, handed over by the prediction), gradient
+    m = StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=0.1, parallel=True)
+    assert abs(float(m.maximum_log_likelihood_objective()) - ref_ll) <= 1e-11 * abs(ref_ll)
+    pm, pv = m.predict_f(tq[:, None])
+    assert np.max(np.abs(pm[:, 0] - ref_mean)) < 1e-10 and np.max(np.abs(pv[:, 0] - ref_var)) < 1e-10
+    assert abs(float(m.maximum_log_likelihood_objective()) - ref_ll) <= 1e-11 * abs(ref_ll)
+    if d <= B.LTI_BATCH_DIM_MAX:
+        ll_g, g = m.log_likelihood_and_grad()
+        assert abs(ll_g - ref_ll) <= 1e-10 * abs(ref_ll) and np.all(np.isfinite(g))
