@@ -1,28 +1,20 @@
-"""Matern-3/2, state dim 2; closed-form P_inf = diag(s2, lambda^2 s2)
-(reference: matern/matern32.py:10-28)."""
-import math
-
-import numpy as np
-
+"""Matern-3/2, state dimension 2, Pinf = diag(s2, lam^2 s2) in closed form: the p = 1 member of MaternFamily (common.py).\nReference semantics: pssgp/kernels/matern/matern32.py:10-28."""
 from ..base import ContinuousDiscreteModel, Kernel, SDEKernelMixin, _pairwise_dist, get_lssm_spec
-from .common import get_matern_sde
+from .common import MaternFamily
 
 
-class Matern32(SDEKernelMixin, Kernel):
+class Matern32(MaternFamily, SDEKernelMixin, Kernel):
+    state_dim = 2
+
     def __init__(self, variance=1.0, lengthscales=1.0, **kwargs):
-        self.variance = float(variance)
-        self.lengthscales = float(lengthscales)
+        self._init_matern(variance, lengthscales, kwargs)
         SDEKernelMixin.__init__(self, **kwargs)
 
     def K(self, X, X2=None):
-        r = math.sqrt(3.0) * _pairwise_dist(X, X2) / self.lengthscales
-        return self.variance * (1.0 + r) * np.exp(-r)
+        return self._matern_K(_pairwise_dist(X, X2))
 
     def get_spec(self, T):
-        return get_lssm_spec(2, T)
+        return get_lssm_spec(self.state_dim, T)
 
     def get_sde(self):
-        F, L, H, Q = get_matern_sde(self.variance, self.lengthscales, 2)
-        lam = math.sqrt(3.0) / self.lengthscales
-        P_infty = np.diag([self.variance, lam ** 2 * self.variance])
-        return ContinuousDiscreteModel(P_infty, F, L, H, Q)
+        return ContinuousDiscreteModel(*self._matern_sde())

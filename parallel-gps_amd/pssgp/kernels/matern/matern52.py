@@ -1,31 +1,21 @@
-"""Matern-5/2, state dim 3; balanced, P_inf from the Lyapunov solve
-(reference: matern/matern52.py:10-25)."""
-import math
-
-import numpy as np
-
-from ... import config as pssgp_config
+"""Matern-5/2, state dimension 3, balanced, Pinf from the Lyapunov equation: the p = 2 member of MaternFamily (common.py).\nReference semantics: pssgp/kernels/matern/matern52.py:10-25."""
 from ..base import ContinuousDiscreteModel, Kernel, SDEKernelMixin, _pairwise_dist, get_lssm_spec
-from ..math_utils import balance_ss, solve_lyap_vec
-from .common import get_matern_sde
+from .common import MaternFamily
 
 
-class Matern52(SDEKernelMixin, Kernel):
+class Matern52(MaternFamily, SDEKernelMixin, Kernel):
+    state_dim = 3
+    balanced = True
+
     def __init__(self, variance=1.0, lengthscales=1.0, **kwargs):
-        self._balancing_iter = kwargs.pop('balancing_iter', pssgp_config.NUMBER_OF_BALANCING_STEPS)
-        self.variance = float(variance)
-        self.lengthscales = float(lengthscales)
+        self._init_matern(variance, lengthscales, kwargs)
         SDEKernelMixin.__init__(self, **kwargs)
 
     def K(self, X, X2=None):
-        r = math.sqrt(5.0) * _pairwise_dist(X, X2) / self.lengthscales
-        return self.variance * (1.0 + r + r * r / 3.0) * np.exp(-r)
+        return self._matern_K(_pairwise_dist(X, X2))
 
     def get_spec(self, T):
-        return get_lssm_spec(3, T)
+        return get_lssm_spec(self.state_dim, T)
 
     def get_sde(self):
-        F, L, H, q = get_matern_sde(self.variance, self.lengthscales, 3)
-        Fb, Lb, Hb, Qb = balance_ss(F, L, H, q, n_iter=self._balancing_iter)
-        Pinf = solve_lyap_vec(Fb, Lb, Qb)
-        return ContinuousDiscreteModel(Pinf, Fb, Lb, Hb, Qb)
+        return ContinuousDiscreteModel(*self._matern_sde())
