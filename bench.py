@@ -66,7 +66,7 @@ def parse():
                     help="lib: RCCL communicator owned by the libpgps context, one call per pass (default); torch: the "
                          "three library phases with torch.distributed collectives in between (--dist-backend)")
     ap.add_argument("--kernel", default="matern32",
-                    choices=["matern32", "matern52", "matern12", "c5", "periodic10"] + [f"rbf{n}" for n in range(2, 33)],
+                    choices=["matern32", "matern52", "matern12", "c5", "periodic10", "co2"] + [f"rbf{n}" for n in range(2, 33)],
                     help="rbfN = RBF of order N (state dimension N)")
     ap.add_argument("--family", type=int, default=0,
                     help="0 auto, 1 lane-chunk, 2 wave-cooperative, 3 row-cooperative, 4 quad-cooperative (fp32, d = 5..8) kernels")
@@ -137,7 +137,11 @@ def make_kernel(name):
             # BASELINE config c5: quasi-periodic (Periodic * Matern32) + Matern52, d = 11
             "c5": lambda: Periodic(SquaredExponential(1.0, 1.0), period=1.0, order=1) * Matern32(1.0, 1.0)
             + Matern52(1.0, 1.0),
-            "periodic10": lambda: Periodic(SquaredExponential(1.0, 1.0), period=1.0, order=10)}[name]()
+            "periodic10": lambda: Periodic(SquaredExponential(1.0, 1.0), period=1.0, order=10),
+            # the reference's CO2 kernel at its default order 3 (pssgp/experiments/co2/mcmc.py:42-65): d = 18, the
+            # wave-cooperative family
+            "co2": lambda: Periodic(SquaredExponential(5.0, 1.0), period=1.0, order=3) * Matern32(0.1, 50.0)
+            + Matern32(1.0, 100.0)}[name]()
 
 
 def sample_prior_observations(P0, Fs, Qs, H, R, rng):
