@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import config as pssgp_config
 from ..kalman.base import LGSSM
-from .math_utils import balance_ss, solve_lyap_vec
+from .math_utils import balance_ss, balanced_covariance, kron, solve_lyap_vec
 
 ContinuousDiscreteModel = namedtuple("ContinuousDiscreteModel", ["P0", "F", "L", "H", "Q"])
 
@@ -148,8 +148,11 @@ class SDESum(_Combination):
         L = block_diag([np.atleast_2d(p.L) for p in parts])
         H = np.concatenate([np.atleast_2d(p.H) for p in parts], axis=1)
         Q = block_diag([np.atleast_2d(p.Q) for p in parts])
-        Fb, Lb, Hb, Qb = balance_ss(F, L, H, Q, pssgp_config.NUMBER_OF_BALANCING_STEPS)
-        Pinf = solve_lyap_vec(Fb, Lb, Qb)
+        Fb, Lb, Hb, Qb, scaling = balance_ss(F, L, H, Q, pssgp_config.NUMBER_OF_BALANCING_STEPS, return_scaling=True)
+        # independent parts: the stationary covariance is block diagonal before balancing
+        Pinf = balanced_covariance(block_diag([p.P0 for p in parts]), scaling, Fb, Lb, Qb)
+        if Pinf is None:
+            Pinf = solve_lyap_vec(Fb, Lb, Qb)
         return ContinuousDiscreteModel(Pinf, Fb, Lb, Hb, Qb)
 
 
@@ -171,12 +174,12 @@ class SDEProduct(_Combination):
         """Unbalanced product of two SDEs (base.py:200-220,235-239): F = F1 (+) F2,
         diffusion = G1 (x) P2 + P1 (x) G2 with G = L Q L^T, H = H1 (x) H2."""
         n1, n2 = s1.F.shape[0], s2.F.shape[0]
-        F = np.kron(s1.F, np.eye(n2)) + np.kron(np.eye(n1), s2.F)
+        F = kron(s1.F, np.eye(n2)) + kron(np.eye(n1), s2.F)
         G1 = s1.L @ np.atleast_2d(s1.Q) @ s1.L.T
         G2 = s2.L @ np.atleast_2d(s2.Q) @ s2.L.T
-        Q = np.kron(G1, s2.P0) + np.kron(s1.P0, G2)
-        H = np.kron(np.atleast_2d(s1.H), np.atleast_2d(s2.H))
-        P0 = np.kron(s1.P0, s2.P0)
+        Q = kron(G1, s2.P0) + kron(s1.P0, G2)
+        H = kron(np.atleast_2d(s1.H), np.atleast_2d(s2.H))
+        P0 = kron(s1.P0, s2.P0)
         return ContinuousDiscreteModel(P0, F, np.eye(n1 * n2), H, Q)
 
     def get_sde(self):
@@ -184,7 +187,10 @@ class SDEProduct(_Combination):
         acc = sdes[0]
         for nxt in sdes[1:]:
             acc = self._pair(acc, nxt)
-        Fb, Lb, Hb, Qb = balance_ss(acc.F, acc.L, acc.H, acc.Q,
-                                    pssgp_config.NUMBER_OF_BALANCING_STEPS)
-        Pinf = solve_lyap_vec(Fb, Lb, Qb)
+        Fb, Lb, Hb, Qb, scaling = balance_ss(acc.F, acc.L, acc.H, acc.Q, pssgp_config.NUMBER_OF_BALANCING_STEPS,
+                                             return_scaling=True)
+        # a product of independent stationary processes: P0 = P1 (x) P2 before balancing (carried by _pair)
+        Pinf = balanced_covariance(acc.P0, scaling, Fb, Lb, Qb)
+        if Pinf is None:
+            Pinf = solve_lyap_vec(Fb, Lb, Qb)
         return ContinuousDiscreteModel(Pinf, Fb, Lb, Hb, Qb)

@@ -13,6 +13,14 @@ except Exception:                       # pragma: no cover
     _lyap = None
 
 
+def kron(A, B):
+    """np.kron for the small matrices of an SDE, as one broadcast product (np.kron spends ~35 us of Python per call on
+    them, nine calls per composite get_sde()); same entries, same values."""
+    A = np.atleast_2d(np.asarray(A, np.float64))
+    B = np.atleast_2d(np.asarray(B, np.float64))
+    return (A[:, None, :, None] * B[None, :, None, :]).reshape(A.shape[0] * B.shape[0], A.shape[1] * B.shape[1])
+
+
 def _native_balancing_diagonal(F, n_iter):
     """The same sweep in libpgps' host code (pgps_host_balance_f64; the reference compiles this loop with numba):
     None when the library is not built."""
@@ -55,11 +63,13 @@ def _balancing_diagonal(F, n_iter):
     return scale
 
 
-def balance_ss(F, L, H, q, n_iter=5):
+def balance_ss(F, L, H, q, n_iter=5, return_scaling=False):
     """Balance (F, L, H, q) for numerical stability; returns (F, L, H, q).
 
     F <- D^-1 F D, L <- D^-1 L, H <- H D, then L and H are normalised to unit
     max-abs with q absorbing both squared factors (math_utils.py:68-81).
+    return_scaling: also (d, h_max) -- the balanced state is  x_b = h_max D^-1 x  (L's normalisation is absorbed by q and
+    leaves the state alone), so a stationary covariance known before balancing is known after it: balanced_covariance().
     """
     F = np.asarray(F, dtype=np.float64)
     L = np.asarray(L, dtype=np.float64)
@@ -75,7 +85,26 @@ def balance_ss(F, L, H, q, n_iter=5):
     h_max = np.max(np.abs(Hb))
     Hb = Hb / h_max
     q = (h_max ** 2) * q
+    if return_scaling:
+        return Fb, Lb, Hb, q, (d, h_max)
     return Fb, Lb, Hb, q
+
+
+def balanced_covariance(P, scaling, Fb, Lb, qb, tol=1e-9):
+    """Stationary covariance of the BALANCED model from the one of the model before balancing, P_b = h_max^2 D^-1 P D^-1
+    -- what sums and products of kernels know in closed form (block diagonal, Kronecker product of the parts') and the
+    reference obtains from a Lyapunov solve of the balanced system (base.py:130-183, 186-244): the same matrix, without
+    the two Schur decompositions that were 45 % of a composite kernel's get_sde().  Checked against the Lyapunov
+    equation; None (the caller then solves it) if the residual is not at rounding level."""
+    d, h_max = scaling
+    Pb = (h_max * h_max) * np.asarray(P, np.float64) / np.outer(d, d)
+    Pb = 0.5 * (Pb + Pb.T)
+    G = Lb @ np.atleast_2d(qb) @ Lb.T
+    res = Fb @ Pb + Pb @ Fb.T + G
+    scale = max(float(np.max(np.abs(G))), float(np.max(np.abs(Fb))) * float(np.max(np.abs(Pb))), 1e-300)
+    if not np.all(np.isfinite(res)) or float(np.max(np.abs(res))) > tol * scale:
+        return None
+    return Pb
 
 
 def solve_lyap_vec(F, L, Q):

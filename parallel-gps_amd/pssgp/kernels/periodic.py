@@ -12,6 +12,7 @@ import numpy as np
 from scipy.special import comb, factorial
 
 from .base import ContinuousDiscreteModel, Kernel, SDEKernelMixin, _pairwise_dist, get_lssm_spec
+from .math_utils import kron
 
 
 class SquaredExponential(Kernel):
@@ -64,8 +65,8 @@ class Periodic(SDEKernelMixin, Kernel):
             * self.base_kernel.variance
         q2 = np.sum(terms, axis=0)
         rot = np.array([[0.0, -w0], [w0, 0.0]])
-        F = np.kron(np.diag(np.arange(N + 1, dtype=np.float64)), rot)
+        F = kron(np.diag(np.arange(N + 1, dtype=np.float64)), rot)
         dim = 2 * (N + 1)
-        Pinf = np.kron(np.diag(q2), np.eye(2))
-        H = np.kron(np.ones((1, N + 1)), np.array([[1.0, 0.0]]))
+        Pinf = kron(np.diag(q2), np.eye(2))
+        H = kron(np.ones((1, N + 1)), np.array([[1.0, 0.0]]))
         return ContinuousDiscreteModel(Pinf, F, np.eye(dim), H, np.zeros((dim, dim)))
