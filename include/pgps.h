@@ -94,7 +94,7 @@ int pgps_set_one_launch(pgps_ctx* ctx, int max_steps);
 /* pgps_gp_ll_grad_* at d <= 2: series up to max_steps take ONE derivative direction per model, the directions side by side
  * in the same launches (a Dual<1> scan tree is less than half of a Dual<3> one, and for a short series the tree's latency
  * is the whole cost); longer ones carry all directions in one dual number (the primal arithmetic is shared).
- * -1 = automatic (32768 steps), 0 = never.  d = 3 always runs one direction per model. */
+ * -1 = automatic (2^18 steps), 0 = never.  d = 3 always runs one direction per model. */
 int pgps_set_grad_pack(pgps_ctx* ctx, long max_steps);
 /* What a lane-chunk call (or one rank's segment) of N steps at state dimension d <= PGPS_MAX_DIM_LANE runs with: lanes per
  * workgroup (128 / 256), steps per lane, workgroups -- after pgps_set_block / pgps_set_chunk. */

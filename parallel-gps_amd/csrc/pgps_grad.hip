@@ -105,9 +105,11 @@ static int launch_grad_pack(pgps_ctx* ctx, long N, int np, const double* model, 
     return PGPS_OK;
 }
 
-// Series up to this many steps take one direction per model at d <= 2 as well (PGPS_GRAD_PACK_MAX; d = 3 always does)
+// Series up to this many steps take one direction per model at d <= 2 as well (PGPS_GRAD_PACK_MAX; d = 3 always does).
+// Matern-3/2, us per call, all directions in one dual / one per model: 2^12 152 / 80, 2^15 158 / 75, 2^17 146 / 104,
+// 2^18 165 / 119, 2^20 207 / 211 (Matern-1/2 at 2^20: 80 / 100) -- tools/grad_pack_probe.py
 #ifndef PGPS_GRAD_PACK_MAX
-#define PGPS_GRAD_PACK_MAX (1L << 15)
+#define PGPS_GRAD_PACK_MAX (1L << 18)
 #endif
 
 // model: (1 + np) consecutive blocks, block 0 = values, block p = d/dtheta_p, each

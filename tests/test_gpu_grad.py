@@ -66,12 +66,13 @@ def test_gradient_chunk_geometry_invariance():
         assert relerr(r, res[0]) < 1e-10
 
 
+@pytest.mark.parametrize("n", [5003, 70001])
 @pytest.mark.parametrize("kname", ["m12", "m32"])
-def test_gradient_one_direction_per_model_equals_all_in_one_dual(kname):
+def test_gradient_one_direction_per_model_equals_all_in_one_dual(kname, n):
     """At d <= 2 short series run one derivative direction per model side by side (a Dual<1> scan tree per direction),
     long ones all directions in one Dual<3> (pgps_set_grad_pack): the same numbers either way."""
     from pssgp import _backend as B
-    cls, _, t, y = grad_case(kname, 5003, 29, nan_frac=0.1)
+    cls, _, t, y = grad_case(kname, n, 29, nan_frac=0.1)
     m = _model(cls, np.array([1.2, 0.6, 0.25]), t, y)
     ctx = B.get_context()
     res = []
@@ -82,7 +83,7 @@ def test_gradient_one_direction_per_model_equals_all_in_one_dual(kname):
             res.append(np.concatenate([[ll], g]))
     finally:
         ctx.set_grad_pack(-1)
-    assert relerr(res[1], res[0]) < 1e-11
+    assert relerr(res[1], res[0]) < 1e-10
 
 
 def test_gradient_descends():
