@@ -213,6 +213,9 @@ __device__ __forceinline__ void gp_apply_body(const GpArgs<T>& g, GpLds<T, D>& s
         const double v = ll.value();
         const double t = block_sum_double(v, lds_ll);
         if (threadIdx.x == 0) a.llpart[blockIdx.x] = t;
+        if constexpr (!SMOOTH) {
+            if (a.ll != nullptr && a.ll_in_apply) ll_finish(a.llpart, a.nblocks, a.ll, a.status + kLlTicketWord, lds_ll);
+        }
     }
     if (SMOOTH) {
         SE excl, total;

@@ -168,8 +168,9 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     if (mode == MODE_PKF || mode == MODE_PKFS) {
         timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_filter_reduce<T, D, G>, grid, block, 0, a);
         if (mode == MODE_PKFS) launch_apply(std::true_type{}); else {
+            a.ll_in_apply = (a.ll != nullptr && a.status != nullptr) ? 1 : 0;
             launch_apply(std::false_type{});
-            if (a.ll) {
+            if (a.ll && !a.ll_in_apply) {
                 timed_launch(ctx, PGPS_K_LL_FINALIZE, k_ll_finalize, dim3(1), block, 0, (const double*)a.llpart, a.nblocks,
                              a.ll);
             }
@@ -249,8 +250,9 @@ static int launch_gp_nt(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_
             timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_gp_smooth<T, D, NT>, grid, block, 0, g);
     } else {
         (void)want_filtered;
+        a.ll_in_apply = (a.ll != nullptr && a.status != nullptr) ? 1 : 0;
         timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_apply<T, D, false, NT>, grid, block, 0, g);
-        if (a.ll)
+        if (a.ll && !a.ll_in_apply)
             timed_launch(ctx, PGPS_K_LL_FINALIZE, k_ll_finalize, dim3(1), block, 0, (const double*)a.llpart, a.nblocks,
                          a.ll);
     }

@@ -140,6 +140,7 @@ struct ScanArgs {
     // single-pass filter (k_filter_single): inter-workgroup look-back state, zeroed before every launch
     int* ticket;            // dynamic tile counter
     int* flags;             // (nblocks,) 0 = nothing, 1 = aggregate published, 2 = inclusive prefix published
+    int ll_in_apply;        // filter-only calls: the apply kernel's last workgroup sums the log-likelihood (no finalize launch)
     T* incl;                // (nblocks, d + d(d+1)/2) inclusive (m, P) of the window-closing tiles
     int win;                // look-back window (tiles); <= kBlock
     long long* stamps;      // diagnostic build only (-DPGPS_STAMPS): (3 kernels, nblocks, 8) s_memtime stamps

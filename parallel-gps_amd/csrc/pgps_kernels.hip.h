@@ -478,6 +478,30 @@ __device__ __forceinline__ double block_sum_double(double x, double* lds) {
     return t;
 }
 
+// The workgroup that draws the last ticket sums every workgroup's log-likelihood partial -- in a fixed order, so the result
+// does not depend on which workgroup that is -- and writes the total: the filter-only calls need no finalize launch of
+// their own (5 us of kernel and a launch boundary on a 37 us call at c1's length).  `ticket` is a device word that is zero
+// between calls (word 16 of the context's status buffer); the summing workgroup resets it.  One call in flight per context.
+constexpr int kLlTicketWord = 16;
+__device__ __forceinline__ void ll_finish(const double* llpart, int nblocks, double* ll, int* ticket, double* lds) {
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        __threadfence();                            // this workgroup's partial before its ticket
+        s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += (int)blockDim.x)
+        v += __hip_atomic_load(&llpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double t = block_sum_double(v, lds);
+    if (threadIdx.x == 0) {
+        *ll = t;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wavefront-private LDS staging: coalesced global <-> LDS, lane-owned records out of LDS.
 //
@@ -1275,6 +1299,9 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
         const double v = ll.value();
         const double t = block_sum_double(v, lds_ll);
         if (threadIdx.x == 0) a.llpart[blockIdx.x] = t;
+        if constexpr (!SMOOTH) {                    // filter only: the total as well (with the smoother, its kernel sums)
+            if (a.ll != nullptr && a.ll_in_apply) ll_finish(a.llpart, a.nblocks, a.ll, a.status + kLlTicketWord, lds_ll);
+        }
     }
     PGPS_STAMP(1, 4);
 
