@@ -39,8 +39,16 @@ template <int DP>
 struct Geo {
     // lane grid GR x GR (lanes >= GR*GR idle in tile operations); DP = 12 serves d = 9..12 (the d = 11
     // config) on a 6 x 6 grid of 2 x 2 tiles with 58 % of the LDS a 16-padding would need
-    static constexpr int GR = (DP == 12) ? 6 : 8;
+    // (DP = 18 likewise serves d = 17, 18 -- the d = 18 CO2 model -- on 6 x 6 lanes of 3 x 3 tiles: 56 % of the
+    // multiply-adds and of the LDS a 24-padding costs, so four waves share a CU instead of two)
+    static constexpr int GR = (DP == 12 || DP == 18) ? 6 : 8;
     static constexpr int TS = DP / GR;          // tile edge of one lane
+    static constexpr int KU = (DP % 4 == 0) ? 4 : 3;    // unroll of the inner-product loops; DP % KU == 0
+    static_assert(DP % KU == 0, "inner-product unroll");
+    // inner-product length for state dimension d: d rounded up to the unroll (never beyond the padded slot)
+    // DP = 18 serves two state dimensions only: full-length inner products there, unrolled at compile time
+    static constexpr bool FIXK = (DP == 18);
+    __host__ __device__ static constexpr int dk(int d) { return FIXK ? DP : (d + KU - 1) / KU * KU; }
     static constexpr int LD = DP + 2;           // leading dimension of an LDS matrix
     static constexpr int MSZ = DP * LD;         // elements of one matrix slot (even)
     static constexpr int NRC = 2 * DP + GR;     // leading dimension of combine's right-hand side [A1 | C1 | w | 0..]
@@ -127,9 +135,9 @@ __device__ __forceinline__ void mm(int dk, const T* __restrict__ A, const T* __r
     for (int ti = 0; ti < TS; ++ti)
 #pragma unroll
         for (int tj = 0; tj < TS; ++tj) acc[ti][tj] = Add ? Add[(r0 + ti) * LD + c0 + tj] : T(0);
-    for (int k0 = 0; k0 < dk; k0 += 4) {
+    for (int k0 = 0; k0 < dk; k0 += Geo<DP>::KU) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < Geo<DP>::KU; ++kk) {
             const int k = k0 + kk;
             T a[TS], b[TS];
 #pragma unroll
@@ -177,16 +185,16 @@ __device__ __forceinline__ void mv(int dk, const T* __restrict__ A, const T* __r
     constexpr int LD = Geo<DP>::LD;
     const int i = lane_id();
     if (i < DP) {
-        T acc0 = add ? add[i] : T(0), acc1 = T(0);
-        for (int k0 = 0; k0 < dk; k0 += 4) {
-            const T a0 = TRANS ? A[(k0 + 0) * LD + i] : A[i * LD + k0 + 0], a1 = TRANS ? A[(k0 + 1) * LD + i] : A[i * LD + k0 + 1];
-            const T a2 = TRANS ? A[(k0 + 2) * LD + i] : A[i * LD + k0 + 2], a3 = TRANS ? A[(k0 + 3) * LD + i] : A[i * LD + k0 + 3];
-            acc0 += a0 * x[k0];
-            acc1 += a1 * x[k0 + 1];
-            acc0 += a2 * x[k0 + 2];
-            acc1 += a3 * x[k0 + 3];
+        constexpr int KU = Geo<DP>::KU;
+        T acc[2] = {add ? add[i] : T(0), T(0)};     // even and odd terms of the sum
+        for (int k0 = 0; k0 < dk; k0 += KU) {
+            T av[KU];
+#pragma unroll
+            for (int kk = 0; kk < KU; ++kk) av[kk] = TRANS ? A[(k0 + kk) * LD + i] : A[i * LD + k0 + kk];
+#pragma unroll
+            for (int kk = 0; kk < KU; ++kk) acc[kk & 1] += av[kk] * x[k0 + kk];
         }
-        y[i] = acc0 + acc1;
+        y[i] = acc[0] + acc[1];
     }
 }
 
@@ -336,6 +344,8 @@ struct WcArgs {
     T R;
     const T *Fs, *Qs, *ys;
     T *fms, *fPs, *sms, *sPs;
+    T* Es;                  // (N, d, d) smoother gains, wc_apply1 -> wc_smooth1: sPs itself, or workspace between the
+                            // phases of a segment (the smoothed arrays only arrive with the last phase)
     double* ll;
     // workspace (compact records)
     T* agg1;                // (nchunk, nfilt)
@@ -374,55 +384,15 @@ struct StepTiles {
                 q[ti][tj] = in ? T(0.5) * (Qg[i * d + j] + Qg[j * d + i]) : T(0);
             }
     }
-    __device__ __forceinline__ void park(T* F, T* Q) const {
+    __device__ __forceinline__ void park_f(T* F) const {      // F alone: Q is only ever added tile by tile
         const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
         if (!lactive<DP>()) return;
 #pragma unroll
         for (int ti = 0; ti < TS; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < TS; ++tj) {
-                F[(r0 + ti) * Geo<DP>::LD + c0 + tj] = f[ti][tj];
-                Q[(r0 + ti) * Geo<DP>::LD + c0 + tj] = q[ti][tj];
-            }
+            for (int tj = 0; tj < TS; ++tj) F[(r0 + ti) * Geo<DP>::LD + c0 + tj] = f[ti][tj];
     }
 };
-
-// acc <- acc (x) raw step (F, Q, y): predict the conditional, scalar-innovation update (filt_extend)
-template <typename T, int DP>
-__device__ __forceinline__ void extend(int dk, T* acc, const T* F, const T* Q, T y, const T* h, T R, T* t1, T* t2,
-                                       T* v1, T* v2, T* v3) {
-    constexpr int LD = Geo<DP>::LD, MSZ = Geo<DP>::MSZ;
-    Filt<T, DP> a(acc);
-    mm<T, DP, 0>(dk, F, a.A, t1);               // A' = F A
-    mv<T, DP, false>(dk, F, a.b, v1);           // b' = F b
-    mm<T, DP, 0>(dk, F, a.C, t2);               // F C
-    sync();
-    slot_copy(MSZ, t1, a.A);
-    mm<T, DP, 1>(dk, t2, F, a.C, Q);            // C' = F C F^T + Q   (a.C is no longer an input)
-    if (lane_id() < DP) a.b[lane_id()] = v1[lane_id()];
-    sync();
-    symmetrise<T, DP>(a.C);
-    sync();
-    if (y != y) return;
-    mv<T, DP, false>(dk, a.C, h, v2);           // u = C' h
-    mv<T, DP, true>(dk, a.A, h, v3);            // v = (h A')^T
-    sync();
-    const T S = dot<T, DP>(h, v2) + R;
-    const T hb = dot<T, DP>(h, a.b);
-    const T inv = T(1) / S;
-    const T res = y - hb;
-    for_tile<DP>([&](int i, int j) {
-        const T ui = v2[i], uj = v2[j], vi = v3[i], vj = v3[j];
-        a.A[i * LD + j] -= ui * inv * vj;
-        a.C[i * LD + j] -= ui * uj * inv;
-        a.J[i * LD + j] += vi * vj * inv;
-    });
-    if (lane_id() < DP) {
-        a.b[lane_id()] += v2[lane_id()] * inv * res;
-        a.eta[lane_id()] += v3[lane_id()] * res * inv;
-    }
-    sync();
-}
 
 // first element of the series: update of the prior without a predict (filt_first); P0 is an LDS matrix
 template <typename T, int DP>
@@ -477,9 +447,9 @@ __device__ __forceinline__ void combine(int d, int dk, const T* r1, const T* r2,
         for (int ti = 0; ti < TS; ++ti)
 #pragma unroll
             for (int tj = 0; tj < TS; ++tj) { accA[ti][tj] = T(0); accX[ti][tj] = T(0); }
-        for (int k0 = 0; act && k0 < dk; k0 += 4) {
+        for (int k0 = 0; act && k0 < dk; k0 += Geo<DP>::KU) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < Geo<DP>::KU; ++kk) {
                 const int k = k0 + kk;
                 T a2[TS], g[TS], nm[TS];
 #pragma unroll
@@ -522,9 +492,9 @@ __device__ __forceinline__ void combine(int d, int dk, const T* r1, const T* r2,
         for (int ti = 0; ti < TS; ++ti)
 #pragma unroll
             for (int tj = 0; tj < TS; ++tj) acc[ti][tj] = act ? e1.J[(r0 + ti) * LD + c0 + tj] : T(0);
-        for (int k0 = 0; act && k0 < dk; k0 += 4) {
+        for (int k0 = 0; act && k0 < dk; k0 += Geo<DP>::KU) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < Geo<DP>::KU; ++kk) {
                 const int k = k0 + kk;
                 T g[TS], m[TS];
 #pragma unroll
@@ -632,48 +602,12 @@ struct Pool {
     __device__ T* take(int n) { T* p = base + off; off += (n + 1) & ~1; return p; }
 };
 
-// ====================================================================================================
-// level 1: reduce
-// ====================================================================================================
-template <typename T, int DP>
-__global__ __launch_bounds__(64) void wc_reduce1(const WcArgs<T> a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MSZ = Geo<DP>::MSZ;
-    const int d = a.d, dd = d * d, dk = (d + 3) & ~3;
-    Pool<T> pool(reinterpret_cast<T*>(smem));
-    T* acc = pool.take(Geo<DP>::NFL);
-    T* F = pool.take(MSZ); T* Q = pool.take(MSZ); T* t1 = pool.take(MSZ); T* t2 = pool.take(MSZ);
-    T* h = pool.take(DP); T* v1 = pool.take(DP); T* v2 = pool.take(DP); T* v3 = pool.take(DP);
-    const long c = blockIdx.x;
-    const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
-    vec_g2l<T, DP>(d, a.H, h);
-    filt_set_identity<T, DP>(d, acc);
-    StepTiles<T, DP> st;
-    st.fetch(d, a.Fs + k0 * dd, a.Qs + k0 * dd);
-    T yn = a.ys[k0];
-    sync();
-    for (long k = k0; k < k1; ++k) {
-        st.park(F, Q);
-        const T y = yn;
-        if (k + 1 < k1) { st.fetch(d, a.Fs + (k + 1) * dd, a.Qs + (k + 1) * dd); yn = a.ys[k + 1]; }
-        sync();
-        if (k == 0 && a.seg_first) {
-            mat_g2l<T, DP>(d, a.P0, t1);
-            sync();
-            first_element<T, DP>(dk, acc, t1, y, h, a.R, v2);
-        } else {
-            extend<T, DP>(dk, acc, F, Q, y, h, a.R, t1, t2, v1, v2, v3);
-        }
-    }
-    filt_l2g<T, DP>(d, acc, a.agg1 + c * nfilt(d));
-}
-
 // level 2: serial combine of a group's chunk totals; stores every chunk's exclusive in-group prefix
 template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_reduce2(const WcArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ, NFL = Geo<DP>::NFL;
-    const int d = a.d, nf = nfilt(d), dk = (d + 3) & ~3;
+    const int d = a.d, nf = nfilt(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* acc = pool.take(NFL); T* cur = pool.take(NFL); T* out = pool.take(NFL);
     T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRC); T* X = pool.take(MSZ); T* vt = pool.take(DP);
@@ -701,7 +635,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_carry3(const WcArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ;
-    const int d = a.d, dd = d * d, nf = nfilt(d), dk = (d + 3) & ~3;
+    const int d = a.d, dd = d * d, nf = nfilt(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* m = pool.take(DP); T* P = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NFL);
     T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRA); T* X = pool.take(MSZ);
@@ -731,7 +665,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_ks_filter(int d, long n, long stride, const T* in, T* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ, NFL = Geo<DP>::NFL;
-    const int nf = nfilt(d), dk = (d + 3) & ~3;
+    const int nf = nfilt(d), dk = Geo<DP>::dk(d);
     const long i = blockIdx.x;
     if (i >= n) return;
     if (i < stride) {
@@ -755,7 +689,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_fin_filter(const WcArgs<T> a, const T* incl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ;
-    const int d = a.d, dd = d * d, nf = nfilt(d), dk = (d + 3) & ~3;
+    const int d = a.d, dd = d * d, nf = nfilt(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* m = pool.take(DP); T* P = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NFL);
     T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRA); T* X = pool.take(MSZ);
@@ -787,7 +721,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_ks_smoother(int d, long n, long stride, const T* in, T* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NSL = Geo<DP>::NSL;
-    const int ns = nsmth(d), dk = (d + 3) & ~3;
+    const int ns = nsmth(d), dk = Geo<DP>::dk(d);
     const long i = blockIdx.x;
     if (i >= n) return;
     if (i + stride >= n) {
@@ -824,7 +758,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_fin_smoother_cb(const WcArgs<T> a, const T* sfx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ;
-    const int d = a.d, dd = d * d, ns = nsmth(d), dk = (d + 3) & ~3;
+    const int d = a.d, dd = d * d, ns = nsmth(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* sm = pool.take(DP); T* sP = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NSL);
     T* X = pool.take(MSZ); T* Y = pool.take(MSZ); T* v = pool.take(DP);
@@ -850,7 +784,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_seg_carry_f(int d, const T* P0, const T* recs, int rank, T* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ;
-    const int nf = nfilt(d), dk = (d + 3) & ~3;
+    const int nf = nfilt(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* m = pool.take(DP); T* P = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NFL);
     T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRA); T* X = pool.take(MSZ);
@@ -875,7 +809,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_seg_carry_s(int d, const T* recs, int rank, int nranks, T* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ;
-    const int ns = nsmth(d), dk = (d + 3) & ~3;
+    const int ns = nsmth(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* sm = pool.take(DP); T* sP = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NSL);
     T* X = pool.take(MSZ); T* Y = pool.take(MSZ); T* v = pool.take(DP);
@@ -911,26 +845,324 @@ __device__ __forceinline__ void gain(int d, const T* Pp, const T* FP, T* E, T* M
 }
 
 // ====================================================================================================
-// level 1: apply -- Kalman pass over the chunk, log-likelihood, smoothing aggregate
+// level 1 kernels keep a lane's tile of a matrix in registers wherever the next operation is tile-local
+// (Q, the predicted and the filtered covariance, the smoothing element's L, the elimination of the smoother gain):
+// LDS holds only what another lane reads -- the operands of a product and the transposed reads of a symmetrisation.
+// ====================================================================================================
+template <typename T, int DP>
+struct Tile {
+    static constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD;
+    T v[TS][TS];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = T(0);
+    }
+    __device__ __forceinline__ void ld(const T* M) {            // this lane's tile of an LDS matrix
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) { zero(); return; }
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = M[(r0 + ti) * LD + c0 + tj];
+    }
+    __device__ __forceinline__ void ld_t(const T* M) {          // ... of its transpose
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) { zero(); return; }
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = M[(c0 + tj) * LD + r0 + ti];
+    }
+    __device__ __forceinline__ void st(T* M) const {
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) return;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) M[(r0 + ti) * LD + c0 + tj] = v[ti][tj];
+    }
+    __device__ __forceinline__ void st_t(T* M) const {          // M = (this matrix)^T
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) return;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) M[(c0 + tj) * LD + r0 + ti] = v[ti][tj];
+    }
+    // compact global (d x d)
+    __device__ __forceinline__ void ld_g(int d, const T* g) {
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        const bool act = lactive<DP>();
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) {
+                const int i = r0 + ti, j = c0 + tj;
+                v[ti][tj] = (act && i < d && j < d) ? g[i * d + j] : T(0);
+            }
+    }
+    __device__ __forceinline__ void st_g(int d, T* g) const {
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) return;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) {
+                const int i = r0 + ti, j = c0 + tj;
+                if (i < d && j < d) g[i * d + j] = v[ti][tj];
+            }
+    }
+    __device__ __forceinline__ void st_g_t(int d, T* g) const {     // g = (this matrix)^T
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) return;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) {
+                const int i = r0 + ti, j = c0 + tj;
+                if (i < d && j < d) g[j * d + i] = v[ti][tj];
+            }
+    }
+    // this <- (this + t) / 2: with t the transposed read of the stored tile, the symmetric part
+    __device__ __forceinline__ void average(const Tile& t) {
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = T(0.5) * (v[ti][tj] + t.v[ti][tj]);
+    }
+};
+
+// t += op(A) op(B), the modes of mm
+template <typename T, int DP, int MODE>
+__device__ __forceinline__ void mm_acc(int dk, const T* __restrict__ A, const T* __restrict__ B, Tile<T, DP>& t) {
+    constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD, KU = Geo<DP>::KU;
+    const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+    if (!lactive<DP>()) return;
+    auto body = [&](int k0) {
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) {
+            const int k = k0 + kk;
+            T av[TS], bv[TS];
+#pragma unroll
+            for (int ti = 0; ti < TS; ++ti) av[ti] = (MODE == 2) ? A[k * LD + r0 + ti] : A[(r0 + ti) * LD + k];
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) bv[tj] = (MODE == 1) ? B[(c0 + tj) * LD + k] : B[k * LD + c0 + tj];
+#pragma unroll
+            for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TS; ++tj) t.v[ti][tj] += av[ti] * bv[tj];
+        }
+    };
+    if constexpr (Geo<DP>::FIXK) {
+#pragma unroll
+        for (int k0 = 0; k0 < DP; k0 += KU) body(k0);
+    } else {
+        for (int k0 = 0; k0 < dk; k0 += KU) body(k0);
+    }
+}
+
+// Gauss-Jordan without pivoting on register tiles: tb <- tm^-1 tb for a symmetric positive definite tm (destroyed).
+// Per elimination step only column c and row c travel through LDS (gj: 3 DP values), not the matrices.
+template <typename T, int DP>
+__device__ __forceinline__ void solve_tiles(int d, Tile<T, DP>& tm, Tile<T, DP>& tb, T* gj) {
+    constexpr int TS = Geo<DP>::TS, GR = Geo<DP>::GR;
+    const int lr = lrow<DP>(), lc = lcol<DP>(), r0 = lr * TS, c0 = lc * TS;
+    const bool act = lactive<DP>();
+    for (int cb = 0; cb < GR; ++cb) {
+#pragma unroll
+        for (int cs = 0; cs < TS; ++cs) {
+            const int c = cb * TS + cs;
+            if (c < d) {
+                if (act && lc == cb) {
+#pragma unroll
+                    for (int ti = 0; ti < TS; ++ti) gj[r0 + ti] = tm.v[ti][cs];
+                }
+                if (act && lr == cb) {
+#pragma unroll
+                    for (int tj = 0; tj < TS; ++tj) { gj[DP + c0 + tj] = tm.v[cs][tj]; gj[2 * DP + c0 + tj] = tb.v[cs][tj]; }
+                }
+                sync();
+                if (act) {
+                    const T inv = T(1) / gj[DP + c];
+                    T f[TS], pm[TS], pb[TS];
+#pragma unroll
+                    for (int ti = 0; ti < TS; ++ti) f[ti] = gj[r0 + ti];
+#pragma unroll
+                    for (int tj = 0; tj < TS; ++tj) { pm[tj] = gj[DP + c0 + tj] * inv; pb[tj] = gj[2 * DP + c0 + tj] * inv; }
+#pragma unroll
+                    for (int ti = 0; ti < TS; ++ti) {
+                        const bool piv = (ti == cs) && (lr == cb);
+#pragma unroll
+                        for (int tj = 0; tj < TS; ++tj) {
+                            tm.v[ti][tj] = piv ? pm[tj] : tm.v[ti][tj] - f[ti] * pm[tj];
+                            tb.v[ti][tj] = piv ? pb[tj] : tb.v[ti][tj] - f[ti] * pb[tj];
+                        }
+                    }
+                }
+                sync();
+            }
+        }
+    }
+}
+
+// acc <- acc (x) e in time order (acc earlier), in place: scombine with the results held in registers until every
+// operand has been read.  scratch: X (MSZ), u (DP)
+template <typename T, int DP>
+__device__ __forceinline__ void scombine_tiles(int dk, T* racc, const T* re, T* X, T* u) {
+    Smth<T, DP> s(racc), e(const_cast<T*>(re));
+    Tile<T, DP> oE, xx, oL;
+    oE.zero();
+    xx.zero();
+    mm_acc<T, DP, 0>(dk, s.E, e.E, oE);
+    mm_acc<T, DP, 0>(dk, s.E, e.L, xx);
+    mv<T, DP, false>(dk, s.E, e.g, u, s.g);
+    xx.st(X);
+    sync();
+    oL.ld(s.L);
+    mm_acc<T, DP, 1>(dk, X, s.E, oL);
+    sync();
+    oE.st(s.E);
+    oL.st(s.L);
+    if (lane_id() < DP) s.g[lane_id()] = u[lane_id()];
+    sync();
+    Tile<T, DP> t;
+    t.ld_t(s.L);
+    oL.average(t);
+    sync();
+    oL.st(s.L);
+    sync();
+}
+
+// acc <- acc (x) raw step (F, Q, y): predict the conditional, scalar-innovation update (filt_extend); F A, F C F^T + Q
+// and the rank-one updates on register tiles.
+// scratch: t2 (MSZ), v1..v3 (DP)
+template <typename T, int DP>
+__device__ __forceinline__ void extend_tiles(int dk, T* acc, const T* F, const Tile<T, DP>& qt, T y, const T* h, T R,
+                                             T* t2, T* v1, T* v2, T* v3) {
+    constexpr int TS = Geo<DP>::TS;
+    Filt<T, DP> a(acc);
+    const int lane = lane_id();
+    const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+    Tile<T, DP> ta, tc;
+    ta.zero();
+    tc.zero();
+    mm_acc<T, DP, 0>(dk, F, a.A, ta);           // A' = F A
+    mv<T, DP, false>(dk, F, a.b, v1);           // b' = F b
+    mm_acc<T, DP, 0>(dk, F, a.C, tc);           // F C
+    tc.st(t2);
+    sync();
+    ta.st(a.A);
+    tc = qt;
+    mm_acc<T, DP, 1>(dk, t2, F, tc);            // C' = F C F^T + Q
+    tc.st(a.C);
+    if (lane < DP) a.b[lane] = v1[lane];
+    sync();
+    {
+        Tile<T, DP> t;
+        t.ld_t(a.C);
+        tc.average(t);
+    }
+    sync();
+    tc.st(a.C);
+    sync();
+    if (y != y) return;
+    mv<T, DP, false>(dk, a.C, h, v2);           // u = C' h
+    mv<T, DP, true>(dk, a.A, h, v3);            // v = (h A')^T
+    sync();
+    const T S = dot<T, DP>(h, v2) + R;
+    const T hb = dot<T, DP>(h, a.b);
+    const T inv = T(1) / S;
+    const T res = y - hb;
+    if (lactive<DP>()) {
+        Tile<T, DP> tj;
+        tj.ld(a.J);
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj_ = 0; tj_ < TS; ++tj_) {
+                const T ui = v2[r0 + ti], uj = v2[c0 + tj_], vi = v3[r0 + ti], vj = v3[c0 + tj_];
+                ta.v[ti][tj_] -= ui * inv * vj;
+                tc.v[ti][tj_] -= ui * uj * inv;
+                tj.v[ti][tj_] += vi * vj * inv;
+            }
+        ta.st(a.A);
+        tc.st(a.C);
+        tj.st(a.J);
+    }
+    if (lane < DP) {
+        a.b[lane] += v2[lane] * inv * res;
+        a.eta[lane] += v3[lane] * res * inv;
+    }
+    sync();
+}
+
+// ====================================================================================================
+// level 1: reduce
+// ====================================================================================================
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_reduce1(const WcArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MSZ = Geo<DP>::MSZ, TS = Geo<DP>::TS;
+    const int d = a.d, dd = d * d, dk = Geo<DP>::dk(d);
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* acc = pool.take(Geo<DP>::NFL);
+    T* F = pool.take(MSZ); T* t2 = pool.take(MSZ);
+    T* h = pool.take(DP); T* v1 = pool.take(DP); T* v2 = pool.take(DP); T* v3 = pool.take(DP);
+    const long c = blockIdx.x;
+    const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
+    vec_g2l<T, DP>(d, a.H, h);
+    filt_set_identity<T, DP>(d, acc);
+    StepTiles<T, DP> st;
+    st.fetch(d, a.Fs + k0 * dd, a.Qs + k0 * dd);
+    T yn = a.ys[k0];
+    sync();
+    for (long k = k0; k < k1; ++k) {
+        st.park_f(F);
+        Tile<T, DP> qt;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) qt.v[ti][tj] = st.q[ti][tj];
+        const T y = yn;
+        if (k + 1 < k1) { st.fetch(d, a.Fs + (k + 1) * dd, a.Qs + (k + 1) * dd); yn = a.ys[k + 1]; }
+        sync();
+        if (k == 0 && a.seg_first) {
+            mat_g2l<T, DP>(d, a.P0, t2);
+            sync();
+            first_element<T, DP>(dk, acc, t2, y, h, a.R, v2);
+        } else {
+            extend_tiles<T, DP>(dk, acc, F, qt, y, h, a.R, t2, v1, v2, v3);
+        }
+    }
+    filt_l2g<T, DP>(d, acc, a.agg1 + c * nfilt(d));
+}
+
+// ====================================================================================================
+// level 1: apply -- Kalman pass over the chunk, log-likelihood, smoothing aggregate; the smoother gain of every step
+// is left in a.Es for wc_smooth1 (the smoothed covariances' own buffer, overwritten there step by step)
 // ====================================================================================================
 template <typename T, int DP, bool SMOOTH>
 __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MSZ = Geo<DP>::MSZ, LD = Geo<DP>::LD, NSL = Geo<DP>::NSL;
-    const int d = a.d, dd = d * d, nf = nfilt(d), ns = nsmth(d), dk = (d + 3) & ~3;
+    constexpr int MSZ = Geo<DP>::MSZ, NSL = Geo<DP>::NSL, TS = Geo<DP>::TS;
+    const int d = a.d, dd = d * d, nf = nfilt(d), ns = nsmth(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* m = pool.take(DP); T* P = pool.take(MSZ);
-    T* F = pool.take(MSZ); T* Q = pool.take(MSZ);
-    T* FP = pool.take(MSZ); T* Pp = pool.take(MSZ); T* X = pool.take(MSZ);
-    T* Ee = pool.take(NSL); T* sacc = pool.take(NSL); T* sout = pool.take(NSL);      // contiguous: `rec` aliases them
-    T* h = pool.take(DP); T* mp = pool.take(DP); T* u = pool.take(DP); T* mprev = pool.take(DP);
-    T* Pprev = pool.take(MSZ);
-    T* rhsA = pool.take(DP * Geo<DP>::NRA);
-    T* rec = Ee;                                        // the chunk's in-group prefix (NFL <= 3 NSL): prologue only
-    static_assert(Geo<DP>::NFL <= 3 * ((Geo<DP>::NSL + 1) & ~1), "prefix record must fit the smoothing scratch");
+    T* F = pool.take(MSZ); T* FP = pool.take(MSZ);      // contiguous: the prologue's right-hand side lies over them
+    T* Pp = pool.take(MSZ); T* X = pool.take(MSZ);
+    T* Ee = pool.take(NSL); T* sacc = pool.take(NSL);   // contiguous: the prologue's prefix record lies over them
+    T* h = pool.take(DP); T* mp = pool.take(DP); T* u = pool.take(DP); T* gj = pool.take(3 * DP);
+    T* rhsA = F;
+    T* rec = Ee;
+    static_assert(DP * Geo<DP>::NRA <= 2 * MSZ, "the prologue's right-hand side must fit two matrix slots");
+    static_assert(Geo<DP>::NFL <= 2 * ((NSL + 1) & ~1), "the prefix record must fit the smoothing scratch");
     const long c = blockIdx.x;
     const int g = (int)(c / a.kgroup);
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
+    const int lane = lane_id();
+    const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
     vec_g2l<T, DP>(d, a.H, h);
     {   // state entering the chunk: group carry pushed through the in-group prefix
         const T* cg = a.carry2 + (long)g * (d + dd);
@@ -938,7 +1170,7 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
         mat_g2l<T, DP>(d, cg + d, P);
         filt_g2l<T, DP>(d, a.lpre1 + c * nf, rec);
         sync();
-        apply<T, DP>(d, dk, m, P, rec, Pp, rhsA, X);    // Pp, X are free until the loop starts
+        apply<T, DP>(d, dk, m, P, rec, Pp, rhsA, X);    // Pp, X, F, FP are free until the loop starts
     }
     if (SMOOTH) smth_set_identity<T, DP>(d, sacc);
     StepTiles<T, DP> st;
@@ -946,38 +1178,71 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
     sync();
     double quad = 0.0, mant = 1.0;
     long long expo = 0, count = 0;
+    Tile<T, DP> pt;                                      // the filtered covariance (also in LDS: P)
     for (long k = k0; k <= k1; ++k) {
         const bool halo = (k == k1);
         if (halo && (!SMOOTH || (k == a.N && a.seg_last))) break;
-        st.park(F, Q);
+        st.park_f(F);
+        Tile<T, DP> pp;                                  // Q now, the predicted covariance below
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) pp.v[ti][tj] = st.q[ti][tj];
         if (k + 1 < a.N && (k + 1 < k1 || SMOOTH)) st.fetch(d, a.Fs + (k + 1) * dd, a.Qs + (k + 1) * dd);
         else if (SMOOTH && k + 1 == a.N && !a.seg_last) st.fetch(d, a.halo_F, a.halo_Q);      // the next segment's first step
+        Tile<T, DP> pprev;
+        T mprev = T(0);
         if (SMOOTH) {
-            if (lane_id() < DP) mprev[lane_id()] = m[lane_id()];
-            slot_copy(MSZ, P, Pprev);
+            pprev.ld(P);
+            if (lane < DP) mprev = m[lane];
         }
         sync();
         // predict
+        Tile<T, DP> fp;
+        fp.zero();
         mv<T, DP, false>(dk, F, m, mp);
-        mm<T, DP, 0>(dk, F, P, FP);
+        mm_acc<T, DP, 0>(dk, F, P, fp);
+        fp.st(FP);
         sync();
-        mm<T, DP, 1>(dk, FP, F, Pp, Q);
+        mm_acc<T, DP, 1>(dk, FP, F, pp);
+        pp.st(Pp);
         sync();
-        symmetrise<T, DP>(Pp);
+        {
+            Tile<T, DP> t;
+            t.ld_t(Pp);
+            pp.average(t);
+        }
+        sync();
+        pp.st(Pp);
         sync();
         if (SMOOTH && k > k0) {
             // element of step k-1: E = (Pp^-1 F P)^T, g = m - E mp, L = P - sym(E F P)
             Smth<T, DP> e(Ee);
-            gain<T, DP>(d, Pp, FP, e.E, X, rhsA);
+            {
+                Tile<T, DP> tm = pp;
+                solve_tiles<T, DP>(d, tm, fp, gj);       // fp <- Pp^-1 F P = E^T
+            }
+            fp.st_t(e.E);
+            fp.st_g_t(d, a.Es + (k - 1) * dd);
+            sync();
+            Tile<T, DP> x;
+            x.zero();
             mv<T, DP, false>(dk, e.E, mp, u);
-            mm<T, DP, 0>(dk, e.E, FP, X);
+            mm_acc<T, DP, 0>(dk, e.E, FP, x);
+            x.st(X);
             sync();
-            if (lane_id() < DP) e.g[lane_id()] = mprev[lane_id()] - u[lane_id()];
-            for_tile<DP>([&](int i, int j) { e.L[i * LD + j] = Pprev[i * LD + j] - T(0.5) * (X[i * LD + j] + X[j * LD + i]); });
+            if (lane < DP) e.g[lane] = mprev - u[lane];
+            {
+                Tile<T, DP> xt;
+                xt.ld_t(X);
+#pragma unroll
+                for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TS; ++tj) pprev.v[ti][tj] -= T(0.5) * (x.v[ti][tj] + xt.v[ti][tj]);
+                pprev.st(e.L);
+            }
             sync();
-            scombine<T, DP>(dk, sacc, Ee, sout, X);
-            slot_copy(NSL, sout, sacc);
-            sync();
+            scombine_tiles<T, DP>(dk, sacc, Ee, X, u);
         }
         if (halo) break;
         const T y = a.ys[k];
@@ -996,42 +1261,55 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
             expo += ex;
             count += 1;
         }
+        const bool act = lactive<DP>();
         if (first) {
             // update straight from the prior (m, P still hold m0 = 0, P0)
             mv<T, DP, false>(dk, P, h, u);
             sync();
             const T S0 = dot<T, DP>(h, u) + a.R;
             const T mu0 = dot<T, DP>(h, m);
+            pt.ld(P);
             if (obs) {
                 const T inv = T(1) / S0;
-                for_tile<DP>([&](int i, int j) { P[i * LD + j] -= u[i] * u[j] * inv; });
-                if (lane_id() < DP) m[lane_id()] += u[lane_id()] * (y - mu0) * inv;
+                if (act) {
+#pragma unroll
+                    for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < TS; ++tj) pt.v[ti][tj] -= u[r0 + ti] * u[c0 + tj] * inv;
+                }
+                pt.st(P);
+                if (lane < DP) m[lane] += u[lane] * (y - mu0) * inv;
             }
         } else if (obs) {
             const T inv = T(1) / S;
-            for_tile<DP>([&](int i, int j) { P[i * LD + j] = Pp[i * LD + j] - u[i] * u[j] * inv; });
-            if (lane_id() < DP) m[lane_id()] = mp[lane_id()] + u[lane_id()] * (y - mu) * inv;
+            if (act) {
+#pragma unroll
+                for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TS; ++tj) pt.v[ti][tj] = pp.v[ti][tj] - u[r0 + ti] * u[c0 + tj] * inv;
+            }
+            pt.st(P);
+            if (lane < DP) m[lane] = mp[lane] + u[lane] * (y - mu) * inv;
         } else {
-            slot_copy(MSZ, Pp, P);
-            if (lane_id() < DP) m[lane_id()] = mp[lane_id()];
+            pt = pp;
+            pt.st(P);
+            if (lane < DP) m[lane] = mp[lane];
         }
         sync();
         vec_l2g<T, DP>(d, m, a.fms + k * d);
-        mat_l2g<T, DP>(d, P, a.fPs + k * dd);
+        pt.st_g(d, a.fPs + k * dd);
     }
     if (SMOOTH && k1 == a.N && a.seg_last) {
         // last element of the series: (0, m_N, P_N)
         Smth<T, DP> e(Ee);
         slot_zero(MSZ, e.E);
         slot_copy(MSZ, P, e.L);
-        if (lane_id() < DP) e.g[lane_id()] = m[lane_id()];
+        if (lane < DP) e.g[lane] = m[lane];
         sync();
-        scombine<T, DP>(dk, sacc, Ee, sout, X);
-        slot_copy(NSL, sout, sacc);
-        sync();
+        scombine_tiles<T, DP>(dk, sacc, Ee, X, u);
     }
     if (SMOOTH) smth_l2g<T, DP>(d, sacc, a.sagg1 + c * ns);
-    if (lane_id() == 0) {
+    if (lane == 0) {
         const double logdet = log(mant) + double(expo) * 0.6931471805599453;
         a.llpart[c] = -0.5 * (double(count) * 1.8378770664093453 + logdet + quad);
     }
@@ -1042,7 +1320,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_sreduce2(const WcArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NSL = Geo<DP>::NSL;
-    const int d = a.d, ns = nsmth(d), dk = (d + 3) & ~3;
+    const int d = a.d, ns = nsmth(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* acc = pool.take(NSL); T* cur = pool.take(NSL); T* out = pool.take(NSL); T* X = pool.take(Geo<DP>::MSZ);
     const int g = blockIdx.x;
@@ -1069,7 +1347,7 @@ template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_scarry3(const WcArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ;
-    const int d = a.d, dd = d * d, ns = nsmth(d), dk = (d + 3) & ~3;
+    const int d = a.d, dd = d * d, ns = nsmth(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* sm = pool.take(DP); T* sP = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NSL);
     T* X = pool.take(MSZ); T* Y = pool.take(MSZ); T* v = pool.take(DP);
@@ -1092,21 +1370,23 @@ __global__ __launch_bounds__(64) void wc_scarry3(const WcArgs<T> a) {
     }
 }
 
-// level 1 (smoother): RTS pass backwards over the chunk
+// level 1 (smoother): RTS pass backwards over the chunk with the gains wc_apply1 left in a.Es
 template <typename T, int DP>
 __global__ __launch_bounds__(64) void wc_smooth1(const WcArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MSZ = Geo<DP>::MSZ, LD = Geo<DP>::LD;
-    const int d = a.d, dd = d * d, ns = nsmth(d), dk = (d + 3) & ~3;
+    constexpr int MSZ = Geo<DP>::MSZ, TS = Geo<DP>::TS;
+    const int d = a.d, dd = d * d, ns = nsmth(d), dk = Geo<DP>::dk(d);
     Pool<T> pool(reinterpret_cast<T*>(smem));
     T* sm = pool.take(DP); T* sP = pool.take(MSZ);
-    T* F = pool.take(MSZ); T* Q = pool.take(MSZ); T* P = pool.take(MSZ); T* m = pool.take(DP);
-    T* FP = pool.take(MSZ); T* Pp = pool.take(MSZ); T* E = pool.take(MSZ); T* X = pool.take(MSZ); T* Y = pool.take(MSZ);
-    T* mp = pool.take(DP); T* v = pool.take(DP); T* rec = pool.take(Geo<DP>::NSL);
-    T* rhsA = pool.take(DP * Geo<DP>::NRA);
+    T* F = pool.take(MSZ); T* P = pool.take(MSZ); T* FP = pool.take(MSZ);   // contiguous: the prologue's suffix record
+    T* E = pool.take(MSZ); T* X = pool.take(MSZ); T* Y = pool.take(MSZ);
+    T* m = pool.take(DP); T* mp = pool.take(DP); T* v = pool.take(DP);
+    T* rec = F;
+    static_assert(Geo<DP>::NSL <= 3 * MSZ, "the suffix record must fit three matrix slots");
     const long c = blockIdx.x;
     const int g = (int)(c / a.kgroup);
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
+    const int lane = lane_id();
     {
         const T* cg = a.scarry2 + (long)g * (d + dd);
         vec_g2l<T, DP>(d, cg, sm);
@@ -1120,37 +1400,65 @@ __global__ __launch_bounds__(64) void wc_smooth1(const WcArgs<T> a) {
     else if (!a.seg_last) st.fetch(d, a.halo_F, a.halo_Q);
     for (long k = k1 - 1; k >= k0; --k) {
         const bool terminal = (k == a.N - 1 && a.seg_last);
-        mat_g2l<T, DP>(d, a.fPs + k * dd, P);
+        Tile<T, DP> pt, sp;
+        pt.ld_g(d, a.fPs + k * dd);
+        pt.st(P);
         vec_g2l<T, DP>(d, a.fms + k * d, m);
-        if (!terminal) st.park(F, Q);                   // (F, Q) of step k+1
+        sp.ld(sP);                                       // the step after this one
+        if (!terminal) {
+            mat_g2l<T, DP>(d, a.Es + k * dd, E);
+            st.park_f(F);                                // (F, Q) of step k+1
+#pragma unroll
+            for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TS; ++tj) sp.v[ti][tj] -= st.q[ti][tj];
+        }
         if (k > k0) st.fetch(d, a.Fs + k * dd, a.Qs + k * dd);
         sync();
         if (terminal) {
-            if (lane_id() < DP) sm[lane_id()] = m[lane_id()];
-            slot_copy(MSZ, P, sP);
+            if (lane < DP) sm[lane] = m[lane];
+            sp = pt;
+            sp.st(sP);
             sync();
         } else {
+            Tile<T, DP> fp;
+            fp.zero();
             mv<T, DP, false>(dk, F, m, mp);
-            mm<T, DP, 0>(dk, F, P, FP);
+            mm_acc<T, DP, 0>(dk, F, P, fp);
+            fp.st(FP);
             sync();
-            mm<T, DP, 1>(dk, FP, F, Pp, Q);
+            // X = sP' - (F P F^T + Q): the predicted covariance is not symmetrised on its own here -- the smoothed
+            // one is, and sym(E X E^T) = E sym(X) E^T
+            fp.zero();
+            mm_acc<T, DP, 1>(dk, FP, F, fp);
+#pragma unroll
+            for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TS; ++tj) sp.v[ti][tj] -= fp.v[ti][tj];
+            sp.st(X);
+            if (lane < DP) v[lane] = sm[lane] - mp[lane];
             sync();
-            symmetrise<T, DP>(Pp);
-            sync();
-            gain<T, DP>(d, Pp, FP, E, X, rhsA);
-            if (lane_id() < DP) v[lane_id()] = sm[lane_id()] - mp[lane_id()];
-            for_tile<DP>([&](int i, int j) { X[i * LD + j] = sP[i * LD + j] - Pp[i * LD + j]; });
-            sync();
+            Tile<T, DP> y;
+            y.zero();
             mv<T, DP, false>(dk, E, v, sm, m);          // sm = m + E (sm' - mp)
-            mm<T, DP, 0>(dk, E, X, Y);
+            mm_acc<T, DP, 0>(dk, E, X, y);
+            y.st(Y);
             sync();
-            mm<T, DP, 1>(dk, Y, E, sP, P);              // sP = P + E (sP' - Pp) E^T
+            sp = pt;
+            mm_acc<T, DP, 1>(dk, Y, E, sp);             // sP = P + E (sP' - Pp) E^T
+            sp.st(sP);
             sync();
-            symmetrise<T, DP>(sP);
+            {
+                Tile<T, DP> t;
+                t.ld_t(sP);
+                sp.average(t);
+            }
+            sync();
+            sp.st(sP);
             sync();
         }
         vec_l2g<T, DP>(d, sm, a.sms + k * d);
-        mat_l2g<T, DP>(d, sP, a.sPs + k * dd);
+        sp.st_g(d, a.sPs + k * dd);
     }
 }
 
@@ -1162,7 +1470,7 @@ __global__ __launch_bounds__(64) void wc_discretise(long N, int d, int steps_per
                                                     const T* ts, T t_prev, T* Fs, T* Qs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MSZ = Geo<DP>::MSZ, LD = Geo<DP>::LD;
-    const int dd = d * d, dk = (d + 3) & ~3;
+    const int dd = d * d, dk = Geo<DP>::dk(d);
     Pool<double> pool(reinterpret_cast<double*>(smem));
     double* A = pool.take(MSZ); double* A2 = pool.take(MSZ); double* A4 = pool.take(MSZ); double* A6 = pool.take(MSZ);
     double* W = pool.take(MSZ); double* U = pool.take(MSZ); double* V = pool.take(MSZ); double* Pm = pool.take(MSZ);
@@ -1360,20 +1668,20 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
     using namespace wc;
     using GE = Geo<DP>;
     const size_t pad = 64;
-    const size_t l_reduce1 = GE::NFL + 4 * GE::MSZ + 4 * DP + pad;
+    const size_t l_reduce1 = GE::NFL + 2 * GE::MSZ + 4 * DP + pad;
     const size_t l_reduce2 = 3 * GE::NFL + 2 * GE::MSZ + (size_t)DP * GE::NRC + DP + pad;
     const size_t l_carry3 = DP + 3 * GE::MSZ + GE::NFL + (size_t)DP * GE::NRA + pad;
-    const size_t l_apply1 = 5 * DP + 7 * GE::MSZ + 3 * GE::NSL + (size_t)DP * GE::NRA + pad;
+    const size_t l_apply1 = 7 * DP + 5 * GE::MSZ + 2 * (GE::NSL + 1) + pad;
     const size_t l_sred2 = 3 * GE::NSL + GE::MSZ + pad;
     const size_t l_scarry3 = 2 * DP + 3 * GE::MSZ + GE::NSL + pad;
-    const size_t l_smooth1 = 4 * DP + 9 * GE::MSZ + GE::NSL + (size_t)DP * GE::NRA + pad;
+    const size_t l_smooth1 = 4 * DP + 7 * GE::MSZ + pad;
     auto bytes = [](size_t n) { return n * sizeof(T); };
     size_t need = 0;
     for (size_t v : {l_reduce1, l_reduce2, l_carry3, l_apply1, l_sred2, l_scarry3, l_smooth1}) need = need > v ? need : v;
     if (bytes(need) > 160 * 1024) return PGPS_E_UNSUPPORTED_DIM;
     // the dynamic-LDS ceilings are set once per context and instantiation (a dozen runtime calls per scan otherwise:
     // they show at the few-thousand-step series of the experiment drivers)
-    bool& attr_done = ctx->wc_attr_done[sizeof(T) == 8 ? 1 : 0][DP / 4];
+    bool& attr_done = ctx->wc_attr_done[sizeof(T) == 8 ? 1 : 0][DP / 2];
 #define WC_ATTR(K, L)                                                                                              \
     if (!attr_done)                                                                                                \
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -1566,12 +1874,14 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     const size_t o_cin = off;    if (seg) off = wc_align(off + (d + dd) * sizeof(T));
     const size_t o_cback = off;  if (seg) off = wc_align(off + (d + dd) * sizeof(T));
     const size_t o_halo = off;   if (seg) off = wc_align(off + 2 * dd * sizeof(T));
+    const size_t o_E = off;      if (seg) off = wc_align(off + (size_t)sa.N * dd * sizeof(T));
     int rc = ensure(ctx, ctx->ws, off);
     if (rc) return rc;
     char* base = (char*)ctx->ws.p;
     a.agg1 = (T*)(base + o_agg1); a.lpre1 = (T*)(base + o_lpre1); a.agg2 = (T*)(base + o_agg2);
     a.carry2 = (T*)(base + o_carry2); a.sagg1 = (T*)(base + o_sagg1); a.lsuf1 = (T*)(base + o_lsuf1);
     a.sagg2 = (T*)(base + o_sagg2); a.scarry2 = (T*)(base + o_sc2); a.llpart = (double*)(base + o_ll);
+    a.Es = seg ? (T*)(base + o_E) : a.sPs;
     a.ksA = (T*)(base + o_ksA); a.ksB = (T*)(base + o_ksB);
     WcSeg<T> sgv{};
     if (seg) {
@@ -1585,6 +1895,7 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     if (d <= 8) return launch_scan_wc_dp<T, 8>(ctx, a, mode, sg);
     if (d <= 12) return launch_scan_wc_dp<T, 12>(ctx, a, mode, sg);
     if (d <= 16) return launch_scan_wc_dp<T, 16>(ctx, a, mode, sg);
+    if (d <= 18) return launch_scan_wc_dp<T, 18>(ctx, a, mode, sg);
     if (d <= 24) return launch_scan_wc_dp<T, 24>(ctx, a, mode, sg);
     return launch_scan_wc_dp<T, 32>(ctx, a, mode, sg);
 }
@@ -1611,6 +1922,7 @@ int launch_disc_wc(pgps_ctx* ctx, long N, int d, const T* F, const T* Pinf, cons
     if (d <= 8) return launch_disc_wc_dp<T, 8>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
     if (d <= 12) return launch_disc_wc_dp<T, 12>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
     if (d <= 16) return launch_disc_wc_dp<T, 16>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
+    if (d <= 18) return launch_disc_wc_dp<T, 18>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
     if (d <= 24) return launch_disc_wc_dp<T, 24>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
     return launch_disc_wc_dp<T, 32>(ctx, N, d, F, Pinf, ts, t0, Fs, Qs);
 }
