@@ -33,6 +33,9 @@
 namespace pgps {
 namespace wc {
 
+#ifndef PGPS_WC_X
+#define PGPS_WC_X 0            // diagnostic builds only (profiles/r03_experiments.txt): bit 0 no gain elimination,
+#endif                         // 1 no smoothing combine, 2 no wave reductions, 3 no symmetrisation of the prediction
 constexpr int kGroupMax = 64;   // level-1 totals per level-2 wave: WcArgs::kgroup, 8..64 (launch_scan_wc)
 
 template <int DP>
@@ -934,32 +937,60 @@ struct Tile {
     }
 };
 
-// t += op(A) op(B), the modes of mm
+// t += op(A) op(B), the modes of mm.  For the paddings this family really serves (DP >= 18) the operands of the next
+// KU inner indices are requested before the multiply-adds of the current ones, with scheduling barriers in between:
+// left alone the compiler waits for every pair of indices in turn, and one wave per SIMD has nothing else to run
+// (tools/micro/wc_mm.hip: 2600 -> 1440 clocks per d = 18 product on an otherwise idle CU).
 template <typename T, int DP, int MODE>
 __device__ __forceinline__ void mm_acc(int dk, const T* __restrict__ A, const T* __restrict__ B, Tile<T, DP>& t) {
     constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD, KU = Geo<DP>::KU;
     const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
     if (!lactive<DP>()) return;
-    auto body = [&](int k0) {
+    auto load = [&](T (&av)[KU][TS], T (&bv)[KU][TS], int k0) {
 #pragma unroll
         for (int kk = 0; kk < KU; ++kk) {
             const int k = k0 + kk;
-            T av[TS], bv[TS];
 #pragma unroll
-            for (int ti = 0; ti < TS; ++ti) av[ti] = (MODE == 2) ? A[k * LD + r0 + ti] : A[(r0 + ti) * LD + k];
+            for (int ti = 0; ti < TS; ++ti) av[kk][ti] = (MODE == 2) ? A[k * LD + r0 + ti] : A[(r0 + ti) * LD + k];
 #pragma unroll
-            for (int tj = 0; tj < TS; ++tj) bv[tj] = (MODE == 1) ? B[(c0 + tj) * LD + k] : B[k * LD + c0 + tj];
+            for (int tj = 0; tj < TS; ++tj) bv[kk][tj] = (MODE == 1) ? B[(c0 + tj) * LD + k] : B[k * LD + c0 + tj];
+        }
+    };
+    auto fma = [&](const T (&av)[KU][TS], const T (&bv)[KU][TS]) {
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk)
 #pragma unroll
             for (int ti = 0; ti < TS; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < TS; ++tj) t.v[ti][tj] += av[ti] * bv[tj];
-        }
+                for (int tj = 0; tj < TS; ++tj) t.v[ti][tj] += av[kk][ti] * bv[kk][tj];
     };
-    if constexpr (Geo<DP>::FIXK) {
+    if constexpr (DP % (2 * KU) == 0 && DP >= 18) {
+        // two buffers, two groups per trip; the inner length rounded up to whole trips stays inside the padded slot
+        const int dk2 = Geo<DP>::FIXK ? DP : (dk + 2 * KU - 1) / (2 * KU) * (2 * KU);
+        T a0[KU][TS], b0[KU][TS], a1[KU][TS], b1[KU][TS];
+        load(a0, b0, 0);
+        auto trip = [&](int k0) {
+            load(a1, b1, k0 + KU);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + 2 * KU < dk2) load(a0, b0, k0 + 2 * KU);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (Geo<DP>::FIXK) {
 #pragma unroll
-        for (int k0 = 0; k0 < DP; k0 += KU) body(k0);
+            for (int k0 = 0; k0 < DP; k0 += 2 * KU) trip(k0);
+        } else {
+            for (int k0 = 0; k0 < dk2; k0 += 2 * KU) trip(k0);
+        }
     } else {
-        for (int k0 = 0; k0 < dk; k0 += KU) body(k0);
+        T av[KU][TS], bv[KU][TS];
+        for (int k0 = 0; k0 < dk; k0 += KU) {
+            load(av, bv, k0);
+            fma(av, bv);
+        }
     }
 }
 
@@ -1016,7 +1047,7 @@ __device__ __forceinline__ void scombine_tiles(int dk, T* racc, const T* re, T* 
     oE.zero();
     xx.zero();
     mm_acc<T, DP, 0>(dk, s.E, e.E, oE);
-    mm_acc<T, DP, 0>(dk, s.E, e.L, xx);
+    mm_acc<T, DP, 1>(dk, s.E, e.L, xx);        // L is symmetric: read as L^T, both operands along the inner index
     mv<T, DP, false>(dk, s.E, e.g, u, s.g);
     xx.st(X);
     sync();
@@ -1050,7 +1081,7 @@ __device__ __forceinline__ void extend_tiles(int dk, T* acc, const T* F, const T
     tc.zero();
     mm_acc<T, DP, 0>(dk, F, a.A, ta);           // A' = F A
     mv<T, DP, false>(dk, F, a.b, v1);           // b' = F b
-    mm_acc<T, DP, 0>(dk, F, a.C, tc);           // F C
+    mm_acc<T, DP, 1>(dk, F, a.C, tc);           // F C (C symmetric, read as C^T)
     tc.st(t2);
     sync();
     ta.st(a.A);
@@ -1201,26 +1232,28 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
         Tile<T, DP> fp;
         fp.zero();
         mv<T, DP, false>(dk, F, m, mp);
-        mm_acc<T, DP, 0>(dk, F, P, fp);
+        mm_acc<T, DP, 1>(dk, F, P, fp);                 // P is symmetric: read as P^T
         fp.st(FP);
         sync();
         mm_acc<T, DP, 1>(dk, FP, F, pp);
         pp.st(Pp);
         sync();
-        {
-            Tile<T, DP> t;
-            t.ld_t(Pp);
-            pp.average(t);
+        if (!(PGPS_WC_X & 8)) {
+            {
+                Tile<T, DP> t;
+                t.ld_t(Pp);
+                pp.average(t);
+            }
+            sync();
+            pp.st(Pp);
+            sync();
         }
-        sync();
-        pp.st(Pp);
-        sync();
         if (SMOOTH && k > k0) {
             // element of step k-1: E = (Pp^-1 F P)^T, g = m - E mp, L = P - sym(E F P)
             Smth<T, DP> e(Ee);
             {
                 Tile<T, DP> tm = pp;
-                solve_tiles<T, DP>(d, tm, fp, gj);       // fp <- Pp^-1 F P = E^T
+                if (!(PGPS_WC_X & 1)) solve_tiles<T, DP>(d, tm, fp, gj);       // fp <- Pp^-1 F P = E^T
             }
             fp.st_t(e.E);
             fp.st_g_t(d, a.Es + (k - 1) * dd);
@@ -1242,7 +1275,7 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
                 pprev.st(e.L);
             }
             sync();
-            scombine_tiles<T, DP>(dk, sacc, Ee, X, u);
+            if (!(PGPS_WC_X & 2)) scombine_tiles<T, DP>(dk, sacc, Ee, X, u);
         }
         if (halo) break;
         const T y = a.ys[k];
@@ -1251,8 +1284,8 @@ __global__ __launch_bounds__(64) void wc_apply1(const WcArgs<T> a) {
         // log-likelihood term from the predicted moments (also for the first step)
         mv<T, DP, false>(dk, Pp, h, u);
         sync();
-        const T S = dot<T, DP>(h, u) + a.R;
-        const T mu = dot<T, DP>(h, mp);
+        const T S = (PGPS_WC_X & 4) ? a.R + T(1) : dot<T, DP>(h, u) + a.R;
+        const T mu = (PGPS_WC_X & 4) ? T(0) : dot<T, DP>(h, mp);
         if (obs) {
             const double r = double(y) - double(mu);
             quad += r * r / double(S);
@@ -1424,7 +1457,7 @@ __global__ __launch_bounds__(64) void wc_smooth1(const WcArgs<T> a) {
             Tile<T, DP> fp;
             fp.zero();
             mv<T, DP, false>(dk, F, m, mp);
-            mm_acc<T, DP, 0>(dk, F, P, fp);
+            mm_acc<T, DP, 1>(dk, F, P, fp);             // P is symmetric: read as P^T
             fp.st(FP);
             sync();
             // X = sP' - (F P F^T + Q): the predicted covariance is not symmetrised on its own here -- the smoothed
@@ -1441,7 +1474,7 @@ __global__ __launch_bounds__(64) void wc_smooth1(const WcArgs<T> a) {
             Tile<T, DP> y;
             y.zero();
             mv<T, DP, false>(dk, E, v, sm, m);          // sm = m + E (sm' - mp)
-            mm_acc<T, DP, 0>(dk, E, X, y);
+            mm_acc<T, DP, 1>(dk, E, X, y);              // X^T for X: the same after the symmetrisation below
             y.st(Y);
             sync();
             sp = pt;
