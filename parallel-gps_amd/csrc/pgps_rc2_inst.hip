@@ -1,0 +1,35 @@
+// pgps_rc2_inst.hip -- one translation unit per padded state dimension of the two-rows level-1 kernels
+// (-DPGPS_RC2_DP=18|24|32): both scalar types, launched from pgps_wc.hip through launch_rc2_level1.
+#include "pgps_internal.h"
+#include "pgps_rc2.hip.h"
+
+#ifndef PGPS_RC2_DP
+#error "compile with -DPGPS_RC2_DP=<18|24|32>"
+#endif
+
+namespace pgps {
+
+#define PGPS_RC2_CAT2(a, b) a##b
+#define PGPS_RC2_CAT(a, b) PGPS_RC2_CAT2(a, b)
+#define PGPS_RC2_LAUNCH PGPS_RC2_CAT(launch_rc2_, PGPS_RC2_DP)
+
+// which: 0 reduce1, 1 apply1 (filter only), 2 apply1 (with the smoothing total), 3 smooth1
+template <typename T>
+static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
+    constexpr int DP = PGPS_RC2_DP;
+    const dim3 blk(64), grid((unsigned)((a.nchunk + 1) / 2));
+    switch (which) {
+        case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_reduce1<T, DP>, grid, blk, 0u, a); break;
+        case 1: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc2::rc2_apply1<T, DP, false>, grid, blk, 0u, a); break;
+        case 2: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc2::rc2_apply1<T, DP, true>, grid, blk, 0u, a); break;
+        case 3: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc2::rc2_smooth1<T, DP>, grid, blk, 0u, a); break;
+        default: return PGPS_E_INVALID;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+int PGPS_RC2_LAUNCH(pgps_ctx* ctx, int which, const wc::WcArgs<double>& a) { return launch_one<double>(ctx, which, a); }
+int PGPS_RC2_LAUNCH(pgps_ctx* ctx, int which, const wc::WcArgs<float>& a) { return launch_one<float>(ctx, which, a); }
+
+}  // namespace pgps

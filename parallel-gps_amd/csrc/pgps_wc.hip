@@ -29,6 +29,7 @@
 
 #include "pgps_internal.h"
 #include "pgps_math.h"
+#include "pgps_wc_args.h"
 
 namespace pgps {
 namespace wc {
@@ -273,8 +274,6 @@ __device__ __forceinline__ void solve(int d, T* M, T* B) {
 // ---- element records --------------------------------------------------------------------------------
 // global (compact): filter [A d^2 | C d^2 | J d^2 | b d | eta d], smoother [E d^2 | L d^2 | g d]
 // LDS (padded):     filter [A MSZ | C MSZ | J MSZ | b DP | eta DP], smoother [E MSZ | L MSZ | g DP]
-__host__ __device__ inline int nfilt(int d) { return 3 * d * d + 2 * d; }
-__host__ __device__ inline int nsmth(int d) { return 2 * d * d + d; }
 
 template <typename T, int DP>
 struct Filt {
@@ -335,38 +334,6 @@ __device__ __forceinline__ void smth_set_identity(int d, T* rec) {
     mat_eye<T, DP>(d, s.E);
 }
 
-// ---- kernel arguments ------------------------------------------------------------------------------
-template <typename T>
-struct WcArgs {
-    long N;
-    int d, Lw;
-    long nchunk;            // level-1 chunks
-    int ngroup;             // level-2 groups
-    int kgroup;             // chunks per group
-    const T *P0, *H;
-    T R;
-    const T *Fs, *Qs, *ys;
-    T *fms, *fPs, *sms, *sPs;
-    T* Es;                  // (N, d, d) smoother gains, wc_apply1 -> wc_smooth1: sPs itself, or workspace between the
-                            // phases of a segment (the smoothed arrays only arrive with the last phase)
-    double* ll;
-    // workspace (compact records)
-    T* agg1;                // (nchunk, nfilt)
-    T* lpre1;               // (nchunk, nfilt)  exclusive prefix of agg1 inside its group
-    T* agg2;                // (ngroup, nfilt)
-    T* carry2;              // (ngroup, d + d^2) filtered (m, P) entering each group
-    T* sagg1;               // (nchunk, nsmth)
-    T* lsuf1;               // (nchunk, nsmth)  exclusive suffix of sagg1 inside its group
-    T* sagg2;               // (ngroup, nsmth)
-    T* scarry2;             // (ngroup, d + d^2) smoothed (m, P) of the first step after each group
-    double* llpart;         // (nchunk,)
-    T *ksA, *ksB;           // (ngroup, nfilt) each: Kogge-Stone ping-pong over the group totals (both scans)
-    // one segment of a series sharded over several GPUs (pgps_seg_*): whole series = first and last, no pointers
-    int seg_first, seg_last;
-    const T* carry_in;      // (d + d^2) filtered (m, P) entering the segment            (not seg_first)
-    const T* carry_back;    // (d + d^2) smoothed (m, P) of the next segment's first step (not seg_last)
-    const T *halo_F, *halo_Q;   // (d, d) each: F, Q of the next segment's first step     (not seg_last)
-};
 
 // One step's (F, Q) as register tiles: fetched a step ahead, parked in LDS when needed.
 template <typename T, int DP>
@@ -717,6 +684,55 @@ __global__ __launch_bounds__(64) void wc_fin_filter(const WcArgs<T> a, const T* 
     T* out = a.carry2 + (long)g * (d + dd);
     vec_l2g<T, DP>(d, m, out);
     mat_l2g<T, DP>(d, P, out + d);
+}
+
+// The state entering every chunk, for the two-rows level-1 kernels (pgps_rc2.hip.h): the group's carry pushed through
+// the chunk's in-group prefix -- the prologue of wc_apply1 as a kernel of its own (one wave per chunk)
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_enter1(const WcArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MSZ = Geo<DP>::MSZ;
+    const int d = a.d, dd = d * d, nf = nfilt(d), dk = Geo<DP>::dk(d);
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* m = pool.take(DP); T* P = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NFL);
+    T* M = pool.take(MSZ); T* rhs = pool.take(DP * Geo<DP>::NRA); T* X = pool.take(MSZ);
+    const long c = blockIdx.x;
+    if (c >= a.nchunk) return;
+    const int g = (int)(c / a.kgroup);
+    const T* cg = a.carry2 + (long)g * (d + dd);
+    vec_g2l<T, DP>(d, cg, m);
+    mat_g2l<T, DP>(d, cg + d, P);
+    filt_g2l<T, DP>(d, a.lpre1 + c * nf, cur);
+    sync();
+    apply<T, DP>(d, dk, m, P, cur, M, rhs, X);
+    sync();
+    T* out = a.enter1 + c * (d + dd);
+    vec_l2g<T, DP>(d, m, out);
+    mat_l2g<T, DP>(d, P, out + d);
+}
+
+// ... and the smoothed state of the first step after every chunk (the prologue of wc_smooth1)
+template <typename T, int DP>
+__global__ __launch_bounds__(64) void wc_senter1(const WcArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MSZ = Geo<DP>::MSZ;
+    const int d = a.d, dd = d * d, ns = nsmth(d), dk = Geo<DP>::dk(d);
+    Pool<T> pool(reinterpret_cast<T*>(smem));
+    T* sm = pool.take(DP); T* sP = pool.take(MSZ); T* cur = pool.take(Geo<DP>::NSL);
+    T* X = pool.take(MSZ); T* Y = pool.take(MSZ); T* v = pool.take(DP);
+    const long c = blockIdx.x;
+    if (c >= a.nchunk) return;
+    const int g = (int)(c / a.kgroup);
+    const T* cg = a.scarry2 + (long)g * (d + dd);
+    vec_g2l<T, DP>(d, cg, sm);
+    mat_g2l<T, DP>(d, cg + d, sP);
+    smth_g2l<T, DP>(d, a.lsuf1 + c * ns, cur);
+    sync();
+    sapply<T, DP>(dk, cur, sm, sP, X, v, Y);
+    sync();
+    T* out = a.senter1 + c * (d + dd);
+    vec_l2g<T, DP>(d, sm, out);
+    mat_l2g<T, DP>(d, sP, out + d);
 }
 
 // suffix scan of the smoothing totals: out[i] = in[i] (x) in[i + stride] (the later element is applied first)
@@ -1696,6 +1712,15 @@ struct WcSeg {
     double* ll;
 };
 
+// level-1 kernels of the two-rows family (pgps_rc2.hip.h; pgps_rc2_inst.hip, one unit per padded dimension).
+// which: 0 reduce1, 1 apply1 (filter only), 2 apply1 (with the smoothing total), 3 smooth1
+int launch_rc2_18(pgps_ctx*, int which, const wc::WcArgs<double>&);
+int launch_rc2_18(pgps_ctx*, int which, const wc::WcArgs<float>&);
+int launch_rc2_24(pgps_ctx*, int which, const wc::WcArgs<double>&);
+int launch_rc2_24(pgps_ctx*, int which, const wc::WcArgs<float>&);
+int launch_rc2_32(pgps_ctx*, int which, const wc::WcArgs<double>&);
+int launch_rc2_32(pgps_ctx*, int which, const wc::WcArgs<float>&);
+
 template <typename T, int DP>
 static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const WcSeg<T>* sg = nullptr) {
     using namespace wc;
@@ -1733,9 +1758,38 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
     WC_ATTR((wc_fin_smoother_cb<T, DP>), l_scarry3);
     WC_ATTR((wc_seg_carry_f<T, DP>), l_carry3);
     WC_ATTR((wc_seg_carry_s<T, DP>), l_scarry3);
+    WC_ATTR((wc_enter1<T, DP>), l_carry3);
+    WC_ATTR((wc_senter1<T, DP>), l_scarry3);
 #undef WC_ATTR
     attr_done = true;
     const dim3 blk(64), g1((unsigned)a.nchunk), g2((unsigned)a.ngroup);
+    // Level 1 (which: 0 reduce, 1 apply filter only, 2 apply with the smoothing total, 3 smooth): the two-rows kernels for
+    // the paddings 18, 24, 32 -- every state dimension this family is chosen for -- unless PGPS_WC_ROWS2=0 asks for the
+    // LDS-tile kernels of this file (the cross-check of the tests, and d <= 16 when this family is forced)
+    const bool rows2 = DP >= 18 && ctx->wc_rows2 != 0;
+    auto level1 = [&](int which) -> int {
+        if (rows2) {
+            if (which == 1 || which == 2)
+                timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_enter1<T, DP>, g1, blk, (unsigned)bytes(l_carry3), a);
+            if (which == 3) timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_senter1<T, DP>, g1, blk, (unsigned)bytes(l_scarry3), a);
+            if constexpr (DP == 18) return launch_rc2_18(ctx, which, a);
+            else if constexpr (DP == 24) return launch_rc2_24(ctx, which, a);
+            else if constexpr (DP == 32) return launch_rc2_32(ctx, which, a);
+            else return PGPS_E_UNSUPPORTED_DIM;
+        }
+        switch (which) {
+            case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T, DP>, g1, blk, (unsigned)bytes(l_reduce1), a); break;
+            case 1: timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, DP, false>, g1, blk, (unsigned)bytes(l_apply1), a); break;
+            case 2: timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, DP, true>, g1, blk, (unsigned)bytes(l_apply1), a); break;
+            default: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_smooth1<T, DP>, g1, blk, (unsigned)bytes(l_smooth1), a); break;
+        }
+        return PGPS_OK;
+    };
+#define WC_LEVEL1(which)                 \
+    do {                                 \
+        const int r1_ = level1(which);   \
+        if (r1_) return r1_;             \
+    } while (0)
     if (sg) {
         // Three phases with the ranks' records exchanged in between (pssgp/distributed.py); chunk / group totals, their
         // scans and the in-group prefixes stay in the workspace from one phase to the next.
@@ -1750,7 +1804,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
             return steps == 0 ? first : ((steps & 1) ? a.ksA : a.ksB);
         };
         if (mode == MODE_SEG_REDUCE) {
-            timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T, DP>, g1, blk, (unsigned)bytes(l_reduce1), a);
+            WC_LEVEL1(0);
             timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce2<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a);
             const T* cur = a.agg2;
             T* nxt = a.ksA;
@@ -1781,7 +1835,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
                 a.halo_Q = sg->halo + dd;
             }
             timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_fin_filter<T, DP>, g2, blk, (unsigned)bytes(l_carry3), a, incl);
-            timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, DP, true>, g1, blk, (unsigned)bytes(l_apply1), a);
+            WC_LEVEL1(2);
             timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_sreduce2<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a);
             const T* cur = a.sagg2;
             T* nxt = a.ksA;
@@ -1811,13 +1865,13 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
         } else {
             timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_fin_smoother<T>, g2, blk, 0u, a, sfx);
         }
-        timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_smooth1<T, DP>, g1, blk, (unsigned)bytes(l_smooth1), a);
+        WC_LEVEL1(3);
         if (sg->ll)
             hipLaunchKernelGGL(rc::seg_ll_sum<T>, dim3(1), dim3(64), 0, ctx->stream, sg->gathered_s, sg->nranks, rs, spad, sg->ll);
         HIPCHK(ctx, hipGetLastError());
         return PGPS_OK;
     }
-    timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T, DP>, g1, blk, (unsigned)bytes(l_reduce1), a);
+    WC_LEVEL1(0);
     timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce2<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a);
     // level 3: Kogge-Stone over the group totals, ping-pong agg2 -> ksA -> ksB -> ...; serial wc_carry3 / wc_scarry3
     // (one wave walking the groups) only when forced (PGPS_WC_SERIAL3, the cross-check of the tests)
@@ -1836,7 +1890,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
         timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_fin_filter<T, DP>, g2, blk, (unsigned)bytes(l_carry3), a, cur);
     }
     if (mode == MODE_PKFS) {
-        timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, DP, true>, g1, blk, (unsigned)bytes(l_apply1), a);
+        WC_LEVEL1(2);
         timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_sreduce2<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a);
         if (serial3) {
             timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_scarry3<T, DP>, dim3(1), blk, (unsigned)bytes(l_scarry3), a);
@@ -1854,13 +1908,14 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
                 timed_launch(ctx, PGPS_K_LL_FINALIZE, wc::wc_ll_finalize, dim3(1), blk, 0u, (const double*)a.llpart,
                              (long)a.nchunk, a.ll);
         }
-        timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_smooth1<T, DP>, g1, blk, (unsigned)bytes(l_smooth1), a);
+        WC_LEVEL1(3);
     } else {
-        timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_apply1<T, DP, false>, g1, blk, (unsigned)bytes(l_apply1), a);
+        WC_LEVEL1(1);
         if (a.ll)
             timed_launch(ctx, PGPS_K_LL_FINALIZE, wc::wc_ll_finalize, dim3(1), blk, 0u, (const double*)a.llpart,
                          (long)a.nchunk, a.ll);
     }
+#undef WC_LEVEL1
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }
@@ -1908,6 +1963,8 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     const size_t o_cback = off;  if (seg) off = wc_align(off + (d + dd) * sizeof(T));
     const size_t o_halo = off;   if (seg) off = wc_align(off + 2 * dd * sizeof(T));
     const size_t o_E = off;      if (seg) off = wc_align(off + (size_t)sa.N * dd * sizeof(T));
+    const size_t o_en = off;     off = wc_align(off + nc * (d + dd) * sizeof(T));
+    const size_t o_sen = off;    off = wc_align(off + nc * (d + dd) * sizeof(T));
     int rc = ensure(ctx, ctx->ws, off);
     if (rc) return rc;
     char* base = (char*)ctx->ws.p;
@@ -1915,6 +1972,7 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     a.carry2 = (T*)(base + o_carry2); a.sagg1 = (T*)(base + o_sagg1); a.lsuf1 = (T*)(base + o_lsuf1);
     a.sagg2 = (T*)(base + o_sagg2); a.scarry2 = (T*)(base + o_sc2); a.llpart = (double*)(base + o_ll);
     a.Es = seg ? (T*)(base + o_E) : a.sPs;
+    a.enter1 = (T*)(base + o_en); a.senter1 = (T*)(base + o_sen);
     a.ksA = (T*)(base + o_ksA); a.ksB = (T*)(base + o_ksB);
     WcSeg<T> sgv{};
     if (seg) {
