@@ -72,7 +72,7 @@ extern "C" int pgps_create(int device, pgps_ctx** out) {
     }
     ctx->stream = ctx->own_stream;
     if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->n_cu = 0;
-    if (const char* e = std::getenv("PGPS_WC_ROWS2")) ctx->wc_rows2 = (e[0] != '0');          // diagnostic, see pgps_wc.hip
+    if (const char* e = std::getenv("PGPS_WC_ROWS2")) ctx->wc_rows2 = std::atoi(e) & 15;            // diagnostic, see pgps_wc.hip
     if (const char* e = std::getenv("PGPS_WC_SERIAL3")) ctx->wc_serial3 = (e[0] == '1');      // diagnostic, see pgps_wc.hip
     if (hipMalloc((void**)&ctx->status_word, 256) != hipSuccess || hipMemset(ctx->status_word, 0, 256) != hipSuccess) {
         (void)hipStreamDestroy(ctx->own_stream);

@@ -35,7 +35,7 @@ struct pgps_ctx {
     DevBuf ws;                          // scratch of the scan kernels
     DevBuf st[12];                      // staging buffers of the host entry points
     bool wc_attr_done[2][17] = {};      // wave-cooperative kernels: dynamic-LDS attributes set (by dtype, DP / 2)
-    int wc_rows2 = 1;                   // d = 17..32: two-rows level-1 kernels (pgps_rc2.hip.h); 0 = the LDS-tile ones (env PGPS_WC_ROWS2)
+    int wc_rows2 = 15;                  // d = 17..32: two-rows level-1 kernels (pgps_rc2.hip.h); 0 = the LDS-tile ones (env PGPS_WC_ROWS2)
     int wc_serial3 = 0;                 // wave-cooperative family: serial level 3 instead of Kogge-Stone (env PGPS_WC_SERIAL3)
     DevBuf lti[12];                     // general-LTI entry points: model, merged series, Fs, Qs, E, g (d > 16: moments)
     DevBuf stamps;                      // diagnostic build only

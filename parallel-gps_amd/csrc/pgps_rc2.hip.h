@@ -186,19 +186,31 @@ struct Ops {
         for (int j = 0; j < DP; ++j) a[j] = T(0.5) * (a[j] + at[j]);
     }
 
-    // row i of a compact (d x d) matrix in global memory; zero padding
+    // row i of a compact (d x d) matrix in global memory; zero padding.  Every lane reads valid addresses (clamped
+    // indices) and the padding is selected afterwards: a load under a lane-dependent condition becomes a branch of
+    // its own with its own wait for memory, DP of them one after the other.
     static __device__ __forceinline__ void ld_row(const T* g, int d, int i, T* a) {
         const bool in = i < d;
         const T* r = g + (in ? i : 0) * d;
+        T v[DP];
 #pragma unroll
-        for (int j = 0; j < DP; ++j) a[j] = (in && j < d) ? r[j] : T(0);
+        for (int j = 0; j < DP; ++j) v[j] = r[j < d ? j : 0];
+#pragma unroll
+        for (int j = 0; j < DP; ++j) a[j] = (in && j < d) ? v[j] : T(0);
     }
     // ... of its symmetric part
     static __device__ __forceinline__ void ld_row_sym(const T* g, int d, int i, T* a) {
         const bool in = i < d;
         const int ii = in ? i : 0;
+        T v[DP], w[DP];
 #pragma unroll
-        for (int j = 0; j < DP; ++j) a[j] = (in && j < d) ? T(0.5) * (g[ii * d + j] + g[j * d + ii]) : T(0);
+        for (int j = 0; j < DP; ++j) {
+            const int jj = j < d ? j : 0;
+            v[j] = g[ii * d + jj];
+            w[j] = g[jj * d + ii];
+        }
+#pragma unroll
+        for (int j = 0; j < DP; ++j) a[j] = (in && j < d) ? T(0.5) * (v[j] + w[j]) : T(0);
     }
     static __device__ __forceinline__ void st_row(T* g, int d, int i, bool ok, const T* a) {
         if (ok && i < d) {

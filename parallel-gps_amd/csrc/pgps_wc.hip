@@ -1764,11 +1764,10 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
     attr_done = true;
     const dim3 blk(64), g1((unsigned)a.nchunk), g2((unsigned)a.ngroup);
     // Level 1 (which: 0 reduce, 1 apply filter only, 2 apply with the smoothing total, 3 smooth): the two-rows kernels for
-    // the paddings 18, 24, 32 -- every state dimension this family is chosen for -- unless PGPS_WC_ROWS2=0 asks for the
+    // the paddings 18, 24, 32 -- every state dimension this family is chosen for -- unless PGPS_WC_ROWS2=0 (or a mask of `which` bits) asks for the
     // LDS-tile kernels of this file (the cross-check of the tests, and d <= 16 when this family is forced)
-    const bool rows2 = DP >= 18 && ctx->wc_rows2 != 0;
     auto level1 = [&](int which) -> int {
-        if (rows2) {
+        if (DP >= 18 && ((ctx->wc_rows2 >> which) & 1)) {
             if (which == 1 || which == 2)
                 timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_enter1<T, DP>, g1, blk, (unsigned)bytes(l_carry3), a);
             if (which == 3) timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_senter1<T, DP>, g1, blk, (unsigned)bytes(l_scarry3), a);
