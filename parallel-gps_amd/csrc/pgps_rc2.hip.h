@@ -189,35 +189,48 @@ struct Ops {
     // row i of a compact (d x d) matrix in global memory; zero padding.  Every lane reads valid addresses (clamped
     // indices) and the padding is selected afterwards: a load under a lane-dependent condition becomes a branch of
     // its own with its own wait for memory, DP of them one after the other.
+    //
+    // FULL (d == DP, e.g. the CO2 kernel's d = 18): no column is padding, and the lanes beyond row d - 1 are left with
+    // a copy of row 0 instead of zeros -- no select at all.  Nothing an active lane reads comes from those lanes (the
+    // broadcasts name lanes below DP, the transposes and stores are guarded by the row, a chain sum multiplies their
+    // term by a zero of h) and what they compute stays finite, being the arithmetic of a real row.
+    template <bool FULL = false>
     static __device__ __forceinline__ void ld_row(const T* g, int d, int i, T* a) {
         const bool in = i < d;
         const T* r = g + (in ? i : 0) * d;
-        T v[DP];
+        if constexpr (FULL) {
 #pragma unroll
-        for (int j = 0; j < DP; ++j) v[j] = r[j < d ? j : 0];
+            for (int j = 0; j < DP; ++j) a[j] = r[j];
+        } else {
+            T v[DP];
 #pragma unroll
-        for (int j = 0; j < DP; ++j) a[j] = (in && j < d) ? v[j] : T(0);
+            for (int j = 0; j < DP; ++j) v[j] = r[j < d ? j : 0];
+#pragma unroll
+            for (int j = 0; j < DP; ++j) a[j] = (in && j < d) ? v[j] : T(0);
+        }
     }
     // ... of its symmetric part
+    template <bool FULL = false>
     static __device__ __forceinline__ void ld_row_sym(const T* g, int d, int i, T* a) {
         const bool in = i < d;
         const int ii = in ? i : 0;
         T v[DP], w[DP];
 #pragma unroll
         for (int j = 0; j < DP; ++j) {
-            const int jj = j < d ? j : 0;
+            const int jj = (FULL || j < d) ? j : 0;
             v[j] = g[ii * d + jj];
             w[j] = g[jj * d + ii];
         }
 #pragma unroll
-        for (int j = 0; j < DP; ++j) a[j] = (in && j < d) ? T(0.5) * (v[j] + w[j]) : T(0);
+        for (int j = 0; j < DP; ++j) a[j] = (FULL || (in && j < d)) ? T(0.5) * (v[j] + w[j]) : T(0);
     }
+    template <bool FULL = false>
     static __device__ __forceinline__ void st_row(T* g, int d, int i, bool ok, const T* a) {
         if (ok && i < d) {
             T* r = g + i * d;
 #pragma unroll
             for (int j = 0; j < DP; ++j)
-                if (j < d) r[j] = a[j];
+                if (FULL || j < d) r[j] = a[j];
         }
     }
 
@@ -256,7 +269,7 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 // ====================================================================================================
 // level 1: reduce -- the chunk's filtering total (wc_reduce1)
 // ====================================================================================================
-template <typename T, int DP>
+template <typename T, int DP, bool FULL>
 __global__ __launch_bounds__(64) void rc2_reduce1(const WcArgs<T> a) {
     using O = Ops<T, DP>;
     __shared__ T tl_all[2 * O::TLN];
@@ -270,9 +283,6 @@ __global__ __launch_bounds__(64) void rc2_reduce1(const WcArgs<T> a) {
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
     const bool row = i < d;
     const T hi_ = row ? a.H[row ? i : 0] : T(0);
-    T hf[DP];
-#pragma unroll
-    for (int j = 0; j < DP; ++j) hf[j] = j < d ? a.H[j < d ? j : 0] : T(0);
     // identity element
     T A[DP], C[DP], J[DP], b = T(0), eta = T(0);
 #pragma unroll
@@ -283,8 +293,8 @@ __global__ __launch_bounds__(64) void rc2_reduce1(const WcArgs<T> a) {
         const long k = kk < k1 ? kk : k1 - 1;
         const bool first = (k == 0 && a.seg_first != 0);
         T F[DP], Q[DP];
-        O::ld_row(a.Fs + k * dd, d, i, F);
-        O::ld_row_sym(a.Qs + k * dd, d, i, Q);
+        O::template ld_row<FULL>(a.Fs + k * dd, d, i, F);
+        O::template ld_row_sym<FULL>(a.Qs + k * dd, d, i, Q);
         const T y = a.ys[k];
         // predict: A' = F A, b' = F b, C' = F C F^T + Q
         T An[DP], Cn[DP], bn;
@@ -303,22 +313,20 @@ __global__ __launch_bounds__(64) void rc2_reduce1(const WcArgs<T> a) {
         }
         if (first) {        // the first element of the series: the prior itself, nothing to propagate
             T P0r[DP];
-            O::ld_row(a.P0, d, i, P0r);
+            O::template ld_row<FULL>(a.P0, d, i, P0r);
 #pragma unroll
             for (int j = 0; j < DP; ++j) { An[j] = T(0); Cn[j] = P0r[j]; }
             bn = T(0);
         }
         O::symmetrise(Cn, tl, i);
         // scalar-innovation update (all zero multipliers when the observation is missing)
-        T u = T(0);
-#pragma unroll
-        for (int j = 0; j < DP; ++j) u = fma_t(Cn[j], hf[j], u);            // u = C' h
-        T v = T(0);
+        // (h is a distributed vector like any other: element i in lane i)
+        const T u = O::mv(Cn, hi_);                     // u = C' h
+        T v;
         {
             T At[DP];
             O::transpose(An, At, tl, i);
-#pragma unroll
-            for (int j = 0; j < DP; ++j) v = fma_t(At[j], hf[j], v);        // v = A'^T h
+            v = O::mv(At, hi_);                         // v = A'^T h
         }
         const T S = O::chain_sum(hi_ * u) + a.R;
         const T hb = O::chain_sum(hi_ * bn);
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(64) void rc2_reduce1(const WcArgs<T> a) {
         const T res = obs ? y - hb : T(0);
         O::rank1(An, v, -u * inv);
         O::rank1(Cn, u, -u * inv);
-        O::rank1(J, v, v * inv);
+        O::rank1(J, v, live ? v * inv : T(0));          // (in place: a chain past its last step adds zeros)
         bn += u * inv * res;
         const T etan = eta + v * res * inv;
         // a chain past its last step keeps its total
@@ -335,14 +343,11 @@ __global__ __launch_bounds__(64) void rc2_reduce1(const WcArgs<T> a) {
         O::select(C, live, Cn);
         b = live ? bn : b;
         eta = live ? etan : eta;
-        // (J was updated in place: undo nothing -- inv = 0 when the chain is not live would be wrong for a dead chain
-        //  with a live observation, so the J update is re-derived below)
-        if (!live) O::rank1(J, v, -(v * inv));
     }
     T* out = a.agg1 + c * nfilt(d);
-    O::st_row(out, d, i, valid, A);
-    O::st_row(out + dd, d, i, valid, C);
-    O::st_row(out + 2 * dd, d, i, valid, J);
+    O::template st_row<FULL>(out, d, i, valid, A);
+    O::template st_row<FULL>(out + dd, d, i, valid, C);
+    O::template st_row<FULL>(out + 2 * dd, d, i, valid, J);
     if (valid && row) {
         out[3 * dd + i] = b;
         out[3 * dd + d + i] = eta;
@@ -378,7 +383,7 @@ __device__ __forceinline__ void scombine(SmthAcc<T, DP>& s, const T* eE, const T
     s.g = take ? og : s.g;
 }
 
-template <typename T, int DP, bool SMOOTH>
+template <typename T, int DP, bool SMOOTH, bool FULL>
 __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
     using O = Ops<T, DP>;
     __shared__ T tl_all[2 * O::TLN];
@@ -394,14 +399,11 @@ __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
     const long k0 = c * a.Lw, k1 = min(a.N, k0 + a.Lw);
     const bool row = i < d;
     const T hi_ = row ? a.H[row ? i : 0] : T(0);
-    T hf[DP];
-#pragma unroll
-    for (int j = 0; j < DP; ++j) hf[j] = j < d ? a.H[j < d ? j : 0] : T(0);
     // state entering the chunk (wc_enter1)
     const T* en = a.enter1 + c * (d + dd);
     T m = row ? en[row ? i : 0] : T(0);
     T P[DP];
-    O::ld_row(en + d, d, i, P);
+    O::template ld_row<FULL>(en + d, d, i, P);
     SmthAcc<T, DP> sacc;
     if (SMOOTH) {
 #pragma unroll
@@ -423,8 +425,8 @@ __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
         const T* Qg = a.Qs + kc * dd;
         if (SMOOTH && k == a.N && !a.seg_last) { Fg = a.halo_F; Qg = a.halo_Q; }
         T F[DP], Q[DP];
-        O::ld_row(Fg, d, i, F);
-        O::ld_row_sym(Qg, d, i, Q);
+        O::template ld_row<FULL>(Fg, d, i, F);
+        O::template ld_row_sym<FULL>(Qg, d, i, Q);
         const T y = a.ys[kc];
         // predict
         const T mp = O::mv(F, m);
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
                 for (int j = 0; j < DP; ++j) X[j] *= dinv;
                 O::transpose(X, E, tl, i);
             }
-            O::st_row(a.Es + (k > 0 ? k - 1 : 0) * dd, d, i, el, E);
+            O::template st_row<FULL>(a.Es + (k > 0 ? k - 1 : 0) * dd, d, i, el, E);
             eg = m - O::mv(E, mp);
             {
                 T lo[DP], hi[DP], X[DP], Xt[DP];
@@ -467,9 +469,7 @@ __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
             scombine<T, DP>(sacc, E, L, eg, el, tl, i);
         }
         // log-likelihood term from the predicted moments (also for the first step), measurement update
-        T u = T(0);
-#pragma unroll
-        for (int j = 0; j < DP; ++j) u = fma_t(Pp[j], hf[j], u);
+        const T u = O::mv(Pp, hi_);                     // (h: a distributed vector, element i in lane i)
         const T S = O::chain_sum(hi_ * u) + a.R;
         const T mu = O::chain_sum(hi_ * mp);
         const bool obs = !(y != y);
@@ -487,9 +487,7 @@ __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
         mn = mp;
         if (blockIdx.x == 0 && s == 0 && a.seg_first) {
             // (wave-uniform) the first step of the series updates straight from the prior: chain 0 of this wave
-            T u0 = T(0);
-#pragma unroll
-            for (int j = 0; j < DP; ++j) u0 = fma_t(P[j], hf[j], u0);
+            const T u0 = O::mv(P, hi_);
             const T S0 = O::chain_sum(hi_ * u0) + a.R;
             const T mu0 = O::chain_sum(hi_ * m);
             O::select(Pn, first, P);
@@ -504,7 +502,7 @@ __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
         O::select(P, regular, Pn);
         m = regular ? mn : m;
         if (regular && row) a.fms[k * d + i] = m;
-        O::st_row(a.fPs + kc * dd, d, i, regular, P);
+        O::template st_row<FULL>(a.fPs + kc * dd, d, i, regular, P);
     }
     if (SMOOTH) {
         // last element of the series: (0, m_N, P_N)
@@ -512,8 +510,8 @@ __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
         O::zero(Z);
         scombine<T, DP>(sacc, Z, P, m, valid && ends_series, tl, i);
         T* out = a.sagg1 + c * nsmth(d);
-        O::st_row(out, d, i, valid, sacc.E);
-        O::st_row(out + dd, d, i, valid, sacc.L);
+        O::template st_row<FULL>(out, d, i, valid, sacc.E);
+        O::template st_row<FULL>(out + dd, d, i, valid, sacc.L);
         if (valid && row) out[2 * dd + i] = sacc.g;
     }
     if (valid && i == 0) {
@@ -525,7 +523,7 @@ __global__ __launch_bounds__(64) void rc2_apply1(const WcArgs<T> a) {
 // ====================================================================================================
 // level 1 (smoother): RTS pass backwards over the chunk with the gains rc2_apply1 left in a.Es (wc_smooth1)
 // ====================================================================================================
-template <typename T, int DP>
+template <typename T, int DP, bool FULL>
 __global__ __launch_bounds__(64) void rc2_smooth1(const WcArgs<T> a) {
     using O = Ops<T, DP>;
     __shared__ T tl_all[2 * O::TLN];
@@ -542,7 +540,7 @@ __global__ __launch_bounds__(64) void rc2_smooth1(const WcArgs<T> a) {
     const T* se = a.senter1 + c * (d + dd);
     T sm = row ? se[row ? i : 0] : T(0);
     T sP[DP];
-    O::ld_row(se + d, d, i, sP);
+    O::template ld_row<FULL>(se + d, d, i, sP);
     for (int s = 0; s < a.Lw; ++s) {
         const long kk = k1 - 1 - s;
         const bool live = valid && kk >= k0;
@@ -553,10 +551,10 @@ __global__ __launch_bounds__(64) void rc2_smooth1(const WcArgs<T> a) {
         const T* Qg = a.Qs + (k + 1 < a.N ? k + 1 : k) * dd;
         if (k + 1 == a.N && !a.seg_last) { Fg = a.halo_F; Qg = a.halo_Q; }
         T F[DP], X[DP], P[DP], E[DP];
-        O::ld_row(Fg, d, i, F);
-        O::ld_row_sym(Qg, d, i, X);                     // X: Q now, sP' - Pp below
-        O::ld_row(a.fPs + k * dd, d, i, P);
-        O::ld_row(a.Es + k * dd, d, i, E);
+        O::template ld_row<FULL>(Fg, d, i, F);
+        O::template ld_row_sym<FULL>(Qg, d, i, X);                     // X: Q now, sP' - Pp below
+        O::template ld_row<FULL>(a.fPs + k * dd, d, i, P);
+        O::template ld_row<FULL>(a.Es + k * dd, d, i, E);
         const T m = row ? a.fms[k * d + (row ? i : 0)] : T(0);
         const T mp = O::mv(F, m);
         {
@@ -586,7 +584,7 @@ __global__ __launch_bounds__(64) void rc2_smooth1(const WcArgs<T> a) {
         O::select(sP, live, sPn);
         sm = live ? smt : sm;
         if (live && row) a.sms[k * d + i] = sm;
-        O::st_row(a.sPs + k * dd, d, i, live, sP);
+        O::template st_row<FULL>(a.sPs + k * dd, d, i, live, sP);
     }
 }
 

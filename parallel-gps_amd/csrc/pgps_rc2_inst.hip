@@ -18,13 +18,20 @@ template <typename T>
 static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
     constexpr int DP = PGPS_RC2_DP;
     const dim3 blk(64), grid((unsigned)((a.nchunk + 1) / 2));
+    const bool full = a.d == DP;        // no padding: the loads and stores without their column conditions
+#define PGPS_RC2_GO(SLOT, ...)                                                              \
+    do {                                                                                    \
+        if (full) timed_launch(ctx, SLOT, rc2::__VA_ARGS__, true>, grid, blk, 0u, a);       \
+        else timed_launch(ctx, SLOT, rc2::__VA_ARGS__, false>, grid, blk, 0u, a);           \
+    } while (0)
     switch (which) {
-        case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_reduce1<T, DP>, grid, blk, 0u, a); break;
-        case 1: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc2::rc2_apply1<T, DP, false>, grid, blk, 0u, a); break;
-        case 2: timed_launch(ctx, PGPS_K_FILTER_APPLY, rc2::rc2_apply1<T, DP, true>, grid, blk, 0u, a); break;
-        case 3: timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, rc2::rc2_smooth1<T, DP>, grid, blk, 0u, a); break;
+        case 0: PGPS_RC2_GO(PGPS_K_FILTER_REDUCE, rc2_reduce1<T, DP); break;
+        case 1: PGPS_RC2_GO(PGPS_K_FILTER_APPLY, rc2_apply1<T, DP, false); break;
+        case 2: PGPS_RC2_GO(PGPS_K_FILTER_APPLY, rc2_apply1<T, DP, true); break;
+        case 3: PGPS_RC2_GO(PGPS_K_SMOOTHER_APPLY, rc2_smooth1<T, DP); break;
         default: return PGPS_E_INVALID;
     }
+#undef PGPS_RC2_GO
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "pgps_internal.h"
 #include "pgps_math.h"
@@ -37,7 +38,7 @@ namespace wc {
 #ifndef PGPS_WC_X
 #define PGPS_WC_X 0            // diagnostic builds only (profiles/r03_experiments.txt): bit 0 no gain elimination,
 #endif                         // 1 no smoothing combine, 2 no wave reductions, 3 no symmetrisation of the prediction
-constexpr int kGroupMax = 64;   // level-1 totals per level-2 wave: WcArgs::kgroup, 8..64 (launch_scan_wc)
+constexpr int kGroupMax = 64;   // level-1 totals per level-2 wave: WcArgs::kgroup, 4..64 (launch_scan_wc)
 
 template <int DP>
 struct Geo {
@@ -1928,14 +1929,17 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     WcArgs<T> a{};
     a.N = sa.N; a.d = d;
-    // one wave per chunk: about a thousand chunks before the chunks grow to 64 steps; groups of 8..64 chunks so that the
+    // one wave per chunk: about a thousand chunks before the chunks grow to 64 steps; groups of 4..64 chunks so that the
     // Kogge-Stone levels over the group totals stay at one round of waves (<= 512 groups up to 2^21 steps)
     long lw = ctx->chunk > 0 ? ctx->chunk : (sa.N + 1023) / 1024;
     if (ctx->chunk <= 0) lw = lw < 16 ? 16 : (lw > 64 ? 64 : lw);
     a.Lw = (int)lw;
     a.nchunk = (sa.N + a.Lw - 1) / a.Lw;
     long kg = (a.nchunk + 511) / 512;
-    a.kgroup = (int)(kg < 8 ? 8 : (kg > kGroupMax ? kGroupMax : kg));
+    // (PGPS_WC_KGROUP_MIN: diagnostic, the smallest group; read once)
+    static const long kgmin_env = [] { const char* e = std::getenv("PGPS_WC_KGROUP_MIN"); return e ? std::atol(e) : 0L; }();
+    const long kgmin = kgmin_env > 0 ? kgmin_env : 4;
+    a.kgroup = (int)(kg < kgmin ? kgmin : (kg > kGroupMax ? kGroupMax : kg));
     a.ngroup = (int)((a.nchunk + a.kgroup - 1) / a.kgroup);
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs; a.ll = seg ? nullptr : sa.ll;

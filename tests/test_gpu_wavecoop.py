@@ -65,8 +65,8 @@ def test_forced_wavecoop_small_d(wave_family, kernel_zoo, idx, dtype):
 @pytest.mark.parametrize("n,lw", [(1, 32), (2, 32), (31, 32), (32, 32), (33, 32), (2049, 32), (2200, 7), (4097, 1),
                                   (70000, 16)])
 def test_wavecoop_ragged_lengths_and_levels(wave_family, n, lw):
-    """Chunk / group / multi-group boundaries of the three-level scan (8..64 chunks per group, Kogge-Stone over the
-    group totals: 9 groups at n = 2049, 456 at n = 4097, 487 at n = 70000)."""
+    """Chunk / group / multi-group boundaries of the three-level scan (4..64 chunks per group, Kogge-Stone over the
+    group totals: 17 groups at n = 2049, 456 at n = 4097, 487 at n = 70000)."""
     from pssgp.kernels import Matern52
     wave_family.set_chunk(lw)
     t = make_times(n, seed=n % 97)
@@ -138,7 +138,7 @@ def test_reference_equivalence_suite_exact_kernels():
 
 def test_level3_kogge_stone_equals_serial_walk(monkeypatch):
     """Level 3 of the scan -- Kogge-Stone over the group totals -- against the single-wave serial walk it replaced
-    (PGPS_WC_SERIAL3=1, read when a context is created), at d = 18 (the CO2 kernel) with 188 groups."""
+    (PGPS_WC_SERIAL3=1, read when a context is created), at d = 18 (the CO2 kernel) with 375 groups."""
     from pssgp import _backend as B
     from pssgp.kernels import Matern32, Periodic, SquaredExponential
     k = Periodic(SquaredExponential(1., 1.), period=1., order=3) * Matern32(0.5, 5.) + Matern32(1., 2.)
@@ -153,7 +153,7 @@ def test_level3_kogge_stone_equals_serial_walk(monkeypatch):
     try:
         for ctx in (default, serial):
             monkeypatch.setitem(B._contexts, 0, ctx)
-            ctx.set_chunk(4)                                  # 1500 chunks, 8 per group
+            ctx.set_chunk(4)                                  # 1500 chunks, 4 per group
             res.append(_gpu_all(ssm, y, np.float64))
     finally:
         monkeypatch.setitem(B._contexts, 0, default)
