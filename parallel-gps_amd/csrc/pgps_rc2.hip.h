@@ -2,8 +2,8 @@
 // registers.
 //
 // A chain of time steps (one level-1 chunk) is owned by 32 lanes -- two 16-lane DPP rows -- and a wave carries two
-// chains.  Lane i of a chain holds ROW i of every DP x DP operand (DP registers; DP = 18, 24 or 32 pads the state
-// dimension), a distributed vector has element i in lane i.  All products are v_fmac_*_dpp with a `row_newbcast`
+// chains.  Lane i of a chain holds ROW i of every DP x DP operand (DP registers; DP is the state dimension itself
+// from 18 on -- one instantiation each, no padding -- and 18 for d = 17), a distributed vector has element i in lane i.  All products are v_fmac_*_dpp with a `row_newbcast`
 // operand, exactly the instruction of the row-cooperative family (pgps_rc.hip.h, d <= 16) -- the broadcast only
 // reaches the 16 lanes of a DPP row, so the operand that is broadcast is first SPLIT: `lo` holds rows 0..15 of it in
 // both DPP rows of the chain, `hi` rows 16..31 (one v_permlane16_swap per 32-bit half, gfx950).  Then

@@ -1,10 +1,10 @@
-// pgps_rc2_inst.hip -- one translation unit per padded state dimension of the two-rows level-1 kernels
-// (-DPGPS_RC2_DP=18|24|32): both scalar types, launched from pgps_wc.hip through launch_rc2_level1.
+// pgps_rc2_inst.hip -- one translation unit per state dimension (their own padding: none from d = 18 on) of the two-rows level-1 kernels
+// (-DPGPS_RC2_DP=18..32): both scalar types, launched from pgps_wc.hip through launch_rc2_level1.
 #include "pgps_internal.h"
 #include "pgps_rc2.hip.h"
 
 #ifndef PGPS_RC2_DP
-#error "compile with -DPGPS_RC2_DP=<18|24|32>"
+#error "compile with -DPGPS_RC2_DP=<18..32>"
 #endif
 
 namespace pgps {

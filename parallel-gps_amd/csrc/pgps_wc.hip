@@ -1715,12 +1715,23 @@ struct WcSeg {
 
 // level-1 kernels of the two-rows family (pgps_rc2.hip.h; pgps_rc2_inst.hip, one unit per padded dimension).
 // which: 0 reduce1, 1 apply1 (filter only), 2 apply1 (with the smoothing total), 3 smooth1
-int launch_rc2_18(pgps_ctx*, int which, const wc::WcArgs<double>&);
-int launch_rc2_18(pgps_ctx*, int which, const wc::WcArgs<float>&);
-int launch_rc2_24(pgps_ctx*, int which, const wc::WcArgs<double>&);
-int launch_rc2_24(pgps_ctx*, int which, const wc::WcArgs<float>&);
-int launch_rc2_32(pgps_ctx*, int which, const wc::WcArgs<double>&);
-int launch_rc2_32(pgps_ctx*, int which, const wc::WcArgs<float>&);
+// Their padding is their own: the state dimension itself from 18 on (no padding at all), 18 for d = 17.
+#define PGPS_RC2_DIMS(X) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+#define PGPS_RC2_DECL(DPV)                                                       \
+    int launch_rc2_##DPV(pgps_ctx*, int which, const wc::WcArgs<double>&);       \
+    int launch_rc2_##DPV(pgps_ctx*, int which, const wc::WcArgs<float>&);
+PGPS_RC2_DIMS(PGPS_RC2_DECL)
+#undef PGPS_RC2_DECL
+template <typename T>
+static int launch_rc2(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
+    switch (a.d < 18 ? 18 : a.d) {
+#define PGPS_RC2_CASE(DPV) \
+    case DPV: return launch_rc2_##DPV(ctx, which, a);
+        PGPS_RC2_DIMS(PGPS_RC2_CASE)
+#undef PGPS_RC2_CASE
+        default: return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
 
 template <typename T, int DP>
 static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const WcSeg<T>* sg = nullptr) {
@@ -1765,17 +1776,14 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
     attr_done = true;
     const dim3 blk(64), g1((unsigned)a.nchunk), g2((unsigned)a.ngroup);
     // Level 1 (which: 0 reduce, 1 apply filter only, 2 apply with the smoothing total, 3 smooth): the two-rows kernels for
-    // the paddings 18, 24, 32 -- every state dimension this family is chosen for -- unless PGPS_WC_ROWS2=0 (or a mask of `which` bits) asks for the
+    // d = 17..32 -- every state dimension this family is chosen for -- unless PGPS_WC_ROWS2=0 (or a mask of `which` bits) asks for the
     // LDS-tile kernels of this file (the cross-check of the tests, and d <= 16 when this family is forced)
     auto level1 = [&](int which) -> int {
-        if (DP >= 18 && ((ctx->wc_rows2 >> which) & 1)) {
+        if (DP >= 18 && a.d >= 17 && ((ctx->wc_rows2 >> which) & 1)) {
             if (which == 1 || which == 2)
                 timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_enter1<T, DP>, g1, blk, (unsigned)bytes(l_carry3), a);
             if (which == 3) timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_senter1<T, DP>, g1, blk, (unsigned)bytes(l_scarry3), a);
-            if constexpr (DP == 18) return launch_rc2_18(ctx, which, a);
-            else if constexpr (DP == 24) return launch_rc2_24(ctx, which, a);
-            else if constexpr (DP == 32) return launch_rc2_32(ctx, which, a);
-            else return PGPS_E_UNSUPPORTED_DIM;
+            return launch_rc2<T>(ctx, which, a);
         }
         switch (which) {
             case 0: timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_reduce1<T, DP>, g1, blk, (unsigned)bytes(l_reduce1), a); break;
@@ -1931,7 +1939,9 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     a.N = sa.N; a.d = d;
     // one wave per chunk: about a thousand chunks before the chunks grow to 64 steps; groups of 4..64 chunks so that the
     // Kogge-Stone levels over the group totals stay at one round of waves (<= 512 groups up to 2^21 steps)
-    long lw = ctx->chunk > 0 ? ctx->chunk : (sa.N + 1023) / 1024;
+    // (the two-rows level-1 kernels of d >= 17 carry two chunks per wave: twice the chunks for a wave on every SIMD)
+    const long waves = (d >= 17 && ctx->wc_rows2) ? 2048 : 1024;
+    long lw = ctx->chunk > 0 ? ctx->chunk : (sa.N + waves - 1) / waves;
     if (ctx->chunk <= 0) lw = lw < 16 ? 16 : (lw > 64 ? 64 : lw);
     a.Lw = (int)lw;
     a.nchunk = (sa.N + a.Lw - 1) / a.Lw;
