@@ -190,12 +190,12 @@ def dominant_symbol(slot, d, suf, family, segments, n_local):
         return rc_names[slot].format(t=t, d=d)
     if family == 2 or (family in (0, 3) and d > 6):
         if d > 16 and os.environ.get("PGPS_WC_ROWS2", "15") != "0":
-            # the two-rows level-1 kernels (csrc/pgps_rc2.hip.h) on the paddings 18 / 24 / 32; levels 2 and 3 stay wc_*
-            dp = 18 if d <= 18 else (24 if d <= 24 else 32)
-            return {"k_filter_reduce": f"pgps::rc2::rc2_reduce1<{t}, {dp}> + pgps::wc::wc_reduce2 + wc_ks_filter levels",
-                    "k_filter_apply": f"pgps::rc2::rc2_apply1<{t}, {dp}, ...> (+ pgps::wc::wc_enter1)",
-                    "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels",
-                    "k_smoother_apply": f"pgps::rc2::rc2_smooth1<{t}, {dp}> (+ pgps::wc::wc_senter1)"}[slot]
+            # the two-rows level-1 kernels (csrc/pgps_rc2.hip.h), one instantiation per d >= 18; levels 2 and 3 stay wc_*
+            dp = max(d, 18)
+            return {"k_filter_reduce": f"pgps::rc2::rc2_reduce1<{t}, {dp}> + pgps::wc::wc_reduce2 + wc_ks_filter levels + wc_enter1",
+                    "k_filter_apply": f"pgps::rc2::rc2_apply1<{t}, {dp}, ...>",
+                    "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels + wc_senter1",
+                    "k_smoother_apply": f"pgps::rc2::rc2_smooth1<{t}, {dp}, ...>"}[slot]
         return wc_names[slot]
     # lane-chunk kernels: whole-series calls run the 128-lane build (suffix _n) except d <= 3 from 2^22 steps
     narrow = not (d <= 3 and n_local >= (1 << 22))

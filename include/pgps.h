@@ -20,7 +20,8 @@
  *   - state dimension d: 1..PGPS_MAX_DIM_LANE use the lane-chunk kernels (one lane owns whole d x d operands), fp64
  *     series with 5 <= d <= 16 and fp32 series with 7 <= d <= 16 the row-cooperative ones (built natively in both
  *     precisions for 2 <= d <= 16), fp32 series at d = 8 -- and at d = 6 away from 2^19 .. 2^20 steps -- the
- *     quad-cooperative level-1 kernels under the row-cooperative driver, up to PGPS_MAX_DIM the wave-cooperative ones;
+ *     quad-cooperative level-1 kernels under the row-cooperative driver, up to PGPS_MAX_DIM the wave-cooperative ones
+ *     (from d = 17 on with the two-rows level-1 kernels: a chain on two DPP rows, the products in registers);
  *     pgps_set_family overrides.
  *     Every call takes every d <= PGPS_MAX_DIM, the segment calls (pgps_seg_*, pgps_pkfs_seg_*) included.
  *   - NaN in `ys` marks a missing observation (parallel.py:42,86-95).
@@ -45,7 +46,8 @@ extern "C" {
 #define PGPS_E_COMM (-7)            /* an RCCL call failed (pgps_last_hip_error carries RCCL's message) */
 
 #define PGPS_MAX_DIM_LANE 6   /* lane-chunk kernels: one lane holds whole d x d operands */
-#define PGPS_MAX_DIM 32       /* wave-cooperative kernels: operands in LDS, 64 lanes share each operation */
+#define PGPS_MAX_DIM 32       /* wave-cooperative kernels: operands in LDS, 64 lanes share each operation (levels 2, 3);
+                                 level 1 from d = 17: two-rows kernels, a row of every operand per lane */
 
 typedef struct pgps_ctx pgps_ctx;
 
@@ -100,7 +102,10 @@ int pgps_set_grad_pack(pgps_ctx* ctx, long max_steps);
  * workgroup (128 / 256), steps per lane, workgroups -- after pgps_set_block / pgps_set_chunk. */
 int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* steps_per_lane, int* workgroups);
 /* (Diagnostic, environment: PGPS_WC_SERIAL3=1 when a context is created makes the wave-cooperative family walk its
- * group totals with one wave instead of the Kogge-Stone scan -- the cross-check of tests/test_gpu_wavecoop.py.) */
+ * group totals with one wave instead of the Kogge-Stone scan -- the cross-check of tests/test_gpu_wavecoop.py.
+ * PGPS_WC_ROWS2=<mask> selects, per level-1 kernel of d >= 17, the two-rows kernels (bit set) or the LDS-tile kernels
+ * they replaced: 1 reduce, 2 Kalman pass without and 4 with the smoothing total, 8 smoother; default 15, 0 = the
+ * LDS-tile kernels throughout -- the cross-check of tests/test_gpu_tworows.py.) */
 /* LDS staging of the lane-chunk kernels: -1 = automatic, 0 = off (direct global accesses),
  * 2 or 4 = steps per lane per staged sub-tile (2: fp64 only).  Tuning / A-B knob. */
 int pgps_set_stage(pgps_ctx* ctx, int steps_per_subtile);

@@ -1780,9 +1780,11 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
     // LDS-tile kernels of this file (the cross-check of the tests, and d <= 16 when this family is forced)
     auto level1 = [&](int which) -> int {
         if (DP >= 18 && a.d >= 17 && ((ctx->wc_rows2 >> which) & 1)) {
+            // (the states entering the chunks close the scan: timed with its slots, so that the apply slots stay one
+            //  launch per pass -- the launch bench.py prices against the roofline)
             if (which == 1 || which == 2)
-                timed_launch(ctx, PGPS_K_FILTER_APPLY, wc_enter1<T, DP>, g1, blk, (unsigned)bytes(l_carry3), a);
-            if (which == 3) timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wc_senter1<T, DP>, g1, blk, (unsigned)bytes(l_scarry3), a);
+                timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_enter1<T, DP>, g1, blk, (unsigned)bytes(l_carry3), a);
+            if (which == 3) timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_senter1<T, DP>, g1, blk, (unsigned)bytes(l_scarry3), a);
             return launch_rc2<T>(ctx, which, a);
         }
         switch (which) {
