@@ -128,37 +128,162 @@ __device__ __forceinline__ void vec_l2g(int d, const T* L, T* g) {
     if (lane_id() < d) g[lane_id()] = L[lane_id()];
 }
 
-// C = op(A) op(B) (+ Add).  MODE 0: A B, 1: A B^T, 2: A^T B.  C must not alias A or B.  dk = d rounded up to 4.
+// ====================================================================================================
+// level 1 kernels keep a lane's tile of a matrix in registers wherever the next operation is tile-local
+// (Q, the predicted and the filtered covariance, the smoothing element's L, the elimination of the smoother gain):
+// LDS holds only what another lane reads -- the operands of a product and the transposed reads of a symmetrisation.
+// ====================================================================================================
+template <typename T, int DP>
+struct Tile {
+    static constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD;
+    T v[TS][TS];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = T(0);
+    }
+    __device__ __forceinline__ void ld(const T* M) {            // this lane's tile of an LDS matrix
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) { zero(); return; }
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = M[(r0 + ti) * LD + c0 + tj];
+    }
+    __device__ __forceinline__ void ld_t(const T* M) {          // ... of its transpose
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) { zero(); return; }
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = M[(c0 + tj) * LD + r0 + ti];
+    }
+    __device__ __forceinline__ void st(T* M) const {
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) return;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) M[(r0 + ti) * LD + c0 + tj] = v[ti][tj];
+    }
+    __device__ __forceinline__ void st_t(T* M) const {          // M = (this matrix)^T
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) return;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) M[(c0 + tj) * LD + r0 + ti] = v[ti][tj];
+    }
+    // compact global (d x d)
+    __device__ __forceinline__ void ld_g(int d, const T* g) {
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        const bool act = lactive<DP>();
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) {
+                const int i = r0 + ti, j = c0 + tj;
+                v[ti][tj] = (act && i < d && j < d) ? g[i * d + j] : T(0);
+            }
+    }
+    __device__ __forceinline__ void st_g(int d, T* g) const {
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) return;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) {
+                const int i = r0 + ti, j = c0 + tj;
+                if (i < d && j < d) g[i * d + j] = v[ti][tj];
+            }
+    }
+    __device__ __forceinline__ void st_g_t(int d, T* g) const {     // g = (this matrix)^T
+        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
+        if (!lactive<DP>()) return;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) {
+                const int i = r0 + ti, j = c0 + tj;
+                if (i < d && j < d) g[j * d + i] = v[ti][tj];
+            }
+    }
+    // this <- (this + t) / 2: with t the transposed read of the stored tile, the symmetric part
+    __device__ __forceinline__ void average(const Tile& t) {
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = T(0.5) * (v[ti][tj] + t.v[ti][tj]);
+    }
+};
+
+// t += op(A) op(B), the modes of mm.  For the paddings this family really serves (DP >= 18) the operands of the next
+// KU inner indices are requested before the multiply-adds of the current ones, with scheduling barriers in between:
+// left alone the compiler waits for every pair of indices in turn, and one wave per SIMD has nothing else to run
+// (tools/micro/wc_mm.hip: 2600 -> 1440 clocks per d = 18 product on an otherwise idle CU).
 template <typename T, int DP, int MODE>
-__device__ __forceinline__ void mm(int dk, const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
-                                   const T* __restrict__ Add = nullptr) {
-    constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD;
+__device__ __forceinline__ void mm_acc(int dk, const T* __restrict__ A, const T* __restrict__ B, Tile<T, DP>& t) {
+    constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD, KU = Geo<DP>::KU;
     const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
     if (!lactive<DP>()) return;
-    T acc[TS][TS];
+    auto load = [&](T (&av)[KU][TS], T (&bv)[KU][TS], int k0) {
 #pragma unroll
-    for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < TS; ++tj) acc[ti][tj] = Add ? Add[(r0 + ti) * LD + c0 + tj] : T(0);
-    for (int k0 = 0; k0 < dk; k0 += Geo<DP>::KU) {
-#pragma unroll
-        for (int kk = 0; kk < Geo<DP>::KU; ++kk) {
+        for (int kk = 0; kk < KU; ++kk) {
             const int k = k0 + kk;
-            T a[TS], b[TS];
 #pragma unroll
-            for (int ti = 0; ti < TS; ++ti) a[ti] = (MODE == 2) ? A[k * LD + r0 + ti] : A[(r0 + ti) * LD + k];
+            for (int ti = 0; ti < TS; ++ti) av[kk][ti] = (MODE == 2) ? A[k * LD + r0 + ti] : A[(r0 + ti) * LD + k];
 #pragma unroll
-            for (int tj = 0; tj < TS; ++tj) b[tj] = (MODE == 1) ? B[(c0 + tj) * LD + k] : B[k * LD + c0 + tj];
+            for (int tj = 0; tj < TS; ++tj) bv[kk][tj] = (MODE == 1) ? B[(c0 + tj) * LD + k] : B[k * LD + c0 + tj];
+        }
+    };
+    auto fma = [&](const T (&av)[KU][TS], const T (&bv)[KU][TS]) {
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk)
 #pragma unroll
             for (int ti = 0; ti < TS; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < TS; ++tj) acc[ti][tj] += a[ti] * b[tj];
+                for (int tj = 0; tj < TS; ++tj) t.v[ti][tj] += av[kk][ti] * bv[kk][tj];
+    };
+    if constexpr (DP % (2 * KU) == 0 && DP >= 18) {
+        // two buffers, two groups per trip; the inner length rounded up to whole trips stays inside the padded slot
+        const int dk2 = Geo<DP>::FIXK ? DP : (dk + 2 * KU - 1) / (2 * KU) * (2 * KU);
+        T a0[KU][TS], b0[KU][TS], a1[KU][TS], b1[KU][TS];
+        load(a0, b0, 0);
+        auto trip = [&](int k0) {
+            load(a1, b1, k0 + KU);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + 2 * KU < dk2) load(a0, b0, k0 + 2 * KU);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (Geo<DP>::FIXK) {
+#pragma unroll
+            for (int k0 = 0; k0 < DP; k0 += 2 * KU) trip(k0);
+        } else {
+            for (int k0 = 0; k0 < dk2; k0 += 2 * KU) trip(k0);
+        }
+    } else {
+        T av[KU][TS], bv[KU][TS];
+        for (int k0 = 0; k0 < dk; k0 += KU) {
+            load(av, bv, k0);
+            fma(av, bv);
         }
     }
-#pragma unroll
-    for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < TS; ++tj) C[(r0 + ti) * LD + c0 + tj] = acc[ti][tj];
+}
+
+// C = op(A) op(B) (+ Add).  MODE 0: A B, 1: A B^T, 2: A^T B.  C must not alias A or B.  dk = d rounded up to the unroll.
+template <typename T, int DP, int MODE>
+__device__ __forceinline__ void mm(int dk, const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
+                                   const T* __restrict__ Add = nullptr) {
+    Tile<T, DP> t;
+    if (Add) t.ld(Add);
+    else t.zero();
+    mm_acc<T, DP, MODE>(dk, A, B, t);
+    t.st(C);
 }
 
 // C = sym_part(C) in place (all reads precede all writes in program order; one wave = lockstep)
@@ -270,6 +395,110 @@ __device__ __forceinline__ void solve(int d, T* M, T* B) {
         }
         sync();
     }
+}
+
+// Gauss-Jordan with partial pivoting on register tiles: M X = B, X over B.  M: DP x DP slot (padding = identity rows), B:
+// DP x NRL (lane (lr, lc) owns TS rows x NRL / GR columns of it).  Per elimination step only column c and the pivot row
+// travel through LDS -- through the M slot itself, free once the tiles are loaded (its contents are NOT restored).  The
+// GR lanes that own column c each offer their best row among those that have not served yet, every lane reads the GR offers
+// and finds the same pivot; no rows are exchanged: the row that served column c is written back as row c of X.  Ends
+// synchronised.  (Until round 3 the whole of M and B went through LDS twice per step and the pivot search was a wave
+// reduction of shuffles: 70 of the 98 thousand clocks of a d = 18 combine.)
+template <typename T, int DP, int NRL>
+__device__ __forceinline__ void solve_piv(int d, T* M, T* B) {
+    constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD, GR = Geo<DP>::GR, TB = NRL / GR;
+    static_assert(DP <= 32, "the mask of used rows is one word");
+    static_assert(DP + 2 * GR + LD + NRL <= DP * LD, "column, offers and pivot row must fit the M slot");
+    const int lr = lrow<DP>(), lc = lcol<DP>();
+    const int r0 = lr * TS, c0 = lc * TS, b0 = lc * TB;
+    const bool act = lactive<DP>();
+    T tm[TS][TS], tb[TS][TB];
+    int slot[TS];                       // the column each of this lane's rows has served as pivot of; -1: none yet
+#pragma unroll
+    for (int ti = 0; ti < TS; ++ti) {
+        slot[ti] = -1;
+#pragma unroll
+        for (int tj = 0; tj < TS; ++tj) tm[ti][tj] = act ? M[(r0 + ti) * LD + c0 + tj] : T(0);
+#pragma unroll
+        for (int tj = 0; tj < TB; ++tj) tb[ti][tj] = act ? B[(r0 + ti) * NRL + b0 + tj] : T(0);
+    }
+    sync();
+    T* col = M;                         // DP values: column c
+    T* offer = M + DP;                  // GR pairs: (|entry|, row) of each owner's best row, -1 when it has none
+    T* prow = M + DP + 2 * GR;          // LD + NRL values: the pivot row of M, then of B
+    unsigned used = 0;
+    for (int cb = 0; cb < GR; ++cb) {
+#pragma unroll
+        for (int cs = 0; cs < TS; ++cs) {
+            const int c = cb * TS + cs;
+            if (c < d) {
+                if (act && lc == cb) {
+                    T best = T(-1);
+                    int row = r0;
+#pragma unroll
+                    for (int ti = 0; ti < TS; ++ti) {
+                        col[r0 + ti] = tm[ti][cs];
+                        const T v = fabs(tm[ti][cs]);
+                        const bool ok = r0 + ti < d && !((used >> (r0 + ti)) & 1u);
+                        if (ok && v > best) { best = v; row = r0 + ti; }
+                    }
+                    offer[2 * lr] = best;
+                    offer[2 * lr + 1] = T(row);
+                }
+                sync();
+                T best = T(-1);
+                int p = 0;
+#pragma unroll
+                for (int g = 0; g < GR; ++g) {          // ties: the lowest row (the offers come in row order)
+                    const T v = offer[2 * g];
+                    const int row = (int)offer[2 * g + 1];
+                    if (v > best) { best = v; p = row; }
+                }
+                used |= 1u << p;
+                T f[TS];
+#pragma unroll
+                for (int ti = 0; ti < TS; ++ti) f[ti] = col[act ? r0 + ti : 0];
+                if (act && lr == p / TS) {
+#pragma unroll
+                    for (int ti = 0; ti < TS; ++ti)
+                        if (r0 + ti == p) {
+#pragma unroll
+                            for (int tj = 0; tj < TS; ++tj) prow[c0 + tj] = tm[ti][tj];
+#pragma unroll
+                            for (int tj = 0; tj < TB; ++tj) prow[LD + b0 + tj] = tb[ti][tj];
+                        }
+                }
+                sync();
+                if (act) {
+                    const T inv = T(1) / prow[c];
+                    T pm[TS], pb[TB];
+#pragma unroll
+                    for (int tj = 0; tj < TS; ++tj) pm[tj] = prow[c0 + tj] * inv;
+#pragma unroll
+                    for (int tj = 0; tj < TB; ++tj) pb[tj] = prow[LD + b0 + tj] * inv;
+#pragma unroll
+                    for (int ti = 0; ti < TS; ++ti) {
+                        const bool piv = (r0 + ti == p);
+                        slot[ti] = piv ? c : slot[ti];
+#pragma unroll
+                        for (int tj = 0; tj < TS; ++tj) tm[ti][tj] = piv ? pm[tj] : tm[ti][tj] - f[ti] * pm[tj];
+#pragma unroll
+                        for (int tj = 0; tj < TB; ++tj) tb[ti][tj] = piv ? pb[tj] : tb[ti][tj] - f[ti] * pb[tj];
+                    }
+                }
+                sync();
+            }
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti) {
+            const int r = slot[ti] >= 0 ? slot[ti] : r0 + ti;       // (padding rows never serve: they stay where they are)
+#pragma unroll
+            for (int tj = 0; tj < TB; ++tj) B[r * NRL + b0 + tj] = tb[ti][tj];
+        }
+    }
+    sync();
 }
 
 // ---- element records --------------------------------------------------------------------------------
@@ -408,7 +637,7 @@ __device__ __forceinline__ void combine(int d, int dk, const T* r1, const T* r2,
         for (int q = 1; q < Geo<DP>::GR; ++q) rhs[i * NR + 2 * DP + q] = T(0);
     }
     sync();
-    solve<T, DP, NR, true>(d, M, rhs);      // rhs = [G | Nm | w]
+    solve_piv<T, DP, NR>(d, M, rhs);        // rhs = [G | Nm | w]
     // A = A2 G ; X = A2 Nm
     {
         const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
@@ -517,7 +746,7 @@ __device__ __forceinline__ void apply(int d, int dk, T* m, T* P, const T* r2, T*
         for (int q = 1; q < Geo<DP>::GR; ++q) rhs[i * NR + DP + q] = T(0);
     }
     sync();
-    solve<T, DP, NR, true>(d, M, rhs);      // rhs = [Nm | w]
+    solve_piv<T, DP, NR>(d, M, rhs);        // rhs = [Nm | w]
     for_tile<DP>([&](int i, int j) { M[i * LD + j] = rhs[i * NR + j]; });   // Nm as a regular matrix
     if (lane_id() < DP) {
         const int i = lane_id();
@@ -862,153 +1091,6 @@ __device__ __forceinline__ void gain(int d, const T* Pp, const T* FP, T* E, T* M
     solve<T, DP, NR, false>(d, M, rhs);     // rhs = Pp^-1 F P = E^T
     for_tile<DP>([&](int i, int j) { E[i * LD + j] = rhs[j * NR + i]; });
     sync();
-}
-
-// ====================================================================================================
-// level 1 kernels keep a lane's tile of a matrix in registers wherever the next operation is tile-local
-// (Q, the predicted and the filtered covariance, the smoothing element's L, the elimination of the smoother gain):
-// LDS holds only what another lane reads -- the operands of a product and the transposed reads of a symmetrisation.
-// ====================================================================================================
-template <typename T, int DP>
-struct Tile {
-    static constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD;
-    T v[TS][TS];
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = T(0);
-    }
-    __device__ __forceinline__ void ld(const T* M) {            // this lane's tile of an LDS matrix
-        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
-        if (!lactive<DP>()) { zero(); return; }
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = M[(r0 + ti) * LD + c0 + tj];
-    }
-    __device__ __forceinline__ void ld_t(const T* M) {          // ... of its transpose
-        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
-        if (!lactive<DP>()) { zero(); return; }
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = M[(c0 + tj) * LD + r0 + ti];
-    }
-    __device__ __forceinline__ void st(T* M) const {
-        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
-        if (!lactive<DP>()) return;
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) M[(r0 + ti) * LD + c0 + tj] = v[ti][tj];
-    }
-    __device__ __forceinline__ void st_t(T* M) const {          // M = (this matrix)^T
-        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
-        if (!lactive<DP>()) return;
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) M[(c0 + tj) * LD + r0 + ti] = v[ti][tj];
-    }
-    // compact global (d x d)
-    __device__ __forceinline__ void ld_g(int d, const T* g) {
-        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
-        const bool act = lactive<DP>();
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) {
-                const int i = r0 + ti, j = c0 + tj;
-                v[ti][tj] = (act && i < d && j < d) ? g[i * d + j] : T(0);
-            }
-    }
-    __device__ __forceinline__ void st_g(int d, T* g) const {
-        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
-        if (!lactive<DP>()) return;
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) {
-                const int i = r0 + ti, j = c0 + tj;
-                if (i < d && j < d) g[i * d + j] = v[ti][tj];
-            }
-    }
-    __device__ __forceinline__ void st_g_t(int d, T* g) const {     // g = (this matrix)^T
-        const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
-        if (!lactive<DP>()) return;
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) {
-                const int i = r0 + ti, j = c0 + tj;
-                if (i < d && j < d) g[j * d + i] = v[ti][tj];
-            }
-    }
-    // this <- (this + t) / 2: with t the transposed read of the stored tile, the symmetric part
-    __device__ __forceinline__ void average(const Tile& t) {
-#pragma unroll
-        for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) v[ti][tj] = T(0.5) * (v[ti][tj] + t.v[ti][tj]);
-    }
-};
-
-// t += op(A) op(B), the modes of mm.  For the paddings this family really serves (DP >= 18) the operands of the next
-// KU inner indices are requested before the multiply-adds of the current ones, with scheduling barriers in between:
-// left alone the compiler waits for every pair of indices in turn, and one wave per SIMD has nothing else to run
-// (tools/micro/wc_mm.hip: 2600 -> 1440 clocks per d = 18 product on an otherwise idle CU).
-template <typename T, int DP, int MODE>
-__device__ __forceinline__ void mm_acc(int dk, const T* __restrict__ A, const T* __restrict__ B, Tile<T, DP>& t) {
-    constexpr int TS = Geo<DP>::TS, LD = Geo<DP>::LD, KU = Geo<DP>::KU;
-    const int r0 = lrow<DP>() * TS, c0 = lcol<DP>() * TS;
-    if (!lactive<DP>()) return;
-    auto load = [&](T (&av)[KU][TS], T (&bv)[KU][TS], int k0) {
-#pragma unroll
-        for (int kk = 0; kk < KU; ++kk) {
-            const int k = k0 + kk;
-#pragma unroll
-            for (int ti = 0; ti < TS; ++ti) av[kk][ti] = (MODE == 2) ? A[k * LD + r0 + ti] : A[(r0 + ti) * LD + k];
-#pragma unroll
-            for (int tj = 0; tj < TS; ++tj) bv[kk][tj] = (MODE == 1) ? B[(c0 + tj) * LD + k] : B[k * LD + c0 + tj];
-        }
-    };
-    auto fma = [&](const T (&av)[KU][TS], const T (&bv)[KU][TS]) {
-#pragma unroll
-        for (int kk = 0; kk < KU; ++kk)
-#pragma unroll
-            for (int ti = 0; ti < TS; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < TS; ++tj) t.v[ti][tj] += av[kk][ti] * bv[kk][tj];
-    };
-    if constexpr (DP % (2 * KU) == 0 && DP >= 18) {
-        // two buffers, two groups per trip; the inner length rounded up to whole trips stays inside the padded slot
-        const int dk2 = Geo<DP>::FIXK ? DP : (dk + 2 * KU - 1) / (2 * KU) * (2 * KU);
-        T a0[KU][TS], b0[KU][TS], a1[KU][TS], b1[KU][TS];
-        load(a0, b0, 0);
-        auto trip = [&](int k0) {
-            load(a1, b1, k0 + KU);
-            __builtin_amdgcn_sched_barrier(0);
-            fma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (k0 + 2 * KU < dk2) load(a0, b0, k0 + 2 * KU);
-            __builtin_amdgcn_sched_barrier(0);
-            fma(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if constexpr (Geo<DP>::FIXK) {
-#pragma unroll
-            for (int k0 = 0; k0 < DP; k0 += 2 * KU) trip(k0);
-        } else {
-            for (int k0 = 0; k0 < dk2; k0 += 2 * KU) trip(k0);
-        }
-    } else {
-        T av[KU][TS], bv[KU][TS];
-        for (int k0 = 0; k0 < dk; k0 += KU) {
-            load(av, bv, k0);
-            fma(av, bv);
-        }
-    }
 }
 
 // Gauss-Jordan without pivoting on register tiles: tb <- tm^-1 tb for a symmetric positive definite tm (destroyed).
