@@ -588,5 +588,189 @@ __global__ __launch_bounds__(64) void rc2_smooth1(const WcArgs<T> a) {
     }
 }
 
+
+// ====================================================================================================
+// level 3: one Kogge-Stone level over the group totals, out[e] = in[e - stride] (x) in[e] (wc_ks_filter), two elements per
+// wave.  filt_combine (pgps_math.h; the reference's filtering operator, pssgp/kalman/parallel.py:55-76) in row layout:
+//   M = I + C1 J2;  M [G | Nm | w] = [A1 | C1 | b1 + C1 eta2]  (Gauss-Jordan with partial pivoting: the pivot of column c is
+//   the largest entry among the rows that have not served -- a chain maximum and a ballot -- and no rows are exchanged: the
+//   rows are put in order through LDS at the end);  A = A2 G,  b = A2 w + b2,  C = sym(A2 Nm A2^T + C2),
+//   J = sym(G^T J2 A1 + J1),  eta = G^T (eta2 - J2 b1) + eta1.
+// An element below the stride is copied: combined with the identity element, which is exact.  Operands are loaded when they
+// are needed and results stored as soon as they are complete (in and out are different buffers): six matrices of an element
+// pair do not fit the registers beside the elimination.
+// ====================================================================================================
+// maximum over the chain (every lane gets it): a butterfly of DPP moves inside the 16-lane rows -- lane ^ 1, lane ^ 2, then
+// the mirrors of 8 and of 16 lanes, which act as ^ 4 and ^ 8 on what the earlier steps made uniform -- and the other row of
+// the chain through the split.  (Five ds_bpermute round trips before: the pivot search of every elimination step.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+template <typename T>
+__device__ __forceinline__ T chain_max(T v) {
+    v = fmax(v, dpp_mov<0xB1>(v));      // quad_perm [1, 0, 3, 2]
+    v = fmax(v, dpp_mov<0x4E>(v));      // quad_perm [2, 3, 0, 1]
+    v = fmax(v, dpp_mov<0x141>(v));     // row_half_mirror
+    v = fmax(v, dpp_mov<0x140>(v));     // row_mirror
+    T lo, hi;
+    split(v, lo, hi);
+    return fmax(lo, hi);
+}
+
+template <typename T, int DP, bool FULL>
+struct KsSolve {
+    using O = Ops<T, DP>;
+    static constexpr int NR = 2 * DP + 1;
+    // M X = R in row layout with partial pivoting; on return row i of R holds the row of X whose index is `served`,
+    // divided through already.  rb: DP + NR values of the chain's LDS.
+    template <int C = 0>
+    static __device__ __forceinline__ void run(int d, T* M, T* R, unsigned& used, T& diag, int& served, T* rb, int i, int ch) {
+        if constexpr (C < DP) {
+            if (C < d) {
+                const bool cand = i < d && !((used >> i) & 1u);
+                const T v = cand ? fabs(M[C]) : T(-1);
+                const T mx = chain_max(v);
+                const unsigned long long bal = __ballot(cand && v == mx);
+                const unsigned half = ch ? (unsigned)(bal >> 32) : (unsigned)bal;
+                const int p = half ? __builtin_ctz(half) : 0;
+                used |= 1u << p;
+                if (i == p) {
+#pragma unroll
+                    for (int j = C; j < DP; ++j) rb[j] = M[j];
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) rb[DP + q] = R[q];
+                    served = C;
+                    diag = M[C];
+                }
+                wsync();
+                const T inv = rcp_nr(rb[C]);
+                const T fs = (i == p) ? T(0) : M[C] * inv;
+#pragma unroll
+                for (int j = C + 1; j < DP; ++j) M[j] = __builtin_fma(-fs, rb[j], M[j]);
+#pragma unroll
+                for (int q = 0; q < NR; ++q) R[q] = __builtin_fma(-fs, rb[DP + q], R[q]);
+                wsync();
+                run<C + 1>(d, M, R, used, diag, served, rb, i, ch);
+            }
+        }
+    }
+};
+
+template <typename T, int DP, bool FULL>
+__global__ __launch_bounds__(64) void rc2_ks_filter(const WcArgs<T> a) {
+    using O = Ops<T, DP>;
+    constexpr int NR = 2 * DP + 1;
+    constexpr int PLD = NR + 1;                     // leading dimension of the row-ordering buffer
+    __shared__ T tl_all[2 * O::TLN];
+    __shared__ T rb_all[2 * (DP + NR)];
+    __shared__ T pm_all[2 * DP * PLD];
+    const int lane = threadIdx.x, ch = lane >> 5, i = lane & 31;
+    T* tl = tl_all + ch * O::TLN;
+    T* rb = rb_all + ch * (DP + NR);
+    T* pm = pm_all + ch * DP * PLD;
+    const int d = a.d;
+    const long dd = (long)d * d;
+    const int nf = nfilt(d);
+    const long e_raw = (long)blockIdx.x * 2 + ch;
+    const bool valid = e_raw < a.ks_n;
+    const long e = valid ? e_raw : a.ks_n - 1;
+    const bool comb = e >= a.ks_stride;             // below the stride: the element itself (combined with the identity)
+    const T* g1 = a.ks_in + (comb ? e - a.ks_stride : e) * nf;
+    const T* g2 = a.ks_in + e * nf;
+    T* go = a.ks_out + e * nf;
+    const bool row = i < d;
+    const int ic = row ? i : 0;
+    const T b1 = (comb && row) ? g1[3 * dd + ic] : T(0);
+    const T eta1 = (comb && row) ? g1[3 * dd + d + ic] : T(0);
+    const T b2 = row ? g2[3 * dd + ic] : T(0);
+    const T eta2 = row ? g2[3 * dd + d + ic] : T(0);
+    T G[DP], Nm[DP], w;
+    {   // M = I + C1 J2, right-hand sides [A1 | C1 | b1 + C1 eta2], elimination, rows back in order
+        T M[DP], R[NR];
+        {
+            T C1[DP], J2[DP], lo[DP], hi[DP];
+            O::template ld_row<FULL>(g1 + dd, d, i, C1);
+            O::template ld_row<FULL>(g2 + 2 * dd, d, i, J2);
+#pragma unroll
+            for (int j = 0; j < DP; ++j) C1[j] = comb ? C1[j] : T(0);
+            O::split_mat(J2, lo, hi);
+#pragma unroll
+            for (int j = 0; j < DP; ++j) M[j] = (j == i) ? T(1) : T(0);
+            O::mm0(M, C1, lo, hi);
+            T A1[DP];
+            O::template ld_row<FULL>(g1, d, i, A1);
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+                R[j] = comb ? A1[j] : ((j == i && row) ? T(1) : T(0));
+                R[DP + j] = C1[j];
+            }
+            R[2 * DP] = b1 + O::mv(C1, eta2);
+        }
+        unsigned used = 0;
+        T diag = T(1);
+        int served = i;
+        KsSolve<T, DP, FULL>::run(d, M, R, used, diag, served, rb, i, ch);
+        const T dinv = rcp_nr(diag);
+        if (i < DP) {
+            const int r = (i < d) ? served : i;     // (rows beyond d never serve: they stay where they are)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) pm[r * PLD + q] = R[q] * dinv;
+        }
+        wsync();
+        const int ii = i < DP ? i : 0;
+#pragma unroll
+        for (int j = 0; j < DP; ++j) { G[j] = pm[ii * PLD + j]; Nm[j] = pm[ii * PLD + DP + j]; }
+        w = pm[ii * PLD + 2 * DP];
+        wsync();
+    }
+    {   // A = A2 G, b = A2 w + b2, C = sym(A2 Nm A2^T + C2)
+        T A2[DP], lo[DP], hi[DP], Ao[DP], X[DP], Co[DP];
+        O::template ld_row<FULL>(g2, d, i, A2);
+        O::split_mat(G, lo, hi);
+        O::zero(Ao);
+        O::mm0(Ao, A2, lo, hi);
+        O::template st_row<FULL>(go, d, i, valid, Ao);
+        O::split_mat(Nm, lo, hi);
+        O::zero(X);
+        O::mm0(X, A2, lo, hi);
+        const T bo = O::mv(A2, w) + b2;
+        if (valid && row) go[3 * dd + i] = bo;
+        O::template ld_row<FULL>(g2 + dd, d, i, Co);
+        O::split_mat(A2, lo, hi);
+        O::mm1(Co, X, lo, hi);
+        O::symmetrise(Co, tl, i);
+        O::template st_row<FULL>(go + dd, d, i, valid, Co);
+    }
+    {   // J = sym(G^T J2 A1 + J1), eta = G^T (eta2 - J2 b1) + eta1
+        T J2[DP], A1[DP], lo[DP], hi[DP], M2[DP], Gt[DP], Jo[DP];
+        O::template ld_row<FULL>(g2 + 2 * dd, d, i, J2);
+        O::template ld_row<FULL>(g1, d, i, A1);
+#pragma unroll
+        for (int j = 0; j < DP; ++j) A1[j] = comb ? A1[j] : ((j == i && row) ? T(1) : T(0));
+        const T z = eta2 - O::mv(J2, b1);
+        O::split_mat(A1, lo, hi);
+        O::zero(M2);
+        O::mm0(M2, J2, lo, hi);
+        O::transpose(G, Gt, tl, i);
+        O::template ld_row<FULL>(g1 + 2 * dd, d, i, Jo);
+#pragma unroll
+        for (int j = 0; j < DP; ++j) Jo[j] = comb ? Jo[j] : T(0);
+        O::split_mat(M2, lo, hi);
+        O::mm0(Jo, Gt, lo, hi);
+        O::symmetrise(Jo, tl, i);
+        O::template st_row<FULL>(go + 2 * dd, d, i, valid, Jo);
+        const T eo = O::mv(Gt, z) + eta1;
+        if (valid && row) go[3 * dd + d + i] = eo;
+    }
+}
+
 }  // namespace rc2
 }  // namespace pgps

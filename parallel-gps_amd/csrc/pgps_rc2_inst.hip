@@ -13,7 +13,7 @@ namespace pgps {
 #define PGPS_RC2_CAT(a, b) PGPS_RC2_CAT2(a, b)
 #define PGPS_RC2_LAUNCH PGPS_RC2_CAT(launch_rc2_, PGPS_RC2_DP)
 
-// which: 0 reduce1, 1 apply1 (filter only), 2 apply1 (with the smoothing total), 3 smooth1
+// which: 0 reduce1, 1 apply1 (filter only), 2 apply1 (with the smoothing total), 3 smooth1, 4 one level of the filter scan
 template <typename T>
 static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
     constexpr int DP = PGPS_RC2_DP;
@@ -29,6 +29,12 @@ static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
         case 1: PGPS_RC2_GO(PGPS_K_FILTER_APPLY, rc2_apply1<T, DP, false); break;
         case 2: PGPS_RC2_GO(PGPS_K_FILTER_APPLY, rc2_apply1<T, DP, true); break;
         case 3: PGPS_RC2_GO(PGPS_K_SMOOTHER_APPLY, rc2_smooth1<T, DP); break;
+        case 4: {       // one Kogge-Stone level over the group totals (a.ks_*)
+            const dim3 gk((unsigned)((a.ks_n + 1) / 2));
+            if (full) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_ks_filter<T, DP, true>, gk, blk, 0u, a);
+            else timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_ks_filter<T, DP, false>, gk, blk, 0u, a);
+            break;
+        }
         default: return PGPS_E_INVALID;
     }
 #undef PGPS_RC2_GO

@@ -1877,6 +1877,18 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
         }
         return PGPS_OK;
     };
+    // one Kogge-Stone level over the group totals: the two-rows combine kernel (two elements per wave, elimination in
+    // registers) wherever the two-rows level-1 kernels run; PGPS_WC_KS2=0 (diagnostic, read once) keeps the LDS-tile one
+    static const bool ks2_env = [] { const char* e = std::getenv("PGPS_WC_KS2"); return !(e && e[0] == '0'); }();
+    auto ks_filter_level = [&](long stride, const T* cur, T* nxt) -> int {
+        if (DP >= 18 && a.d >= 17 && (ctx->wc_rows2 & 1) && ks2_env) {
+            a.ks_n = a.ngroup; a.ks_stride = stride; a.ks_in = cur; a.ks_out = nxt;
+            return launch_rc2<T>(ctx, 4, a);
+        }
+        timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_ks_filter<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a.d, (long)a.ngroup,
+                     stride, cur, nxt);
+        return PGPS_OK;
+    };
 #define WC_LEVEL1(which)                 \
     do {                                 \
         const int r1_ = level1(which);   \
@@ -1901,8 +1913,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
             const T* cur = a.agg2;
             T* nxt = a.ksA;
             for (long stride = 1; stride < a.ngroup; stride <<= 1) {
-                timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_ks_filter<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a.d,
-                             (long)a.ngroup, stride, cur, nxt);
+                { const int rk_ = ks_filter_level(stride, cur, nxt); if (rk_) return rk_; }
                 cur = nxt;
                 nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
             }
@@ -1974,8 +1985,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
         const T* cur = a.agg2;
         T* nxt = a.ksA;
         for (long stride = 1; stride < a.ngroup; stride <<= 1) {
-            timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_ks_filter<T, DP>, g2, blk, (unsigned)bytes(l_reduce2), a.d,
-                         (long)a.ngroup, stride, cur, nxt);
+            { const int rk_ = ks_filter_level(stride, cur, nxt); if (rk_) return rk_; }
             cur = nxt;
             nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
         }

@@ -35,6 +35,9 @@ struct WcArgs {
     T* sagg2;               // (ngroup, nsmth)
     T* scarry2;             // (ngroup, d + d^2) smoothed (m, P) of the first step after each group
     double* llpart;         // (nchunk,)
+    long ks_n, ks_stride;   // one Kogge-Stone level of the two-rows scan kernels: out[e] = in[e - stride] (x) in[e], e < n
+    const T* ks_in;
+    T* ks_out;
     T* enter1;              // (nchunk, d + d^2) filtered (m, P) entering each chunk      (two-rows level-1 kernels)
     T* senter1;             // (nchunk, d + d^2) smoothed (m, P) of the first step after each chunk
     T *ksA, *ksB;           // (ngroup, nfilt) each: Kogge-Stone ping-pong over the group totals (both scans)
