@@ -192,7 +192,7 @@ def dominant_symbol(slot, d, suf, family, segments, n_local):
         if d > 16 and os.environ.get("PGPS_WC_ROWS2", "15") != "0":
             # the two-rows level-1 kernels (csrc/pgps_rc2.hip.h), one instantiation per d >= 18; levels 2 and 3 stay wc_*
             dp = max(d, 18)
-            return {"k_filter_reduce": f"pgps::rc2::rc2_reduce1<{t}, {dp}> + pgps::wc::wc_reduce2 + wc_ks_filter levels + wc_enter1",
+            return {"k_filter_reduce": f"pgps::rc2::rc2_reduce1<{t}, {dp}> + pgps::wc::wc_reduce2 + rc2_ks_filter levels + wc_enter1",
                     "k_filter_apply": f"pgps::rc2::rc2_apply1<{t}, {dp}, ...>",
                     "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels + wc_senter1",
                     "k_smoother_apply": f"pgps::rc2::rc2_smooth1<{t}, {dp}, ...>"}[slot]

@@ -105,7 +105,8 @@ int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* steps_per_l
  * group totals with one wave instead of the Kogge-Stone scan -- the cross-check of tests/test_gpu_wavecoop.py.
  * PGPS_WC_ROWS2=<mask> selects, per level-1 kernel of d >= 17, the two-rows kernels (bit set) or the LDS-tile kernels
  * they replaced: 1 reduce, 2 Kalman pass without and 4 with the smoothing total, 8 smoother; default 15, 0 = the
- * LDS-tile kernels throughout -- the cross-check of tests/test_gpu_tworows.py.) */
+ * LDS-tile kernels throughout -- the cross-check of tests/test_gpu_tworows.py.  The Kogge-Stone levels of the filter scan
+ * follow bit 1; PGPS_WC_KS2=0 keeps the LDS-tile level on its own.) */
 /* LDS staging of the lane-chunk kernels: -1 = automatic, 0 = off (direct global accesses),
  * 2 or 4 = steps per lane per staged sub-tile (2: fp64 only).  Tuning / A-B knob. */
 int pgps_set_stage(pgps_ctx* ctx, int steps_per_subtile);
