@@ -772,5 +772,44 @@ __global__ __launch_bounds__(64) void rc2_ks_filter(const WcArgs<T> a) {
     }
 }
 
+// one Kogge-Stone level of the smoother's suffix scan: out[e] = in[e] (x) in[e + stride] (wc_ks_smoother), two elements per
+// wave; beyond the end: combined with the identity element (exact)
+template <typename T, int DP, bool FULL>
+__global__ __launch_bounds__(64) void rc2_ks_smoother(const WcArgs<T> a) {
+    using O = Ops<T, DP>;
+    __shared__ T tl_all[2 * O::TLN];
+    const int lane = threadIdx.x, ch = lane >> 5, i = lane & 31;
+    T* tl = tl_all + ch * O::TLN;
+    const int d = a.d;
+    const long dd = (long)d * d;
+    const int ns = nsmth(d);
+    const long e_raw = (long)blockIdx.x * 2 + ch;
+    const bool valid = e_raw < a.ks_n;
+    const long e = valid ? e_raw : a.ks_n - 1;
+    const bool comb = e + a.ks_stride < a.ks_n;
+    const T* ga = a.ks_in + e * ns;
+    const T* gb = a.ks_in + (comb ? e + a.ks_stride : e) * ns;
+    T* go = a.ks_out + e * ns;
+    const bool row = i < d;
+    const int ic = row ? i : 0;
+    SmthAcc<T, DP> s;
+    O::template ld_row<FULL>(ga, d, i, s.E);
+    O::template ld_row<FULL>(ga + dd, d, i, s.L);
+    s.g = row ? ga[2 * dd + ic] : T(0);
+    T eE[DP], eL[DP];
+    O::template ld_row<FULL>(gb, d, i, eE);
+    O::template ld_row<FULL>(gb + dd, d, i, eL);
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+        eE[j] = comb ? eE[j] : ((j == i && row) ? T(1) : T(0));
+        eL[j] = comb ? eL[j] : T(0);
+    }
+    const T eg = (comb && row) ? gb[2 * dd + ic] : T(0);
+    scombine<T, DP>(s, eE, eL, eg, true, tl, i);
+    O::template st_row<FULL>(go, d, i, valid, s.E);
+    O::template st_row<FULL>(go + dd, d, i, valid, s.L);
+    if (valid && row) go[2 * dd + i] = s.g;
+}
+
 }  // namespace rc2
 }  // namespace pgps

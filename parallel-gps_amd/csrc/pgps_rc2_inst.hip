@@ -13,7 +13,7 @@ namespace pgps {
 #define PGPS_RC2_CAT(a, b) PGPS_RC2_CAT2(a, b)
 #define PGPS_RC2_LAUNCH PGPS_RC2_CAT(launch_rc2_, PGPS_RC2_DP)
 
-// which: 0 reduce1, 1 apply1 (filter only), 2 apply1 (with the smoothing total), 3 smooth1, 4 one level of the filter scan
+// which: 0 reduce1, 1 apply1 (filter only), 2 apply1 (with the smoothing total), 3 smooth1, 4 / 5 one level of the filter / smoother scan
 template <typename T>
 static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
     constexpr int DP = PGPS_RC2_DP;
@@ -33,6 +33,12 @@ static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
             const dim3 gk((unsigned)((a.ks_n + 1) / 2));
             if (full) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_ks_filter<T, DP, true>, gk, blk, 0u, a);
             else timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_ks_filter<T, DP, false>, gk, blk, 0u, a);
+            break;
+        }
+        case 5: {       // ... of the smoother's suffix scan
+            const dim3 gk((unsigned)((a.ks_n + 1) / 2));
+            if (full) timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc2::rc2_ks_smoother<T, DP, true>, gk, blk, 0u, a);
+            else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc2::rc2_ks_smoother<T, DP, false>, gk, blk, 0u, a);
             break;
         }
         default: return PGPS_E_INVALID;

@@ -1889,6 +1889,15 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
                      stride, cur, nxt);
         return PGPS_OK;
     };
+    auto ks_smoother_level = [&](long stride, const T* cur, T* nxt) -> int {
+        if (DP >= 18 && a.d >= 17 && (ctx->wc_rows2 & 8) && ks2_env) {
+            a.ks_n = a.ngroup; a.ks_stride = stride; a.ks_in = cur; a.ks_out = nxt;
+            return launch_rc2<T>(ctx, 5, a);
+        }
+        timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_ks_smoother<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a.d, (long)a.ngroup,
+                     stride, cur, nxt);
+        return PGPS_OK;
+    };
 #define WC_LEVEL1(which)                 \
     do {                                 \
         const int r1_ = level1(which);   \
@@ -1943,8 +1952,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
             const T* cur = a.sagg2;
             T* nxt = a.ksA;
             for (long stride = 1; stride < a.ngroup; stride <<= 1) {
-                timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_ks_smoother<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a.d,
-                             (long)a.ngroup, stride, cur, nxt);
+                { const int rk_ = ks_smoother_level(stride, cur, nxt); if (rk_) return rk_; }
                 cur = nxt;
                 nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
             }
@@ -2000,8 +2008,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
             const T* cur = a.sagg2;
             T* nxt = a.ksA;
             for (long stride = 1; stride < a.ngroup; stride <<= 1) {
-                timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_ks_smoother<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a.d,
-                             (long)a.ngroup, stride, cur, nxt);
+                { const int rk_ = ks_smoother_level(stride, cur, nxt); if (rk_) return rk_; }
                 cur = nxt;
                 nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
             }
