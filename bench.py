@@ -194,7 +194,7 @@ def dominant_symbol(slot, d, suf, family, segments, n_local):
             dp = max(d, 18)
             return {"k_filter_reduce": f"pgps::rc2::rc2_reduce1<{t}, {dp}> + pgps::wc::wc_reduce2 + rc2_ks_filter levels + wc_enter1",
                     "k_filter_apply": f"pgps::rc2::rc2_apply1<{t}, {dp}, ...>",
-                    "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels + wc_senter1",
+                    "k_smoother_reduce": "pgps::wc::wc_sreduce2 + rc2_ks_smoother levels + wc_senter1",
                     "k_smoother_apply": f"pgps::rc2::rc2_smooth1<{t}, {dp}, ...>"}[slot]
         return wc_names[slot]
     # lane-chunk kernels: whole-series calls run the 128-lane build (suffix _n) except d <= 3 from 2^22 steps
