@@ -425,6 +425,29 @@ int pgps_series_lti_predict_f64(pgps_series* s, int d, const double* F, const do
                                 double* mean /* K */, double* var /* K */, double* ll /* or NULL */);
 int pgps_series_lti_ll_batch_f64(pgps_series* s, int B, int d, const double* models, double* ll /* B */);
 
+/* ---- log-likelihood AND its gradient for any kernel's LTI model, in two passes (round 4) ---------------------------
+ * What the reference obtains from tf.GradientTape over maximum_log_likelihood_objective (tests/test_gp_vs_kfs.py:53-78;
+ * pssgp/model.py:113-117 through pssgp/kalman/parallel.py:121-152 and pssgp/kernels/base.py:29-47), consumed by its
+ * L-BFGS and HMC drivers (pssgp/experiments/sunspot/map.py:74-82, experiments/common.py:95-133): one filter pass and
+ * one reverse (adjoint) pass return the adjoints of the MODEL, whatever the number of hyper-parameters:
+ *   out[0]                    ll
+ *   out[1 .. d d]             Abar (d, d) row-major = sum_k dt_k Fbar_k F_k^T : d ll / d theta gets <Abar, dF> for every
+ *                             dF = dF/dtheta that commutes with F (d expm(dt F) = dt dF expm(dt F); true of every
+ *                             hyper-parameter of every kernel of the reference in a frozen state basis -- time scalings of
+ *                             block / Kronecker factors: pssgp/kernels/sde_grads.py)
+ *   out[1 + d d ..]           Ubar (d):  d ll / d Pinf = sym(Ubar H), i.e. + Ubar^T dPinf H^T
+ *   out[1 + d d + d ..]       Hbar (d):  + Hbar . dH
+ *   out[1 + d d + 2 d]        Rbar    :  + Rbar dR
+ * (1 + d d + 2 d + 1 doubles).  F, Pinf (stationary: F Pinf + Pinf F^T + L Q L^T = 0), H from HOST memory; ts, ys host
+ * pointers for the plain entry point, device pointers for _dev (out device too: asynchronous on the context's stream);
+ * the series entry point leaves `out` on the host.  fp64, 2 <= d <= PGPS_MAX_DIM. */
+int pgps_lti_ll_grad_f64(pgps_ctx*, long N, int d, const double* F, const double* Pinf, const double* H, double R,
+                         const double* ts, const double* ys, double t0, double* out);
+int pgps_lti_ll_grad_dev_f64(pgps_ctx*, long N, int d, const double* F, const double* Pinf, const double* H, double R,
+                             const double* ts, const double* ys, double t0, double* out);
+int pgps_series_lti_ll_grad_f64(pgps_series* s, int d, const double* F, const double* Pinf, const double* H, double R,
+                                double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@
 #include <new>
 
 #include "pgps_internal.h"
+#include "pgps_gradlti.h"
 
 using namespace pgps;
 
@@ -1674,6 +1675,53 @@ extern "C" int pgps_series_lti_ll_batch_f64(pgps_series* s, int B, int d, const 
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(ll, s->host, (size_t)B * sizeof(double));
     return PGPS_OK;
+}
+
+// log-likelihood and the model's adjoints (pgps_gradlti.h): [ll | Abar | Ubar | Hbar | Rbar]
+static int lti_grad_dev(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* H, double R,
+                        const double* ts, const double* ys, double t0, double* out) {
+    if (!ctx || N < 1 || !F || !Pinf || !H || !ts || !ys || !out) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double* model;
+    TRY(lti_model_in(ctx, d, F, Pinf, H, &model));
+    return launch_ll_grad_lti(ctx, N, d, model, R, ts, t0, ys, out);
+}
+extern "C" int pgps_lti_ll_grad_dev_f64(pgps_ctx* c, long N, int d, const double* F, const double* Pinf, const double* H,
+                                        double R, const double* ts, const double* ys, double t0, double* out) {
+    return lti_grad_dev(c, N, d, F, Pinf, H, R, ts, ys, t0, out);
+}
+extern "C" int pgps_lti_ll_grad_f64(pgps_ctx* ctx, long N, int d, const double* F, const double* Pinf, const double* H,
+                                    double R, const double* ts, const double* ys, double t0, double* out) {
+    if (!ctx || N < 1 || !ts || !ys || !out) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nout = 1 + (size_t)grad_lti_nstat(d);
+    double *dts, *dys, *dout;
+    TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
+    TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));
+    TRY(stage_in<double>(ctx, ctx->st[9], nullptr, nout, &dout));
+    TRY(lti_grad_dev(ctx, N, d, F, Pinf, H, R, dts, dys, t0, dout));
+    TRY(stage_out(ctx, out, dout, nout));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return std::isfinite(out[0]) ? PGPS_OK : PGPS_E_NUMERIC;
+}
+extern "C" int pgps_series_lti_ll_grad_f64(pgps_series* s, int d, const double* F, const double* Pinf, const double* H, double R,
+                                           double* out) {
+    if (!s || !out || !F || !Pinf || !H) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > PGPS_MAX_DIM) return PGPS_E_UNSUPPORTED_DIM;
+    pgps_ctx* ctx = s->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nout = 1 + (size_t)grad_lti_nstat(d);
+    TRY(series_host(s, std::max<size_t>(nout, s->host_cap)));
+    double* dout;
+    if (s->zero_copy) dout = s->hdev;
+    else TRY(stage_in<double>(ctx, ctx->st[9], nullptr, nout, &dout));
+    TRY(lti_grad_dev(ctx, s->N, d, F, Pinf, H, R, s->ts, s->ys, s->t0, dout));
+    if (!s->zero_copy) HIPCHK(ctx, hipMemcpyAsync(s->host, dout, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, s->host, nout * sizeof(double));
+    return std::isfinite(out[0]) ? PGPS_OK : PGPS_E_NUMERIC;
 }
 
 extern "C" int pgps_lti_ll_f64(pgps_ctx* c, long N, int d, const double* F, const double* Pinf, const double* H, double R,

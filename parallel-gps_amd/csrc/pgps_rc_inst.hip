@@ -2,6 +2,9 @@
 // dimension (-DPGPS_RC_T=double|float -DPGPS_RC_D=d, d = 2..16), so the fully unrolled units compile in parallel.
 // The discretisation kernel computes in fp64 whatever the series' type: it lives in the double units only.
 #include "pgps_rc.hip.h"
+#ifndef PGPS_RC_NO_DISC
+#include "pgps_rcgrad.hip.h"
+#endif
 
 #ifndef PGPS_RC_T
 #define PGPS_RC_T double
@@ -15,6 +18,7 @@ template int launch_rc_scan_blocked<PGPS_RC_T, PGPS_RC_D>(pgps_ctx*, int, long, 
 template int launch_rc_seg_carry<PGPS_RC_T, PGPS_RC_D>(pgps_ctx*, int, const PGPS_RC_T*, int, int, int, PGPS_RC_T*);
 #ifndef PGPS_RC_NO_DISC
 template int launch_rc_disc<PGPS_RC_D>(pgps_ctx*, long, const double*, const double*, const double*, double, double*, double*, int, long);
+template int launch_rc_grad<PGPS_RC_D>(pgps_ctx*, const GradLtiArgs&, int);
 #endif
 }  // namespace rc
 }  // namespace pgps

@@ -31,6 +31,7 @@
 #include "pgps_internal.h"
 #include "pgps_math.h"
 #include "pgps_wc_args.h"
+#include "pgps_gradlti.h"
 
 namespace pgps {
 namespace wc {
@@ -2504,6 +2505,78 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode, int
         return rc::scan_rc_seg(ctx, d, a, mode, aggA, aggB, sagA, sagB, sg, sa.ll);
     }
     return rc::scan_rc(ctx, d, a, mode, aggA, aggB, sagA, sagB, sa.ll);
+}
+
+// ====================================================================================================
+// Log-likelihood and the model's adjoints (pgps_gradlti.h): discretise -> rc_reduce1 -> scan of the filter totals ->
+// forward pass with the adjoint elements folded (rc_gapply1) -> suffix scan of the adjoint totals (the smoother's scan
+// kernels: the reverse sweep composes under the smoothing operator) -> backward pass (rc_gback1) -> finalize.
+// Everything is enqueued on the context's stream; `out` holds 1 + d d + 2 d + 1 doubles.
+// ====================================================================================================
+static int grad_level1_rc(pgps_ctx* ctx, int d, const GradLtiArgs& g, int phase) {
+    switch (d) {
+#define PGPS_RC_CASE(DV) case DV: return rc::launch_rc_grad<DV>(ctx, g, phase);
+        PGPS_RC_CASE(2) PGPS_RC_CASE(3) PGPS_RC_CASE(4) PGPS_RC_CASE(5) PGPS_RC_CASE(6) PGPS_RC_CASE(7) PGPS_RC_CASE(8)
+        PGPS_RC_CASE(9) PGPS_RC_CASE(10) PGPS_RC_CASE(11) PGPS_RC_CASE(12) PGPS_RC_CASE(13) PGPS_RC_CASE(14)
+        PGPS_RC_CASE(15) PGPS_RC_CASE(16)
+#undef PGPS_RC_CASE
+    }
+    return PGPS_E_UNSUPPORTED_DIM;
+}
+
+int launch_ll_grad_lti(pgps_ctx* ctx, long N, int d, const double* model, double R, const double* ts, double t0,
+                       const double* ys, double* out) {
+    RoctxRange range_("parallel_filter");
+    if (!ctx || N < 1 || !model || !ts || !ys || !out) return PGPS_E_INVALID;
+    if (d < rc::kDimMin || d > rc::kDimMax) return PGPS_E_UNSUPPORTED_DIM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t dd = (size_t)d * d, n = (size_t)N;
+    int rcode;
+    // transition matrices and the filtered moments the backward pass re-reads: the general-LTI scratch of the context
+    if ((rcode = ensure(ctx, ctx->lti[4], n * dd * sizeof(double)))) return rcode;
+    if ((rcode = ensure(ctx, ctx->lti[6], n * dd * sizeof(double)))) return rcode;
+    if ((rcode = ensure(ctx, ctx->lti[7], n * d * sizeof(double)))) return rcode;
+    double* Fs = (double*)ctx->lti[4].p;
+    if ((rcode = launch_disc_rc(ctx, N, d, model, model + dd, ts, t0, Fs, nullptr))) return rcode;     // implicit process noise
+    rc::RcArgsT<double> a{};
+    a.N = N;
+    {
+        long lw = ctx->chunk > 0 ? (ctx->chunk > 4096 ? 4096 : ctx->chunk) : (N + 4095) / 4096;
+        if (ctx->chunk <= 0 && lw > 128) { lw = (N + 8191) / 8192; if (lw < 128) lw = 128; }
+        a.Lw = (int)(lw < 8 && ctx->chunk <= 0 ? 8 : lw > 512 && ctx->chunk <= 0 ? 512 : lw);
+    }
+    a.nchunk = (N + a.Lw - 1) / a.Lw;
+    a.wfast = N >= 2 ? (N - 2) / (4L * a.Lw) : 0;
+    a.P0 = model + dd; a.H = model + 2 * dd; a.R = R; a.Fs = Fs; a.Qs = nullptr; a.ys = ys;
+    a.seg_first = 1; a.seg_last = 1; a.implicit_q = 1; a.store_f = 0;
+    const size_t nf = wc::nfilt(d), ns = wc::nsmth(d), nc = (size_t)a.nchunk, nst = (size_t)grad_lti_nstat(d);
+    size_t off = 0;
+    const size_t o_aggA = off;  off = rc_align(off + nc * nf * sizeof(double));
+    const size_t o_aggB = off;  off = rc_align(off + nc * nf * sizeof(double));
+    const size_t o_sagA = off;  off = rc_align(off + nc * ns * sizeof(double));
+    const size_t o_sagB = off;  off = rc_align(off + nc * ns * sizeof(double));
+    const size_t o_ll = off;    off = rc_align(off + nc * sizeof(double));
+    const size_t o_gp = off;    off = rc_align(off + nc * nst * sizeof(double));
+    if ((rcode = ensure(ctx, ctx->ws, off))) return rcode;
+    char* base = (char*)ctx->ws.p;
+    double *aggA = (double*)(base + o_aggA), *aggB = (double*)(base + o_aggB);
+    double *sagA = (double*)(base + o_sagA), *sagB = (double*)(base + o_sagB);
+    a.llpart = (double*)(base + o_ll);
+    a.agg1 = aggA;
+    if ((rcode = rc::level1(ctx, d, a, 0))) return rcode;
+    double* pre = aggA;
+    if ((rcode = rc::ks_scan(ctx, d, 0, a.nchunk, aggA, aggB, &pre))) return rcode;
+    GradLtiArgs g{};
+    g.N = N; g.d = d; g.Lw = a.Lw; g.nchunk = a.nchunk;
+    g.Pinf = model + dd; g.H = model + 2 * dd; g.R = R; g.Fs = Fs; g.ys = ys; g.ts = ts; g.t0 = t0;
+    g.fPs = (double*)ctx->lti[6].p; g.fms = (double*)ctx->lti[7].p;
+    g.pre = pre; g.sagg = sagA; g.llpart = a.llpart; g.gpart = (double*)(base + o_gp); g.out = out;
+    if ((rcode = grad_level1_rc(ctx, d, g, 0))) return rcode;
+    double* suf = sagA;
+    if ((rcode = rc::ks_scan(ctx, d, 1, a.nchunk, sagA, sagB, &suf))) return rcode;
+    g.suf = suf;
+    if ((rcode = grad_level1_rc(ctx, d, g, 1))) return rcode;
+    return grad_level1_rc(ctx, d, g, 2);
 }
 
 }  // namespace pgps

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("PGPS_LIB", os.path.join(_HERE, "libpgps.so"))
 
 PGPS_OK = 0
+E_UNSUPPORTED_DIM = -2
 PGPS_K_NAMES = None
 COMM_ID_BYTES = 128             # PGPS_COMM_ID_BYTES
 
@@ -544,6 +545,41 @@ def lti_ll(F, Pinf, H, R, ts, ys, t0=0.0, device=0):
     return ll.value
 
 
+def split_grad_stats(out, d):
+    """[ll | Abar | Ubar | Hbar | Rbar] of pgps_lti_ll_grad_* -> (ll, Abar (d, d), Ubar (d,), Hbar (d,), Rbar)."""
+    dd = d * d
+    return (float(out[0]), out[1:1 + dd].reshape(d, d).copy(), out[1 + dd:1 + dd + d].copy(),
+            out[1 + dd + d:1 + dd + 2 * d].copy(), float(out[1 + dd + 2 * d]))
+
+
+def contract_grad_stats(stats, H, grads):
+    """d ll / d theta for the kernel's parameters (grads: [(dF, dPinf, dH)] of pssgp.kernels.sde_grads, every dF
+    commuting with F) followed by d ll / d R -- the host half of the adjoint gradient (include/pgps.h,
+    pgps_lti_ll_grad_f64)."""
+    _, Abar, Ubar, Hbar, Rbar = stats
+    h = np.asarray(H, np.float64).reshape(-1)
+    g = [float(np.sum(Abar * dF) + Ubar @ (np.asarray(dP, np.float64) @ h) + Hbar @ np.asarray(dH, np.float64).reshape(-1))
+         for dF, dP, dH in grads]
+    return np.array(g + [Rbar], np.float64)
+
+
+def lti_ll_grad(F, Pinf, H, R, ts, ys, t0=0.0, device=0):
+    """Log-likelihood and the model's adjoints of any LTI state-space GP (pgps_lti_ll_grad_f64): one filter pass and one
+    reverse pass on the device, whatever the number of hyper-parameters.  Returns (ll, Abar, Ubar, Hbar, Rbar)."""
+    F, Pinf, H, d = _lti_model(F, Pinf, H)
+    ts_a = _prep(ts, np.float64, (-1,))
+    ys_a = _prep(ys, np.float64, (-1,))
+    if ys_a.shape[0] != ts_a.shape[0]:
+        raise ValueError(f"observations has {ys_a.shape[0]} rows, the series {ts_a.shape[0]} steps")
+    ctx = get_context(device)
+    if not hasattr(ctx.lib, "pgps_lti_ll_grad_f64"):
+        raise RuntimeError("this libpgps has no pgps_lti_ll_grad_* entry points")
+    out = np.zeros(2 + d * d + 2 * d, np.float64)
+    ctx.call("pgps_lti_ll_grad_f64", c_long(ts_a.shape[0]), c_int(d), _ptr(F), _ptr(Pinf), _ptr(H), c_double(float(R)),
+             _ptr(ts_a), _ptr(ys_a), c_double(float(t0)), _ptr(out))
+    return split_grad_stats(out, d)
+
+
 def lti_predict(F, Pinf, H, R, ts, ys, tq, t0=0.0, device=0):
     """predict_f of any LTI state-space GP on the device (pgps_lti_predict_f64): merge of the sorted `ts` (N) and
     `tq` (K), discretisation, filter + smoother over the N + K steps, posterior mean / variance of f = H x at the K
@@ -663,6 +699,9 @@ class Series:
             lib.pgps_series_lti_ll_f64.argtypes = [P, c_int, P, P, P, c_double, P]
             lib.pgps_series_lti_predict_f64.argtypes = [P, c_int, P, P, P, c_double, P, P, P]
             lib.pgps_series_lti_ll_batch_f64.argtypes = [P, c_int, c_int, P, P]
+        self.has_lti_grad = hasattr(lib, "pgps_series_lti_ll_grad_f64")
+        if self.has_lti_grad:
+            lib.pgps_series_lti_ll_grad_f64.argtypes = [P, c_int, P, P, P, c_double, P]
         self.N, self.K = ts_a.shape[0], 0
         self._tq = None
         h = P()
@@ -709,6 +748,15 @@ class Series:
             check(self.ctx, self.ctx.lib.pgps_series_lti_ll_f64(self.handle, d, _ptr(F), _ptr(Pinf), _ptr(H), float(R), self._llp),
                   "pgps_series_lti_ll_f64")
         return self._ll.value
+
+    def lti_ll_grad(self, F, Pinf, H, R):
+        """(ll, Abar, Ubar, Hbar, Rbar): the log-likelihood and the model's adjoints (pgps_series_lti_ll_grad_f64)."""
+        F, Pinf, H, d = _lti_model(F, Pinf, H)
+        out = np.zeros(2 + d * d + 2 * d, np.float64)
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_lti_ll_grad_f64(self.handle, d, _ptr(F), _ptr(Pinf), _ptr(H), float(R), _ptr(out)),
+                  "pgps_series_lti_ll_grad_f64")
+        return split_grad_stats(out, d)
 
     def lti_predict(self, F, Pinf, H, R):
         """(mean (K,), var (K,), ll) at the query grid of set_queries()."""

@@ -58,6 +58,21 @@ def _get_ssm(sde, ts, R, t0=0.):
 class Kernel:
     """Minimal stand-in for gpflow.kernels.Kernel: hyper-parameters are plain floats."""
 
+    # Bumped by every assignment to an attribute of any kernel object: what StateSpaceGP memoises per hyper-parameter
+    # setting is revalidated only when this has moved (an evaluation repeated at the same setting costs one comparison).
+    _version = 0
+    _PARAMETERS = ("variance", "lengthscales", "period")
+
+    def __setattr__(self, name, value):
+        # hyper-parameters are kept as Python floats whatever they are assigned as (int, numpy scalar, 0-d array): the
+        # memo keys, the closed-form derivative rules and `trainable_parameters()` then see one type
+        if name in Kernel._PARAMETERS and value is not None and not isinstance(value, float):
+            arr = np.asarray(value)
+            if arr.ndim == 0 and arr.dtype.kind in "fiu":
+                value = float(arr)
+        Kernel._version += 1
+        object.__setattr__(self, name, value)
+
     def K(self, X, X2=None):
         raise NotImplementedError
 

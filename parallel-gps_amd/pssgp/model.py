@@ -10,6 +10,8 @@ the scan kernels) instead of TensorFlow autodiff.
 import numpy as np
 
 from . import config
+from .kernels.base import Kernel
+from .kernels.sde_grads import leaf_parameters
 from .kalman.parallel import pkf, pkfs
 from .kalman.sequential import kf, kfs
 
@@ -60,7 +62,7 @@ class StateSpaceGP:
         if ys.shape[1] != 1:
             raise ValueError("only single-output observations are supported (pssgp/model.py:72)")
         self.kernel = kernel
-        self.data = ts, ys
+        self._data = ts, ys
         self.num_latent_gps = ys.shape[-1]
         self.parallel = bool(parallel)
         self.max_parallel = max_parallel
@@ -71,22 +73,70 @@ class StateSpaceGP:
             self._kf = lambda ssm, y: pkf(ssm, y, return_loglikelihood=True, max_parallel=ts.shape[0])
             self._kfs = lambda ssm, y: pkfs(ssm, y, max_parallel=max_parallel)
 
+    @property
+    def data(self):
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        """Assigning new data (the GPflow idiom `model.data = (X, Y)` the reference inherits) drops the device copy of
+        the series and every memoised result; an IN-PLACE edit of the arrays is caught by the checksum of
+        _device_series()."""
+        ts, ys = value
+        dtype = config.default_float()
+        ts, ys = np.asarray(ts, dtype=dtype), np.asarray(ys, dtype=dtype)
+        if ts.ndim == 1:
+            ts = ts[:, None]
+        if ys.ndim == 1:
+            ys = ys[:, None]
+        if ys.shape[1] != 1:
+            raise ValueError("only single-output observations are supported (pssgp/model.py:72)")
+        self._data = ts, ys
+        self.invalidate_device_series()
+
+    @staticmethod
+    def _data_stamp(ts, ys):
+        """Identity and shape of the arrays a device copy was made from, plus the bytes of their last entries
+        (O(1) per evaluation: a whole-array checksum would cost more than a short series' likelihood).  An in-place edit
+        that misses every sampled entry is not seen: call invalidate_device_series() after such an edit."""
+        return (id(ts), id(ys), ts.shape, ys.shape, ts[-1:].tobytes(), ys[-1:].tobytes())
+
     def _param_key(self):
         """The kernel's hyper-parameters as a tuple (the memo key of _device_forms: an evaluation repeated at the same
-        setting -- predict_f after the objective, a benchmark loop -- does not rebuild the SDE)."""
-        # (the kernel object itself is part of the key: replacing `model.kernel` by another kernel with the same numbers in
-        # it must not find the old one's forms)
-        return (id(self.kernel),) + tuple(getattr(o, n) for o, n in self.trainable_parameters()[:-1])
+        setting -- predict_f after the objective, a benchmark loop -- does not rebuild the SDE): the float value of
+        every variance / lengthscales / period leaf WHATEVER its type (int, numpy scalar, 0-d array), and what else
+        shapes the SDE (order, balancing sweeps, the class of every node).  The memo keeps a reference to the kernel it
+        was made for and is compared by identity (`is`), so a new kernel object never finds an old one's forms."""
+        quick = getattr(self, "_key_memo", None)
+        if (quick is not None and quick[0] == Kernel._version and quick[1] is self.kernel
+                and quick[2] == config.NUMBER_OF_BALANCING_STEPS):
+            return quick[3]             # no kernel attribute has been assigned since the key was built
+        version = Kernel._version
+        vals = tuple(float(getattr(o, n)) for o, n in leaf_parameters(self.kernel))
+
+        def shape_of(k):
+            sub = tuple(shape_of(x) for x in getattr(k, "kernels", ()))
+            base = getattr(k, "base_kernel", None)
+            return (type(k).__name__, getattr(k, "_order", None), getattr(k, "_balancing_iter", None), sub,
+                    None if base is None else type(base).__name__)
+
+        key = (shape_of(self.kernel), config.NUMBER_OF_BALANCING_STEPS) + vals
+        self._key_memo = (version, self.kernel, config.NUMBER_OF_BALANCING_STEPS, key)
+        return key
 
     def _device_series(self):
         """The training series resident on the device (pgps_series_*, fp64 fused path): created at the first call, kept
         for the model's life -- an optimiser or sampler loop then sends only the model's scalars per evaluation.  None
         when the data are not sorted or not float64 (the host entry points take those)."""
         ser = getattr(self, "_series", None)
+        ts, ys = self.data
+        if ser is not None and getattr(self, "_series_stamp", None) != self._data_stamp(ts, ys):
+            self.invalidate_device_series()         # the arrays were replaced or edited since the copy was made
+            ser = None
         if ser is None:
             from . import _backend
-            ts, ys = self.data
             t = ts.reshape(-1)
+            self._series_stamp = self._data_stamp(ts, ys)
             if ts.dtype != np.float64 or t.size < 1 or not np.all(np.diff(t) >= 0):
                 self._series = False
                 return None
@@ -98,19 +148,22 @@ class StateSpaceGP:
         return ser or None
 
     def invalidate_device_series(self):
-        """Call after changing `self.data` in place: the device copy is rebuilt at the next evaluation."""
+        """The device copy of the series is rebuilt at the next evaluation and memoised likelihoods are dropped (done
+        automatically when `data` is assigned or found edited)."""
         ser = getattr(self, "_series", None)
         if ser:
             ser.close()
         self._series = None
+        self._series_stamp = None
+        self._ll_memo = None
 
     def _device_forms(self):
         key = self._param_key()
         memo = getattr(self, "_forms_memo", None)
-        if memo is not None and memo[0] == key:
+        if memo is not None and memo[2] is self.kernel and memo[0] == key:
             return memo[1]
         out = self._device_forms_uncached()
-        self._forms_memo = (key, out)
+        self._forms_memo = (key, out, self.kernel)
         return out
 
     def _packed_fused(self, fused):
@@ -194,8 +247,8 @@ class StateSpaceGP:
             return None
         from . import _backend
         ref = getattr(self, "_rbf_ref", None)
-        tag = (id(k), getattr(k, "_order", None), getattr(k, "_balancing_iter", None))
-        if ref is not None and ref[5] != tag:
+        tag = (getattr(k, "_order", None), getattr(k, "_balancing_iter", None))
+        if ref is not None and (ref[6] is not k or ref[5] != tag):
             ref = None                              # another kernel object (or order / balancing) than the reference's
         if ref is None or not (0.8 <= ell / ref[1] <= 1.25):
             sde = k.get_sde()
@@ -206,7 +259,7 @@ class StateSpaceGP:
             LQL = L @ np.atleast_2d(np.asarray(sde.Q, np.float64)) @ L.T
             if np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) > 1e-8 * max(1.0, float(np.max(np.abs(LQL)))):
                 return None
-            ref = self._rbf_ref = (s2, ell, F, P0, np.asarray(sde.H, np.float64), tag)
+            ref = self._rbf_ref = (s2, ell, F, P0, np.asarray(sde.H, np.float64), tag, k)
         from types import SimpleNamespace
         return SimpleNamespace(F=ref[2] * (ref[1] / ell), P0=ref[3] * (s2 / ref[0]), H=ref[4])
 
@@ -269,7 +322,7 @@ class StateSpaceGP:
                 mean, var, ll = ser.gp_predict(self._packed_fused(fused), self.noise_variance)
                 # (the filter pass of the prediction IS the training log-likelihood -- the query rows are missing
                 # observations: an objective evaluated next at the same setting costs nothing)
-                self._ll_memo = (self._param_key(), self.noise_variance, ser, np.float64(ll))
+                self._ll_memo = (self._param_key(), float(self.noise_variance), ser, np.float64(ll), self.kernel)
                 return mean[:, None], var[:, None]
         if (fused is not None and squeezed_Xnew.size > 0 and np.all(np.diff(squeezed_ts) >= 0)
                 and np.all(np.diff(squeezed_Xnew) >= 0)):
@@ -289,7 +342,7 @@ class StateSpaceGP:
             if ser is not None and ser.has_lti:
                 ser.set_queries(squeezed_Xnew)
                 mean, var, ll = ser.lti_predict(lti.F, lti.P0, lti.H, self.noise_variance)
-                self._ll_memo = (self._param_key(), self.noise_variance, ser, config.default_float()(ll))
+                self._ll_memo = (self._param_key(), float(self.noise_variance), ser, config.default_float()(ll), self.kernel)
                 return mean[:, None].astype(dtype), var[:, None].astype(dtype)
             mean, var, _ = _backend.lti_predict(lti.F, lti.P0, lti.H, self.noise_variance, squeezed_ts, ys.reshape(-1),
                                                 squeezed_Xnew)
@@ -323,7 +376,8 @@ class StateSpaceGP:
             ser = self._device_series() if ts.dtype == np.float64 else None
             if ser is not None:
                 memo = getattr(self, "_ll_memo", None)
-                if memo is not None and memo[2] is ser and memo[1] == self.noise_variance and memo[0] == self._param_key():
+                if (memo is not None and memo[2] is ser and memo[4] is self.kernel and memo[1] == float(self.noise_variance)
+                        and memo[0] == self._param_key()):
                     return memo[3]
                 return np.float64(ser.gp_ll(self._packed_fused(fused), self.noise_variance))
             sde, form = fused
@@ -333,7 +387,8 @@ class StateSpaceGP:
             ser = self._device_series() if ts.dtype == np.float64 else None
             if ser is not None and ser.has_lti:
                 memo = getattr(self, "_ll_memo", None)
-                if memo is not None and memo[2] is ser and memo[1] == self.noise_variance and memo[0] == self._param_key():
+                if (memo is not None and memo[2] is ser and memo[4] is self.kernel and memo[1] == float(self.noise_variance)
+                        and memo[0] == self._param_key()):
                     return memo[3]
                 return config.default_float()(ser.lti_ll(lti.F, lti.P0, lti.H, self.noise_variance))
             ll = _backend.lti_ll(lti.F, lti.P0, lti.H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))
@@ -348,19 +403,7 @@ class StateSpaceGP:
         lengthscale and period (the reference's gpflow Parameters: the Matern / RBF kernels' variance /
         lengthscales, Periodic's period and its base kernel's parameters, the leaves of sums and products in order),
         then the observation-noise variance (pssgp/model.py:68)."""
-        ps = []
-
-        def walk(k):
-            for sub in getattr(k, "kernels", ()):
-                walk(sub)
-            if getattr(k, "kernels", None):
-                return
-            ps.extend((k, a) for a in ("variance", "lengthscales", "period") if isinstance(getattr(k, a, None), float))
-            if getattr(k, "base_kernel", None) is not None:
-                walk(k.base_kernel)
-
-        walk(self.kernel)
-        return ps + [(self, "noise_variance")]
+        return leaf_parameters(self.kernel) + [(self, "noise_variance")]
 
     def _grad_blocks_matern(self):
         """_grad_blocks() of a single Matern-1/2, -3/2 or -5/2 kernel in closed form, from the memoised get_sde() of the
@@ -493,22 +536,89 @@ class StateSpaceGP:
                 setattr(owner, name, x0)
         return rows, sizes
 
-    def log_likelihood_and_grad(self, wrt=None):
+    def _adjoint_ll_and_grad(self, wrt=None):
+        """(ll, grad) by the adjoint pass of the general-LTI device path (pgps_lti_ll_grad_f64): the device returns the
+        adjoints of the model (F, Pinf, H, R) from one filter pass and one reverse pass, pssgp.kernels.sde_grads the
+        model's derivatives in a frozen state basis; exact (no differences), ONE device call, any number of parameters.
+        None when the kernel has no derivative rule, a derivative of the drift does not commute with it (the contraction
+        the device makes would not apply), or the library lacks the entry point."""
+        from . import _backend
+        from .kernels.sde_grads import sde_with_grads
+        key = self._param_key()
+        memo = getattr(self, "_grads_memo", None)
+        if memo is not None and memo[2] is self.kernel and memo[0] == key:
+            prepared = memo[1]
+        else:
+            try:
+                sde, grads = sde_with_grads(self.kernel)
+            except (NotImplementedError, ZeroDivisionError, FloatingPointError):
+                sde = None
+            prepared = None
+            if sde is not None:
+                F, P0 = np.ascontiguousarray(sde.F, np.float64), np.ascontiguousarray(sde.P0, np.float64)
+                H = np.ascontiguousarray(np.asarray(sde.H, np.float64).reshape(-1))
+                L = np.asarray(sde.L, np.float64)
+                LQL = L @ np.atleast_2d(np.asarray(sde.Q, np.float64)) @ L.T
+                fmax = max(1.0, float(np.max(np.abs(F))))
+                ok = (_backend.LTI_DIM_MIN <= F.shape[0] <= _backend.LTI_DIM_MAX and np.all(np.isfinite(F)) and np.all(np.isfinite(P0))
+                      and np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) <= 1e-8 * max(1.0, float(np.max(np.abs(LQL)))))
+                for dF, dP, dH in grads if ok else ():
+                    if not (np.all(np.isfinite(dF)) and np.all(np.isfinite(dP))) or \
+                            np.max(np.abs(F @ dF - dF @ F)) > 1e-9 * fmax * max(1.0, float(np.max(np.abs(dF)))):
+                        ok = False
+                if ok:
+                    prepared = (F, P0, H, grads)
+            self._grads_memo = (key, prepared, self.kernel)
+        if prepared is None:
+            return None
+        F, P0, H, grads = prepared
+        ts, Y = self.data
+        ser = self._device_series() if ts.dtype == np.float64 else None
+        try:
+            if ser is not None and getattr(ser, "has_lti_grad", False):
+                stats = ser.lti_ll_grad(F, P0, H, self.noise_variance)
+            else:
+                stats = _backend.lti_ll_grad(F, P0, H, self.noise_variance, ts.reshape(-1), Y.reshape(-1))
+        except _backend.PgpsError as e:
+            if getattr(e, "code", None) == _backend.E_UNSUPPORTED_DIM:
+                return None
+            raise
+        except RuntimeError:
+            return None
+        g = _backend.contract_grad_stats(stats, H, grads)
+        if wrt is not None:
+            keep = np.zeros(len(g), bool)
+            keep[[int(i) for i in wrt]] = True
+            g = np.where(keep, g, 0.0)
+        return config.default_float()(stats[0]), g
+
+    def log_likelihood_and_grad(self, wrt=None, method=None):
         """(ll, grad): the marginal log-likelihood and its gradient with respect to
         `trainable_parameters()` -- what the reference obtains from tf.GradientTape over
         maximum_log_likelihood_objective (tests/test_gp_vs_kfs.py:53-78).  parallel=True.  Matern family (d <= 3):
-        ONE pass of the parallel filter on dual numbers, exact.  Every other kernel: Richardson central differences,
-        batched into one device call up to d = 16 (`wrt`: differentiate only these parameter indices, the others
-        get 0 -- each one costs four likelihood evaluations)."""
+        ONE pass of the parallel filter on dual numbers, exact.  Every other kernel (RBF, Periodic, sums, products,
+        2 <= d <= 32): the ADJOINT pass -- one filter pass and one reverse pass on the device, exact, whatever the number
+        of parameters (`_adjoint_ll_and_grad`).  `method`: None = automatic, "adjoint", "dual" (sums / products of Matern
+        kernels up to d = 6 on dual numbers) or "differences" (Richardson central differences of batched likelihoods:
+        the cross-checks of the tests); `wrt`: only these parameter indices, the others get 0."""
         if not self.parallel:
             raise NotImplementedError("gradients run on the parallel (HIP) path: construct with parallel=True")
         from . import _backend
         ts, Y = self.data
         fused, lti = self._device_forms()
+        if fused is None and lti is not None and method in (None, "adjoint"):
+            # every kernel without the closed-form discretisation: the adjoint pass (two passes whatever the number of
+            # parameters); None when the kernel has no derivative rule or the library no such entry point
+            out = self._adjoint_ll_and_grad(wrt)
+            if out is not None:
+                return out
+            if method == "adjoint":
+                raise NotImplementedError("no adjoint gradient for this kernel / library")
         if fused is None:
             # sums / products of Matern kernels (block-nilpotent drift, d <= 6): exact, dual numbers through the scan
             rows, sizes = (None, None)
-            if lti is not None and lti.F.shape[0] <= _backend.GRAD_BLOCKS_DIM_MAX and not getattr(self, "_no_composite", False):
+            if (method in (None, "dual") and lti is not None and lti.F.shape[0] <= _backend.GRAD_BLOCKS_DIM_MAX
+                    and not getattr(self, "_no_composite", False)):
                 rows, sizes = self._grad_rows_composite()
             if rows is not None:
                 ll, g = _backend.gp_ll_grad_blocks(rows, sizes, ts.reshape(-1), Y.reshape(-1))
