@@ -1419,11 +1419,11 @@ static bool diagonal_blocks(int d, const double* F, const double* P, int cap, st
 
 // 16 < d <= 32: the same chain on the wave-cooperative kernels -- discretisation with Qs written out, whole filtered (and
 // smoothed) moments into scratch, projection at the query rows by k_project_rows.  Everything stays on the device.
-static int lti_dev_wc(pgps_ctx* ctx, size_t m, int d, const double* model, const double* F_host, const double* P_host,
-                      double R, const double* ts_m, const double* ys_m, double t0, const int* qslot, double* mean,
-                      double* var, double* ll) {
+// discretisation of the d <= 32 road into the context's scratch: Fs, Qs (m, d, d)
+static int lti_disc_wc(pgps_ctx* ctx, size_t m, int d, const double* model, const double* F_host, const double* P_host,
+                       const double* ts_m, double t0, double** Fs_out, double** Qs_out) {
     const size_t dd = (size_t)d * d;
-    double *Fs, *Qs, *fms, *fPs;
+    double *Fs, *Qs;
     TRY(stage_in<double>(ctx, ctx->lti[4], nullptr, m * dd, &Fs));
     TRY(stage_in<double>(ctx, ctx->lti[5], nullptr, m * dd, &Qs));
     std::vector<std::vector<int>> blocks;
@@ -1471,6 +1471,17 @@ static int lti_dev_wc(pgps_ctx* ctx, size_t m, int d, const double* model, const
     } else {
         TRY(launch_disc_wc<double>(ctx, (long)m, d, model, model + dd, ts_m, t0, Fs, Qs));
     }
+    *Fs_out = Fs;
+    *Qs_out = Qs;
+    return PGPS_OK;
+}
+
+static int lti_dev_wc(pgps_ctx* ctx, size_t m, int d, const double* model, const double* F_host, const double* P_host,
+                      double R, const double* ts_m, const double* ys_m, double t0, const int* qslot, double* mean,
+                      double* var, double* ll) {
+    const size_t dd = (size_t)d * d;
+    double *Fs, *Qs, *fms, *fPs;
+    TRY(lti_disc_wc(ctx, m, d, model, F_host, P_host, ts_m, t0, &Fs, &Qs));
     ScanArgs<double> a{};
     a.N = (long)m; a.seg_first = 1; a.seg_last = 1;
     a.P0 = model + dd; a.H = model + 2 * dd; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys_m;
@@ -1685,7 +1696,12 @@ static int lti_grad_dev(pgps_ctx* ctx, long N, int d, const double* F, const dou
     HIPCHK(ctx, hipSetDevice(ctx->device));
     double* model;
     TRY(lti_model_in(ctx, d, F, Pinf, H, &model));
-    return launch_ll_grad_lti(ctx, N, d, model, R, ts, t0, ys, out);
+    // row-cooperative kernels up to d = 16; above that (and wherever the wave-cooperative family is forced: the tests'
+    // cross-check) the wave-cooperative ones, from discretised arrays
+    if (d <= rc::kDimMax && ctx->family != 2) return launch_ll_grad_lti(ctx, N, d, model, R, ts, t0, ys, out);
+    double *Fs, *Qs;
+    TRY(lti_disc_wc(ctx, (size_t)N, d, model, F, Pinf, ts, t0, &Fs, &Qs));
+    return launch_ll_grad_lti_wc(ctx, N, d, model, R, Fs, Qs, ts, t0, ys, out);
 }
 extern "C" int pgps_lti_ll_grad_dev_f64(pgps_ctx* c, long N, int d, const double* F, const double* Pinf, const double* H,
                                         double R, const double* ts, const double* ys, double t0, double* out) {

@@ -43,7 +43,26 @@ struct GradLtiArgs {
     double* gpart;              // (nchunk, d d + 2 d + 1) chain partials [Abar | Ubar | Hbar | Rbar]
     double* out;                // [ll | Abar (d d, row-major) | Ubar (d) | Hbar (d) | Rbar]
 };
-inline int grad_lti_nstat(int d) { return d * d + 2 * d + 1; }
+__host__ __device__ inline int grad_lti_nstat(int d) { return d * d + 2 * d + 1; }
+
+// out[0] = sum of the chains' log-likelihood partials, out[1 + e] = sum over the chains of entry e of their partials:
+// one workgroup per entry, a fixed order of additions (bit-reproducible).  Shared by the families (a HIP translation unit each).
+static __global__ __launch_bounds__(256) void k_grad_lti_finalize(long nchunk, int nst, const double* llpart, const double* gpart,
+                                                                   double* out) {
+    __shared__ double part[256];
+    const int e = blockIdx.x;                   // 0: ll, 1 + e: statistic e
+    const double* src = e == 0 ? llpart : gpart + (e - 1);
+    const long stride = e == 0 ? 1 : nst;
+    double t = 0.0;
+    for (long c = threadIdx.x; c < nchunk; c += 256) t += src[c * stride];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[e] = part[0];
+}
 
 namespace rc {
 // phase 0: forward (rc_gapply1), 1: backward (rc_gback1), 2: finalize.  Defined in pgps_rc_inst.hip (fp64 units).
@@ -55,5 +74,9 @@ int launch_rc_grad(pgps_ctx* ctx, const GradLtiArgs& a, int phase);
 // 1 + grad_lti_nstat(d) doubles).  2 <= d <= 32.  Defined in pgps_wc.hip.
 int launch_ll_grad_lti(pgps_ctx* ctx, long N, int d, const double* model, double R, const double* ts, double t0,
                        const double* ys, double* out);
+// The same on the wave-cooperative family (any d <= 32; the road of d = 17..32) from DISCRETISED arrays Fs, Qs (N, d, d)
+// [device]: the caller runs the discretisation (pgps_core.hip: block-wise for block-diagonal models).
+int launch_ll_grad_lti_wc(pgps_ctx* ctx, long N, int d, const double* model, double R, const double* Fs, const double* Qs,
+                          const double* ts, double t0, const double* ys, double* out);
 
 }  // namespace pgps

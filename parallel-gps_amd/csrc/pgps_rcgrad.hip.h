@@ -236,25 +236,6 @@ __global__ __launch_bounds__(64) void rc_gback1(const GradLtiArgs a) {
     }
 }
 
-// out[0] = sum of the chains' log-likelihood partials, out[1 + e] = sum over the chains of entry e of their partials:
-// one workgroup per entry, a fixed order of additions (bit-reproducible).  Shared by every family.
-static __global__ __launch_bounds__(256) void k_grad_lti_finalize(long nchunk, int nst, const double* llpart, const double* gpart,
-                                                                   double* out) {
-    __shared__ double part[256];
-    const int e = blockIdx.x;                   // 0: ll, 1 + e: statistic e
-    const double* src = e == 0 ? llpart : gpart + (e - 1);
-    const long stride = e == 0 ? 1 : nst;
-    double t = 0.0;
-    for (long c = threadIdx.x; c < nchunk; c += 256) t += src[c * stride];
-    part[threadIdx.x] = t;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[e] = part[0];
-}
-
 template <int D>
 int launch_rc_grad(pgps_ctx* ctx, const GradLtiArgs& a, int phase) {
     const dim3 blk(64), g1((unsigned)((a.nchunk + 3) / 4));

@@ -1702,6 +1702,9 @@ static __global__ __launch_bounds__(64) void wc_ll_finalize(const double* llpart
 }
 
 }  // namespace wc
+}  // namespace pgps
+#include "pgps_wcgrad.hip.h"
+namespace pgps {
 
 // ---- segment records (pgps_seg_*): shared by the row-cooperative and the wave-cooperative drivers ------------
 namespace rc {
@@ -1817,7 +1820,8 @@ static int launch_rc2(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
 }
 
 template <typename T, int DP>
-static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const WcSeg<T>* sg = nullptr) {
+static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const WcSeg<T>* sg = nullptr,
+                             const GradLtiArgs* gr = nullptr) {
     using namespace wc;
     using GE = Geo<DP>;
     const size_t pad = 64;
@@ -2000,6 +2004,35 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
         }
         timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_fin_filter<T, DP>, g2, blk, (unsigned)bytes(l_carry3), a, cur);
     }
+    if constexpr (sizeof(T) == 8) {
+        if (gr) {
+            // log-likelihood + the model's adjoints (pgps_gradlti.h): forward pass with the adjoint elements folded, the
+            // smoother's scan over their totals, backward pass, finalize
+            if (serial3 || mode != MODE_PKF) return PGPS_E_INVALID;
+            const size_t l_gapply = 7 * GE::MSZ + 12 * DP + pad, l_gback = 9 * GE::MSZ + 14 * DP + pad;
+            if (bytes(l_gback) > 160 * 1024) return PGPS_E_UNSUPPORTED_DIM;
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(wg_apply1<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(l_gapply)));
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(wg_back1<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(l_gback)));
+            timed_launch(ctx, PGPS_K_FILTER_REDUCE, wc_enter1<T, DP>, g1, blk, (unsigned)bytes(l_carry3), a);
+            timed_launch(ctx, PGPS_K_FILTER_APPLY, wg_apply1<DP>, g1, blk, (unsigned)bytes(l_gapply), a);
+            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_sreduce2<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a);
+            const T* cur = a.sagg2;
+            T* nxt = a.ksA;
+            for (long stride = 1; stride < a.ngroup; stride <<= 1) {
+                timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_ks_smoother<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a.d, (long)a.ngroup,
+                             stride, cur, nxt);
+                cur = nxt;
+                nxt = (nxt == a.ksA) ? a.ksB : a.ksA;
+            }
+            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_fin_smoother<T>, g2, blk, 0u, a, cur);
+            timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_senter1<T, DP>, g1, blk, (unsigned)bytes(l_scarry3), a);
+            timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, wg_back1<DP>, g1, blk, (unsigned)bytes(l_gback), a, *gr);
+            hipLaunchKernelGGL(k_grad_lti_finalize, dim3((unsigned)(1 + grad_lti_nstat(a.d))), dim3(256), 0, ctx->stream,
+                               (long)a.nchunk, grad_lti_nstat(a.d), (const double*)a.llpart, (const double*)gr->gpart, gr->out);
+            HIPCHK(ctx, hipGetLastError());
+            return PGPS_OK;
+        }
+    }
     if (mode == MODE_PKFS) {
         WC_LEVEL1(2);
         timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, wc_sreduce2<T, DP>, g2, blk, (unsigned)bytes(l_sred2), a);
@@ -2031,7 +2064,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
 }
 
 template <typename T>
-int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
+static int launch_scan_wc_impl(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode, GradLtiArgs* gr) {
     using namespace wc;
     if (mode == MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;      // stand-alone pks: the other two families (d <= 16)
     const bool seg = mode == MODE_SEG_REDUCE || mode == MODE_SEG_FILTER || mode == MODE_SEG_SMOOTHER;
@@ -2080,9 +2113,11 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
     const size_t o_E = off;      if (seg) off = wc_align(off + (size_t)sa.N * dd * sizeof(T));
     const size_t o_en = off;     off = wc_align(off + nc * (d + dd) * sizeof(T));
     const size_t o_sen = off;    off = wc_align(off + nc * (d + dd) * sizeof(T));
+    const size_t o_gp = off;     if (gr) off = wc_align(off + nc * (size_t)grad_lti_nstat(d) * sizeof(double));
     int rc = ensure(ctx, ctx->ws, off);
     if (rc) return rc;
     char* base = (char*)ctx->ws.p;
+    if (gr) gr->gpart = (double*)(base + o_gp);
     a.agg1 = (T*)(base + o_agg1); a.lpre1 = (T*)(base + o_lpre1); a.agg2 = (T*)(base + o_agg2);
     a.carry2 = (T*)(base + o_carry2); a.sagg1 = (T*)(base + o_sagg1); a.lsuf1 = (T*)(base + o_lsuf1);
     a.sagg2 = (T*)(base + o_sagg2); a.scarry2 = (T*)(base + o_sc2); a.llpart = (double*)(base + o_ll);
@@ -2098,12 +2133,35 @@ int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
         sgv.ll = sa.ll;
     }
     const WcSeg<T>* sg = seg ? &sgv : nullptr;
-    if (d <= 8) return launch_scan_wc_dp<T, 8>(ctx, a, mode, sg);
-    if (d <= 12) return launch_scan_wc_dp<T, 12>(ctx, a, mode, sg);
-    if (d <= 16) return launch_scan_wc_dp<T, 16>(ctx, a, mode, sg);
-    if (d <= 18) return launch_scan_wc_dp<T, 18>(ctx, a, mode, sg);
-    if (d <= 24) return launch_scan_wc_dp<T, 24>(ctx, a, mode, sg);
-    return launch_scan_wc_dp<T, 32>(ctx, a, mode, sg);
+    if (d <= 8) return launch_scan_wc_dp<T, 8>(ctx, a, mode, sg, gr);
+    if (d <= 12) return launch_scan_wc_dp<T, 12>(ctx, a, mode, sg, gr);
+    if (d <= 16) return launch_scan_wc_dp<T, 16>(ctx, a, mode, sg, gr);
+    if (d <= 18) return launch_scan_wc_dp<T, 18>(ctx, a, mode, sg, gr);
+    if (d <= 24) return launch_scan_wc_dp<T, 24>(ctx, a, mode, sg, gr);
+    return launch_scan_wc_dp<T, 32>(ctx, a, mode, sg, gr);
+}
+template <typename T>
+int launch_scan_wc(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode) {
+    return launch_scan_wc_impl<T>(ctx, sa, d, mode, nullptr);
+}
+
+int launch_ll_grad_lti_wc(pgps_ctx* ctx, long N, int d, const double* model, double R, const double* Fs, const double* Qs,
+                          const double* ts, double t0, const double* ys, double* out) {
+    RoctxRange range_("parallel_filter");
+    if (!ctx || N < 1 || !model || !Fs || !Qs || !ts || !ys || !out) return PGPS_E_INVALID;
+    if (d < 1 || d > 32) return PGPS_E_UNSUPPORTED_DIM;
+    const size_t dd = (size_t)d * d, n = (size_t)N;
+    int rcode;
+    if ((rcode = ensure(ctx, ctx->lti[6], n * dd * sizeof(double)))) return rcode;
+    if ((rcode = ensure(ctx, ctx->lti[7], n * d * sizeof(double)))) return rcode;
+    ScanArgs<double> a{};
+    a.N = N; a.seg_first = 1; a.seg_last = 1;
+    a.P0 = model + dd; a.H = model + 2 * dd; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys;
+    a.fPs = (double*)ctx->lti[6].p; a.fms = (double*)ctx->lti[7].p;
+    a.ll = nullptr;
+    GradLtiArgs g{};
+    g.N = N; g.d = d; g.ts = ts; g.t0 = t0; g.out = out;
+    return launch_scan_wc_impl<double>(ctx, a, d, MODE_PKF, &g);
 }
 
 template <typename T, int DP>

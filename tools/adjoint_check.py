@@ -41,6 +41,23 @@ def main():
             gd, gr = _backend.contract_grad_stats(dev, sde.H, grads), G.contract(ref, sde.H, grads)
             print(f"{name:8s} d={d:2d} N={n:5d}: rel err ll {errs[0]:.1e} Abar {errs[1]:.1e} Ubar {errs[2]:.1e} Hbar {errs[3]:.1e} "
                   f"Rbar {errs[4]:.1e}  grad {np.max(np.abs(gd - gr) / (1e-12 + np.abs(gr))):.1e}", flush=True)
+    # the wave-cooperative kernels (the road of d = 17..32) forced for every kernel: cross-check of the two families
+    ctx = _backend.get_context()
+    ctx.set_family(2)
+    try:
+        n = 700
+        t = np.sort(rng.uniform(0, 21, n)); y = np.sin(3 * t) + 0.3 * rng.standard_normal(n)
+        y[rng.uniform(size=n) < 0.15] = np.nan
+        for name, k in kernels():
+            sde, grads = sde_with_grads(k)
+            dev = _backend.lti_ll_grad(sde.F, sde.P0, sde.H, 0.1, t, y)
+            ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, 0.1, t, y)
+            errs = [abs(dev[0] - ref[0]) / abs(ref[0])] + [float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / (1e-300 + np.max(np.abs(b))))
+                                                            for a, b in zip(dev[1:], ref[1:])]
+            print(f"family 2 {name:8s} d={sde.F.shape[0]:2d} N={n}: rel err ll {errs[0]:.1e} Abar {errs[1]:.1e} Ubar {errs[2]:.1e} "
+                  f"Hbar {errs[3]:.1e} Rbar {errs[4]:.1e}", flush=True)
+    finally:
+        ctx.set_family(0)
     # the model's call, three ways, with timings
     n = 1000
     t = np.sort(rng.uniform(0, 10, n)); y = np.sin(t) + 0.3 * rng.standard_normal(n)
