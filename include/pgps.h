@@ -112,9 +112,20 @@ int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* steps_per_l
 int pgps_set_stage(pgps_ctx* ctx, int steps_per_subtile);
 int pgps_get_chunk(pgps_ctx* ctx, long n_steps, int* steps_per_lane, int* n_workgroups);
 const char* pgps_last_hip_error(pgps_ctx* ctx);
-/* Diagnostic flags raised on the device since the last call (synchronises; 0 = none; bit 1: a bounded
- * look-back spin of the single-pass filter gave up -- results of that pass are invalid). */
+/* Diagnostic flags raised since the last call (synchronises; 0 = none; bit 1: a bounded look-back spin of the
+ * single-pass filter gave up -- results of that pass are invalid; PGPS_STATUS_F32_PROMOTED: a float32 call ran in fp64
+ * arithmetic, see pgps_set_f32_policy). */
+#define PGPS_STATUS_F32_PROMOTED 4
 int pgps_status(pgps_ctx* ctx, int* flags);
+/* float32 series whose call runs a smoother (pgps_pkfs_f32, pgps_pks_f32 and their _dev forms).  The reference's own
+ * benchmark grid -- np.linspace(0, 4, N), pssgp/experiments/toy_models/common.py:31-32, with --dtype float32,
+ * speed_and_stability.py:68 -- is so dense at N >= 2^15 that float32 ARITHMETIC cannot hold 1e-3 on the smoothed moments
+ * (pssgp/kalman/parallel.py:159-166 and sequential.py:57-61 alike rebuild a covariance from a cancellation behind an
+ * ill-conditioned solve).  policy 0 (default): such calls probe a sample of the transition matrices on the device and,
+ * where the grid is that dense, run in fp64 arithmetic on the float32 arrays (widened into scratch, results rounded
+ * back; state dimensions above 16 always do) -- the arrays, the entry points and the tolerances stay the float32 ones;
+ * 1: float32 arithmetic whatever the grid; 2: always fp64 arithmetic.  pgps_status tells which way the calls went. */
+int pgps_set_f32_policy(pgps_ctx* ctx, int policy);
 
 /* ---- device memory helpers (for hosts without a device-array library) ----------------- */
 int pgps_malloc(pgps_ctx* ctx, size_t bytes, void** dptr);

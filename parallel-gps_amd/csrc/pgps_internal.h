@@ -40,6 +40,11 @@ struct pgps_ctx {
     DevBuf lti[12];                     // general-LTI entry points: model, merged series, Fs, Qs, E, g (d > 16: moments)
     DevBuf stamps;                      // diagnostic build only
     int* status_word = nullptr;         // device word kernels raise flags in (pgps_status)
+    int host_flags = 0;                 // flags raised on the host side (bit 2: a float32 call ran in fp64 arithmetic), reported and cleared by pgps_status
+    int f32_policy = 0;                 // float32 series with a smoother: 0 = automatic promotion on dense grids, 1 = always native, 2 = always fp64 arithmetic (pgps_set_f32_policy)
+    int* probe_host = nullptr;          // pinned word pair the dense-grid probe of a float32 call writes (and its device alias)
+    int* probe_dev = nullptr;
+    DevBuf wide[9];                     // fp64 copies of a promoted float32 call's arrays: P0, H, Fs, Qs, ys, fms, fPs, sms, sPs
     void* comm = nullptr;               // ncclComm_t (RCCL) of a series sharded over GPUs: pgps_comm_init (pgps_comm.hip)
     int comm_rank = 0, comm_nranks = 0;
     DevBuf comm_buf;                    // [rec_f | rec_s | gathered_f | gathered_s] of pgps_pkfs_seg_dev_*
@@ -247,6 +252,7 @@ int launch_ll_batch_rc(pgps_ctx* ctx, long N, int d, int batch, const double* ta
                        const double* Qs, const double* ys, double* ll);
 namespace rc {
 constexpr int kDimMin = 2, kDimMax = 16;
+constexpr int kScanBlockedDimMax = 15;     // blocked scans of the chain totals: the dimensions whose kernels need no scratch
 template <typename Real>
 struct RcArgsT {
     long N;

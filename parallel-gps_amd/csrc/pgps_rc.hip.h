@@ -1860,6 +1860,10 @@ constexpr int scan_block_rows(int which) {
 template <typename Real, int D>
 int launch_rc_scan_blocked(pgps_ctx* ctx, int which, long n, Real* data, Real* scratch) {
     if (n <= 1) return PGPS_OK;
+    // d = 16: the blocked kernels spill (528 / 272 B per lane in fp64, 272 / 144 B in fp32) -- not built, the driver scans
+    // those totals one Kogge-Stone level per launch (kScanBlockedDimMax in pgps_internal.h; tools/scratch_gate.py)
+    if constexpr (D > kScanBlockedDimMax) return PGPS_E_UNSUPPORTED_DIM;
+    else {
     constexpr int BF = scan_block_rows<Real, D>(0), BS = scan_block_rows<Real, D>(1);
     const int B = which == 0 ? BF : BS;
     const int rec = which == 0 ? 3 * D * D + 2 * D : 2 * D * D + D;
@@ -1885,6 +1889,7 @@ int launch_rc_scan_blocked(pgps_ctx* ctx, int which, long n, Real* data, Real* s
         HIPCHK(ctx, hipGetLastError());
     }
     return PGPS_OK;
+    }
 }
 
 template <int D>

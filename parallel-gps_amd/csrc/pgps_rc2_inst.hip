@@ -19,10 +19,13 @@ static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
     constexpr int DP = PGPS_RC2_DP;
     const dim3 blk(64), grid((unsigned)((a.nchunk + 1) / 2));
     const bool full = a.d == DP;        // no padding: the loads and stores without their column conditions
-#define PGPS_RC2_GO(SLOT, ...)                                                              \
-    do {                                                                                    \
-        if (full) timed_launch(ctx, SLOT, rc2::__VA_ARGS__, true>, grid, blk, 0u, a);       \
-        else timed_launch(ctx, SLOT, rc2::__VA_ARGS__, false>, grid, blk, 0u, a);           \
+    // (the padded flavour exists for d = 17 on 18 alone: every other dimension has a unit of its own)
+    constexpr bool PADDED = DP == 18;
+    if (!full && !PADDED) return PGPS_E_UNSUPPORTED_DIM;
+#define PGPS_RC2_GO(SLOT, ...)                                                                  \
+    do {                                                                                        \
+        if (full) timed_launch(ctx, SLOT, rc2::__VA_ARGS__, true>, grid, blk, 0u, a);           \
+        else if constexpr (PADDED) timed_launch(ctx, SLOT, rc2::__VA_ARGS__, false>, grid, blk, 0u, a); \
     } while (0)
     switch (which) {
         case 0: PGPS_RC2_GO(PGPS_K_FILTER_REDUCE, rc2_reduce1<T, DP); break;
@@ -32,13 +35,13 @@ static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
         case 4: {       // one Kogge-Stone level over the group totals (a.ks_*)
             const dim3 gk((unsigned)((a.ks_n + 1) / 2));
             if (full) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_ks_filter<T, DP, true>, gk, blk, 0u, a);
-            else timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_ks_filter<T, DP, false>, gk, blk, 0u, a);
+            else if constexpr (PADDED) timed_launch(ctx, PGPS_K_FILTER_REDUCE, rc2::rc2_ks_filter<T, DP, false>, gk, blk, 0u, a);
             break;
         }
         case 5: {       // ... of the smoother's suffix scan
             const dim3 gk((unsigned)((a.ks_n + 1) / 2));
             if (full) timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc2::rc2_ks_smoother<T, DP, true>, gk, blk, 0u, a);
-            else timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc2::rc2_ks_smoother<T, DP, false>, gk, blk, 0u, a);
+            else if constexpr (PADDED) timed_launch(ctx, PGPS_K_SMOOTHER_REDUCE, rc2::rc2_ks_smoother<T, DP, false>, gk, blk, 0u, a);
             break;
         }
         default: return PGPS_E_INVALID;
@@ -48,7 +51,14 @@ static int launch_one(pgps_ctx* ctx, int which, const wc::WcArgs<T>& a) {
     return PGPS_OK;
 }
 
-int PGPS_RC2_LAUNCH(pgps_ctx* ctx, int which, const wc::WcArgs<double>& a) { return launch_one<double>(ctx, which, a); }
-int PGPS_RC2_LAUNCH(pgps_ctx* ctx, int which, const wc::WcArgs<float>& a) { return launch_one<float>(ctx, which, a); }
+// (instantiated only where the kernels compile without scratch memory: pgps_wc_args.h, rc2_covers)
+int PGPS_RC2_LAUNCH(pgps_ctx* ctx, int which, const wc::WcArgs<double>& a) {
+    if constexpr (wc::rc2_covers<double>(PGPS_RC2_DP)) return launch_one<double>(ctx, which, a);
+    else return PGPS_E_UNSUPPORTED_DIM;
+}
+int PGPS_RC2_LAUNCH(pgps_ctx* ctx, int which, const wc::WcArgs<float>& a) {
+    if constexpr (wc::rc2_covers<float>(PGPS_RC2_DP)) return launch_one<float>(ctx, which, a);
+    else return PGPS_E_UNSUPPORTED_DIM;
+}
 
 }  // namespace pgps

@@ -1866,7 +1866,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
     // d = 17..32 -- every state dimension this family is chosen for -- unless PGPS_WC_ROWS2=0 (or a mask of `which` bits) asks for the
     // LDS-tile kernels of this file (the cross-check of the tests, and d <= 16 when this family is forced)
     auto level1 = [&](int which) -> int {
-        if (DP >= 18 && a.d >= 17 && ((ctx->wc_rows2 >> which) & 1)) {
+        if (DP >= 18 && rc2_covers<T>(a.d) && ((ctx->wc_rows2 >> which) & 1)) {
             // (the states entering the chunks close the scan: timed with its slots, so that the apply slots stay one
             //  launch per pass -- the launch bench.py prices against the roofline)
             if (which == 1 || which == 2)
@@ -1886,7 +1886,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
     // registers) wherever the two-rows level-1 kernels run; PGPS_WC_KS2=0 (diagnostic, read once) keeps the LDS-tile one
     static const bool ks2_env = [] { const char* e = std::getenv("PGPS_WC_KS2"); return !(e && e[0] == '0'); }();
     auto ks_filter_level = [&](long stride, const T* cur, T* nxt) -> int {
-        if (DP >= 18 && a.d >= 17 && (ctx->wc_rows2 & 1) && ks2_env) {
+        if (DP >= 18 && rc2_covers<T>(a.d) && (ctx->wc_rows2 & 1) && ks2_env) {
             a.ks_n = a.ngroup; a.ks_stride = stride; a.ks_in = cur; a.ks_out = nxt;
             return launch_rc2<T>(ctx, 4, a);
         }
@@ -1895,7 +1895,7 @@ static int launch_scan_wc_dp(pgps_ctx* ctx, wc::WcArgs<T> a, Mode mode, const Wc
         return PGPS_OK;
     };
     auto ks_smoother_level = [&](long stride, const T* cur, T* nxt) -> int {
-        if (DP >= 18 && a.d >= 17 && (ctx->wc_rows2 & 8) && ks2_env) {
+        if (DP >= 18 && rc2_covers<T>(a.d) && (ctx->wc_rows2 & 8) && ks2_env) {
             a.ks_n = a.ngroup; a.ks_stride = stride; a.ks_in = cur; a.ks_out = nxt;
             return launch_rc2<T>(ctx, 5, a);
         }
@@ -2075,7 +2075,7 @@ static int launch_scan_wc_impl(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode, 
     // one wave per chunk: about a thousand chunks before the chunks grow to 64 steps; groups of 4..64 chunks so that the
     // Kogge-Stone levels over the group totals stay at one round of waves (<= 512 groups up to 2^21 steps)
     // (the two-rows level-1 kernels of d >= 17 carry two chunks per wave: twice the chunks for a wave on every SIMD)
-    const long waves = (d >= 17 && ctx->wc_rows2) ? 2048 : 1024;
+    const long waves = (rc2_covers<T>(d) && ctx->wc_rows2) ? 2048 : 1024;
     long lw = ctx->chunk > 0 ? ctx->chunk : (sa.N + waves - 1) / waves;
     if (ctx->chunk <= 0) lw = lw < 16 ? 16 : (lw > 64 ? 64 : lw);
     a.Lw = (int)lw;
@@ -2280,13 +2280,13 @@ static int scan_blocked(pgps_ctx* ctx, int d, int which, long n, Real* data, Rea
 // Which scan runs over n chain totals: the blocked one (in place, a handful of launches: pgps_rc.hip.h) or one launch per
 // Kogge-Stone level (ping-pong between the two buffers).  A pure function of the context's setting and n, so the three
 // phases of a segment pass agree on where the result lives.
-static inline bool scan_is_blocked(const pgps_ctx* ctx, long n, int batch) {
-    return batch <= 1 && (ctx->rc_scan == 1 || (ctx->rc_scan < 0 && n >= 64));
+static inline bool scan_is_blocked(const pgps_ctx* ctx, long n, int batch, int d) {
+    return batch <= 1 && d <= kScanBlockedDimMax && (ctx->rc_scan == 1 || (ctx->rc_scan < 0 && n >= 64));
 }
 // inclusive scan of the n records in A (B: second buffer / scratch); *res = where the result is
 template <typename Real>
 static int ks_scan(pgps_ctx* ctx, int d, int which, long n, Real* A, Real* B, Real** res, int batch = 1, long bstride = 0) {
-    if (scan_is_blocked(ctx, n, batch)) {
+    if (scan_is_blocked(ctx, n, batch, d)) {
         *res = A;
         return scan_blocked(ctx, d, which, n, A, B);
     }
@@ -2322,8 +2322,8 @@ struct SegInfo {
 
 // number of Kogge-Stone steps over n records, and the buffer the result ends up in
 template <typename Real>
-static inline Real* ks_result(const pgps_ctx* ctx, long n, Real* A, Real* B) {
-    if (scan_is_blocked(ctx, n, 1)) return A;
+static inline Real* ks_result(const pgps_ctx* ctx, int d, long n, Real* A, Real* B) {
+    if (scan_is_blocked(ctx, n, 1, d)) return A;
     int steps = 0;
     for (long s = 1; s < n; s *= 2) ++steps;
     return (steps & 1) ? B : A;
@@ -2351,7 +2351,7 @@ static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgsT<Real> a, Mode mode, Real* a
         return PGPS_OK;
     }
     if (mode == MODE_SEG_FILTER) {
-        Real* pre = ks_result(ctx, a.nchunk, aggA, aggB);
+        Real* pre = ks_result(ctx, d, a.nchunk, aggA, aggB);
         if (!a.seg_first) {
             // everything before this segment, combined into every local prefix (and the entry state of chain 0)
             if ((rcode = seg_carry(ctx, d, 0, sg.gathered_f, sg.rank, sg.nranks, rf, sg.carry_rec))) return rcode;
@@ -2375,7 +2375,7 @@ static int scan_rc_seg(pgps_ctx* ctx, int d, RcArgsT<Real> a, Mode mode, Real* a
         return PGPS_OK;
     }
     // MODE_SEG_SMOOTHER
-    Real* suf = ks_result(ctx, a.nchunk, saggA, saggB);
+    Real* suf = ks_result(ctx, d, a.nchunk, saggA, saggB);
     if (!a.seg_last) {
         if ((rcode = seg_carry(ctx, d, 1, sg.gathered_s, sg.rank, sg.nranks, rs, sg.cb_rec))) return rcode;
         Real* other = suf == saggA ? saggB : saggA;

@@ -10,6 +10,16 @@ namespace wc {
 __host__ __device__ inline int nfilt(int d) { return 3 * d * d + 2 * d; }
 __host__ __device__ inline int nsmth(int d) { return 2 * d * d + d; }
 
+// The two-rows level-1 kernels (pgps_rc2.hip.h) pass operands between lanes in registers (DPP broadcasts,
+// v_permlane16_swap): they are used -- and compiled -- only where they need NO scratch memory (tools/scratch_gate.py, DESIGN.md
+// section 4k: a register spilled or reloaded under a partial EXEC mask does not carry the inactive lanes' values, and a
+// later cross-lane read of such a lane returns garbage; the one wrong result this family ever produced came from a kernel
+// with 444 B of scratch).  fp64 spills from d = 24 (140 B per lane in rc2_apply1 at d = 24 .. 1676 B at d = 32), fp32 at
+// d = 32 (80 B): those dimensions run on the LDS-tile kernels of pgps_wc.hip, which exchange operands through LDS.
+constexpr int kRc2MaxF64 = 23, kRc2MaxF32 = 31;
+template <typename T>
+__host__ __device__ constexpr bool rc2_covers(int d) { return d >= 17 && d <= (sizeof(T) == 8 ? kRc2MaxF64 : kRc2MaxF32); }
+
 // ---- kernel arguments ------------------------------------------------------------------------------
 template <typename T>
 struct WcArgs {

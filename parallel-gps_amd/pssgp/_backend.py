@@ -170,6 +170,14 @@ class Context:
         level-1 kernels (fp32, 5 <= d <= 8)."""
         check(self, self.lib.pgps_set_family(self.handle, int(family)), "pgps_set_family")
 
+    def set_f32_policy(self, policy):
+        """float32 series through a smoother (pkfs / pks): 0 = fp64 arithmetic on the float32 arrays where the grid is too
+        dense for float32 arithmetic (probed per call on the device; always above d = 16), 1 = float32 arithmetic whatever
+        the grid, 2 = always fp64 arithmetic.  `status()` & 4 tells whether a call was promoted."""
+        if not hasattr(self.lib, "pgps_set_f32_policy"):
+            raise RuntimeError("this libpgps has no pgps_set_f32_policy")
+        check(self, self.lib.pgps_set_f32_policy(self.handle, int(policy)), "pgps_set_f32_policy")
+
     def set_block(self, lanes):
         """Lanes per workgroup of the lane-chunk kernels: 0 = automatic, 128, 256 (pgps_set_block)."""
         check(self, self.lib.pgps_set_block(self.handle, int(lanes)), "pgps_set_block")

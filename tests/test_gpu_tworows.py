@@ -53,6 +53,29 @@ def test_two_rows_random_models(d):
         ctx.set_chunk(0)
 
 
+@pytest.mark.parametrize("d", [23, 24, 27, 29, 32])
+def test_large_dimensions_long_series_against_the_c_oracle(d):
+    """2^15 steps at the top of the range against oracle/kalman_seq.c -- d = 23 is the last dimension the two-rows kernels
+    serve in fp64, 24 .. 32 run on the LDS-tile kernels since round 4 (their two-rows kernels needed scratch memory:
+    pgps_wc_args.h, tools/scratch_gate.py; the one wrong result of this family, at the first two-rows commit, was a d = 32
+    kernel with 444 B of it -- tools/d32_ghost.py reproduces it from that commit's library)."""
+    from oracle import c_oracle as C
+    from pssgp import _backend as B
+    rng = np.random.default_rng(5100 + d)
+    F, P, H = _random_model(rng, d)
+    n = 1 << 15
+    t = make_times(n, seed=3 * d)
+    ssm = _ssm(F, P, H, t, 0.2)
+    y = sample_series(ssm, seed=d, nan_frac=0.2)
+    cf, cP, cs, csP, cll = C.kfs(ssm, y, np.float64)
+    got = _all(B, ssm, y)
+    assert relerr(got["fms"], cf) < 1e-8 and relerr(got["fPs"], cP) < 1e-8
+    assert relerr(got["sms"], cs) < 1e-8 and relerr(got["sPs"], csP) < 1e-8
+    assert abs(got["ll"][0] - cll) <= 1e-9 * abs(cll)
+    fms, fPs, ll = B.pkf(ssm, y, return_loglikelihood=True)
+    assert relerr(fms, cf) < 1e-8 and relerr(fPs, cP) < 1e-8 and abs(float(ll) - cll) <= 1e-9 * abs(cll)
+
+
 @pytest.mark.parametrize("d", [18, 22, 29])
 def test_two_rows_equal_the_lds_tile_kernels(d, monkeypatch):
     from pssgp import _backend as B
@@ -90,4 +113,15 @@ def test_two_rows_float32(d):
     ssm32 = tuple(np.asarray(a, np.float32) for a in ssm)
     got = _all(B, ssm32, y.astype(np.float32))
     assert got["sms"].dtype == np.float32
-    _close(got, _want(ssm, y), 2e-3, f"d={d} float32")
+    # (since round 4 float32 smoother calls above d = 16 compute in fp64 on the float32 arrays: the north star's 1e-3)
+    _close(got, _want(ssm, y), 1e-3, f"d={d} float32")
+    assert B.get_context().status() & 4
+    # the float32 arithmetic of the two-rows kernels themselves, on request (2e-3 on this grid: what round 3 asserted)
+    ctx = B.get_context()
+    ctx.set_f32_policy(1)
+    try:
+        native = _all(B, ssm32, y.astype(np.float32))
+        assert not (ctx.status() & 4)
+    finally:
+        ctx.set_f32_policy(0)
+    _close(native, _want(ssm, y), 2e-3, f"d={d} float32 arithmetic")
