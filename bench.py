@@ -97,6 +97,12 @@ def parse():
     ap.add_argument("--event-every", type=int, default=8,
                     help="hipEvent-time every n-th launch of the dominant kernel inside the timed region")
     ap.add_argument("--nan-frac", type=float, default=0.0)
+    ap.add_argument("--grid", default="baseline", choices=["baseline", "reference"],
+                    help="time stamps: BASELINE's irregular steps of ~0.05 (default) or the reference's own benchmark grid "
+                         "np.linspace(0, 4, N) (toy_models/common.py:31-32) -- dense: float32 smoother calls are promoted there")
+    ap.add_argument("--f32-policy", type=int, default=0, choices=[0, 1, 2],
+                    help="float32 series: 0 automatic promotion to fp64 arithmetic on dense grids, 1 never, 2 always "
+                         "(pgps_set_f32_policy)")
     args = ap.parse_args()
     if args.scaling == "auto":
         args.scaling = "strong" if args.gpus > 1 else "weak"
@@ -336,18 +342,32 @@ def allgather_latency(ctx, d, dtype_t, dev, stream, world, n=100):
     return out
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources (csrc/*.hip, *.h): what a committed PMC figure was measured on (tools/pmc_traffic.py
+    stamps its entries with it; a figure whose stamp differs from the tree's is reported with traffic_stale = true)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "parallel-gps_amd", "csrc", "*.h*"))):
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic(key, slot):
-    """HBM-side bytes per launch of `slot` for workload `key` from the newest committed PMC summary that has it
-    (profiles/r*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 * FETCH + WRITE)."""
+    """(bytes, source, stale): HBM-side bytes per launch of `slot` for workload `key` from the newest committed PMC
+    summary that has it (profiles/r*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    fetch_factor * FETCH + WRITE); stale = the kernels have changed since it was collected (or it carries no stamp)."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             with open(path) as fh:
                 tj = json.load(fh)
             if key in tj and slot in tj[key]:
-                return tj[key][slot]["traffic_bytes"], f"profiles/{os.path.basename(path)} (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+                stale = tj[key].get("_kernel_source_sha") != kernel_source_sha()
+                return (tj[key][slot]["traffic_bytes"],
+                        f"profiles/{os.path.basename(path)} (rocprofv3 --pmc, fetch_factor*FETCH_SIZE + WRITE_SIZE)", stale)
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 def main():
@@ -405,6 +425,8 @@ def main():
     noise = 0.1
     rng = np.random.default_rng(0)
     ts_all = np.cumsum(0.05 * rng.uniform(0.5, 1.5, size=n_total))
+    if args.grid == "reference":
+        ts_all = np.linspace(0.0, 4.0, n_total)
     lo, hi = rank * n_local, (rank + 1) * n_local
     ts = ts_all[lo:hi]
     t_prev = 0.0 if rank == 0 else float(ts_all[lo - 1])
@@ -420,6 +442,8 @@ def main():
     ctx.set_dma(args.dma)
     ctx.set_rc_scan(args.rc_scan)
     ctx.set_single_pass(args.single_pass, 0)
+    if args.f32_policy:
+        ctx.set_f32_policy(args.f32_policy)
 
     def dev_from(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -617,6 +641,7 @@ def main():
     ctx.profile_enable(0)
 
     ll_val = float(ll_d[0].item())
+    status_flags = ctx.status()         # bit 2: float32 calls of this run ran in fp64 arithmetic (dense grid / policy)
 
     # ---- roofline of the dominant kernel -----------------------------------------------------
     dom_ms, dom_n = prof[dominant]
@@ -632,9 +657,25 @@ def main():
     achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     alg_bytes_step = (7 * d * d + 3 * d + 1) * w
     # HBM-side bytes per launch of the dominant kernel from the committed PMC profile of this workload
-    traffic, traffic_src = None, None
-    if world == 1 and not args.chunk and args.stage < 0 and args.family == 0 and args.path == "lgssm":
-        traffic, traffic_src = committed_traffic(f"{args.kernel}_{suf}_log2n{args.log2n}", dominant)
+    traffic, traffic_src, traffic_stale = None, None, None
+    default_cfg = (world == 1 and not args.chunk and args.stage < 0 and args.family == 0 and args.path == "lgssm"
+                   and args.grid == "baseline" and not args.f32_policy)
+    tkey = f"{args.kernel}_{suf}_log2n{args.log2n}"
+    if default_cfg:
+        traffic, traffic_src, traffic_stale = committed_traffic(tkey, dominant)
+    # every launch slot of the pass against the bytes of the contract it touches itself (two slots within a few per cent of
+    # each other swap the `dominant` role from box to box: read them side by side)
+    slots = {}
+    for sname, fn in SLOT_BYTES.items():
+        ms_tot, n_l = breakdown.get(sname, (0.0, 0))
+        if not n_l:
+            continue
+        ms_pass = ms_tot / n_break
+        ab = fn(d, w) * n_local
+        tb = committed_traffic(tkey, sname) if default_cfg else (None, None, None)
+        slots[sname] = {"ms_per_pass": ms_pass, "launches_per_pass": n_l / n_break, "alg_bytes": ab,
+                        "frac": ab / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_pass > 0 else 0.0,
+                        "traffic": tb[0], "traffic_stale": tb[2]}
     whole_gbps = alg_bytes_step * n_total * args.steps / (gpu_ms * 1e-3) / 1e9 / world     # per GPU
 
     out = {
@@ -660,7 +701,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": dominant_symbol(dominant, d, suf, args.family, world > 1 or args.force_segments, n_local),
                      "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_source": traffic_src,
+                     "traffic_source": traffic_src, "traffic_stale": traffic_stale, "slots": slots,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_avg_s * 1e3,
                      "launches_timed": dom_n, "empty_event_pair_ms": empty_pair_ms,
                      "dominant_by": {k: round(v, 6) for k, v in per_pass.items()},
@@ -678,6 +719,8 @@ def main():
         "host_enqueue_ms_per_step": (t_enq - t0) / args.steps * 1e3,
         "gpu_event_ms_per_step": gpu_ms / args.steps,
         "log_likelihood": ll_val,
+        "grid": args.grid,
+        "f32_promoted": bool(status_flags & 4) if suf == "f32" else None,
         "chunk": ctx.get_chunk(n_local),
         # lane-chunk kernels (d <= 6): lanes per workgroup, steps per lane, workgroups of the pass that was timed
         "lane_geometry": (list(ctx.get_geometry(n_local, d)) if d <= 6 and args.family in (0, 1)

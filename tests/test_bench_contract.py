@@ -87,6 +87,13 @@ def test_one_gpu_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["launches_timed"] == 5                 # a short timed region samples every launch of the dominant kernel
+    # every launch slot side by side (two slots within a few per cent swap the `dominant` role from box to box), and
+    # whether the committed PMC traffic was measured on the kernels of this tree
+    assert {"k_filter_reduce", "k_filter_apply", "k_smoother_apply"} <= set(r["slots"])
+    for v in r["slots"].values():
+        assert v["ms_per_pass"] > 0 and abs(v["frac"] - v["alg_bytes"] / (v["ms_per_pass"] * 1e-3) / 1e9 / r["peak"]) < 1e-9
+    assert "traffic_stale" in r
+    assert j["f32_promoted"] is None and j["grid"] == "baseline"
     for leg in ("filter+smooth+log-lik", "log-lik only"):
         f = j["fused_path"][leg]
         assert f["ms_min"] <= f["ms_per_step"] <= f["ms_max"] and f["rounds"] >= 2
@@ -95,6 +102,16 @@ def test_one_gpu_line_has_the_contract_fields():
     c = j["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["cores"] == 1
     assert c["value"] > 0 and c["unit"] == j["unit"]
+
+
+@pytest.mark.gpu
+def test_float32_line_says_whether_it_was_promoted():
+    """BASELINE's c3 grid keeps float32 arithmetic; the reference's dense grid is promoted to fp64 arithmetic."""
+    j = _run(["--kernel", "rbf6", "--dtype", "f32", "--log2n", "15", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--main-only"])
+    assert j["dtype"] == "f32" and j["f32_promoted"] is False
+    j = _run(["--kernel", "rbf6", "--dtype", "f32", "--log2n", "15", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--main-only",
+              "--grid", "reference"])
+    assert j["f32_promoted"] is True and j["grid"] == "reference"
 
 
 @pytest.mark.gpu

@@ -37,9 +37,12 @@ def main():
             qf, qP, qs, qsP, qll = C.kfs(ssm, y, np.float32)         # the sequential filter / RTS smoother in float32
             print(f"{name:6s} {n:7d}  seq32  {relerr(qf, cf):.2e}  {relerr(qP, cP):.2e}  {relerr(qs, cs):.2e}  "
                   f"{relerr(qsP, csP):.2e}  {abs(qll - cll) / abs(cll):.2e}   (the C oracle's float32 build)", flush=True)
-            fams = [(0, "auto")] + ([(1, "lane")] if d <= 6 else []) + [(3, "rows")] + ([(4, "quad")] if 5 <= d <= 8 else [])
+            # "f32": float32 arithmetic whatever the grid (pgps_set_f32_policy 1: what rounds 1-3 did), by kernel family;
+            # "auto": the default since round 4 -- dense grids are computed in fp64 on the float32 arrays
+            fams = [(0, "f32"), (-1, "auto")] + ([(1, "lane")] if d <= 6 else []) + [(3, "rows")] + ([(4, "quad")] if 5 <= d <= 8 else [])
             for fam, label in fams:
-                ctx.set_family(fam)
+                ctx.set_family(max(fam, 0))
+                ctx.set_f32_policy(0 if fam < 0 else 1)
                 try:
                     ssm32 = tuple(np.asarray(a, np.float32) for a in ssm)
                     sms, sPs, fms, fPs, ll = B.pkfs(ssm32, np.asarray(y, np.float32), return_filtered=True, return_loglikelihood=True)
@@ -49,6 +52,7 @@ def main():
                     print(f"{name:6s} {n:7d}  {label:5s}  {e}", flush=True)
                 finally:
                     ctx.set_family(0)
+                    ctx.set_f32_policy(0)
 
 
 if __name__ == "__main__":

@@ -67,11 +67,19 @@ def main():
                                "reports half the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section) -- "
                                "factor 2; kernels with direct record accesses are calibrated on their reduce kernel's known read "
                                "volume (see tools/pmc_traffic.py)")
+    # what the figures were measured on: bench.py reports traffic_stale = true once the kernels have changed
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from bench import kernel_source_sha
+        entry["_kernel_source_sha"] = kernel_source_sha()
+    except Exception:                   # noqa: BLE001
+        pass
     doc[key] = entry
     text = json.dumps(doc, indent=1)
     if out_path:
         open(out_path, "w").write(text + "\n")
-    print(json.dumps({key: {k: v["traffic_bytes"] for k, v in entry.items()}}))
+    print(json.dumps({key: {k: v["traffic_bytes"] for k, v in entry.items() if isinstance(v, dict)}}))
 
 
 if __name__ == "__main__":
