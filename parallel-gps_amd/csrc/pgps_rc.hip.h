@@ -1518,7 +1518,11 @@ __global__ __launch_bounds__(B * 16) void rc_scan_blk_f(long n, Real* data, Real
     Real* rg = data + (cv ? c : 0) * nf;
     ld_filt<D>(rg, ok, lane, A2, C2, J2, b2, e2);
     Real* mine = recs + (size_t)row * nf;
-    for (int s = 1; s < B; s <<= 1) {
+    // records in this block: a level whose stride reaches past them changes nothing -- a block of four totals (the second
+    // pass over a short series' chains) runs two levels, not log2(B) (a level is the latency of one combine: 4.7 us at d = 6)
+    const long left = n - (long)blockIdx.x * B;
+    const int nvalid = left < B ? (int)left : B;
+    for (int s = 1; s < nvalid; s <<= 1) {
         if (lv) st_filt<D>(mine, true, lane, A2, C2, J2, b2, e2);
         __syncthreads();
         const bool have = row >= s;
@@ -1537,7 +1541,7 @@ __global__ __launch_bounds__(B * 16) void rc_scan_blk_f(long n, Real* data, Real
         __syncthreads();
     }
     st_filt<D>(rg, ok, lane, A2, C2, J2, b2, e2);
-    if (row == B - 1 && lv) st_filt<D>(tot + (long)blockIdx.x * nf, true, lane, A2, C2, J2, b2, e2);
+    if (row == nvalid - 1 && lv) st_filt<D>(tot + (long)blockIdx.x * nf, true, lane, A2, C2, J2, b2, e2);
 }
 
 template <typename Real, int D, int B>
@@ -1560,7 +1564,9 @@ __global__ __launch_bounds__(B * 16) void rc_scan_blk_s(long n, Real* data, Real
     ld_rec_mat<D>(rg, ok, lane, Ea); ld_rec_mat<D>(rg + dd, ok, lane, La);
     if (ok) ga = rg[2 * dd + lane];
     Real* mine = recs + (size_t)row * ns;
-    for (int s = 1; s < B; s <<= 1) {
+    const long left = n - (long)blockIdx.x * B;
+    const int nvalid = left < B ? (int)left : B;           // (see rc_scan_blk_f)
+    for (int s = 1; s < nvalid; s <<= 1) {
         if (lv) { st_rec_mat<D>(mine, true, lane, Ea); st_rec_mat<D>(mine + dd, true, lane, La); mine[2 * dd + lane] = ga; }
         __syncthreads();
         const bool have = row + s < B;

@@ -8,7 +8,7 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "parallel-gps_amd"))
-from pssgp.kernels import Matern32, Matern52, RBF, Periodic
+from pssgp.kernels import Matern32, Matern52, RBF, Periodic, SquaredExponential
 from pssgp.model import StateSpaceGP
 
 
@@ -27,9 +27,9 @@ def make(name):
     elif name.startswith("rbf15"):
         k = RBF(1., 0.5, order=15, balancing_iter=10)
     elif name.startswith("per2"):
-        k = Periodic(RBF(1., 1.), period=1., order=2)
+        k = Periodic(SquaredExponential(1., 1.), period=1., order=2)
     elif name.startswith("c5"):
-        k = Periodic(RBF(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.)
+        k = Periodic(SquaredExponential(1., 1.), period=1., order=1) * Matern32(1., 1.) + Matern52(1., 1.)
     else:
         k = Matern32(1., 0.5)
     return StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=0.1, parallel=True), t
