@@ -200,3 +200,39 @@ def random_segments_case(seed):
 @pytest.mark.parametrize("seed", range(10))
 def test_random_segments(seed):
     random_segments_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_adjoint_statistics(seed):
+    """pgps_lti_ll_grad_f64 on random stable models of random state dimension (2..32: row-cooperative kernels up to 16, the
+    wave-cooperative ones above and -- forced -- below), random lengths ragged against random chain lengths, missing
+    observations: log-likelihood and the model's adjoints against the numpy reverse sweep (oracle/np_grad.py)."""
+    from oracle import np_grad as G
+    from pssgp import _backend as B
+    rng = np.random.default_rng(7000 + seed)
+    ctx = B.get_context()
+    try:
+        for case in range(5):
+            d = int(rng.integers(2, 33))
+            n = int(rng.choice([1, 2, 3, 5, 17, 33, 64, 100, 257, 700, 1500]))
+            chunk = int(rng.choice([0, 1, 2, 3, 5, 8, 13, 32, 100]))
+            family = int(rng.choice([0, 0, 2]))
+            F, P, H = _random_model(rng, d)
+            t = make_times(n, seed=seed * 100 + case)
+            y = np.sin(t) + 0.3 * rng.standard_normal(n)
+            if n > 3:
+                y[rng.uniform(size=n) < float(rng.choice([0.0, 0.2, 0.6]))] = np.nan
+            if np.all(np.isnan(y)):
+                y[0] = 0.1
+            ctx.set_family(family)
+            ctx.set_chunk(chunk)
+            dev = B.lti_ll_grad(F, P, H.reshape(-1), 0.2, t, y)
+            ref = G.ll_grad_stats(F, P, H.reshape(-1), 0.2, t, y)
+            tag = f"seed={seed} d={d} n={n} chunk={chunk} family={family}"
+            assert abs(dev[0] - ref[0]) <= 1e-8 * abs(ref[0]) + 1e-12, tag
+            for name, a, b in zip(("Abar", "Ubar", "Hbar", "Rbar"), dev[1:], ref[1:]):
+                err = float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) / max(1e-6, float(np.max(np.abs(b))))
+                assert err < 1e-7, (tag, name, err)
+    finally:
+        ctx.set_family(0)
+        ctx.set_chunk(0)
