@@ -549,11 +549,25 @@ class StateSpaceGP:
         if memo is not None and memo[2] is self.kernel and memo[0] == key:
             prepared = memo[1]
         else:
-            try:
-                sde, grads = sde_with_grads(self.kernel)
-            except (NotImplementedError, ZeroDivisionError, FloatingPointError):
-                sde = None
             prepared = None
+            scaled = self._rbf_scaled_sde()
+            if scaled is not None:
+                # a single RBF kernel near a setting whose SDE is built (the steps of an optimiser or sampler): the
+                # lengthscale is a scaling of time and the variance one of Pinf, so the model AND its derivatives are
+                # written down from the reference realisation -- no polynomial roots, balancing or Lyapunov solve per step
+                k = self.kernel
+                F = np.ascontiguousarray(scaled.F, np.float64)
+                P0 = np.ascontiguousarray(scaled.P0, np.float64)
+                H = np.ascontiguousarray(np.asarray(scaled.H, np.float64).reshape(-1))
+                zF, zP, zH = np.zeros_like(F), np.zeros_like(P0), np.zeros((1, H.size))
+                by_name = {"variance": (zF, P0 / float(k.variance), zH), "lengthscales": (-F / float(k.lengthscales), zP, zH)}
+                prepared = (F, P0, H, [by_name[a] for _, a in leaf_parameters(k)])
+                sde = None
+            else:
+                try:
+                    sde, grads = sde_with_grads(self.kernel)
+                except (NotImplementedError, ZeroDivisionError, FloatingPointError):
+                    sde = None
             if sde is not None:
                 F, P0 = np.ascontiguousarray(sde.F, np.float64), np.ascontiguousarray(sde.P0, np.float64)
                 H = np.ascontiguousarray(np.asarray(sde.H, np.float64).reshape(-1))

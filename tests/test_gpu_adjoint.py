@@ -260,3 +260,22 @@ def test_gradient_ascent_on_the_adjoint_gradient():
         for (o, n), v in zip(params, x * np.exp(step)):
             setattr(o, n, float(v))
     assert last > first + 1.0
+
+
+def test_rbf_gradient_through_the_scaled_realisation():
+    """An optimiser's loop over a single RBF kernel: after the first evaluation the model and its derivatives are written
+    down from the reference realisation by time / variance scaling (no get_sde per step) -- the same gradient as the full
+    derivation gives through the oracle's reverse sweep, also after the lengthscale has left the 25 % window."""
+    from pssgp.kernels import RBF
+    from pssgp.kernels.sde_grads import sde_with_grads
+    from pssgp.model import StateSpaceGP
+    t, y = _series(500, seed=4, nan_frac=0.1)
+    k = RBF(1.1, 0.9, order=6, balancing_iter=5)
+    gp = StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=0.2, parallel=True)
+    for ell, s2 in ((0.9, 1.1), (0.93, 1.4), (1.05, 0.8), (1.6, 0.8), (0.5, 2.0)):
+        k.lengthscales, k.variance = ell, s2
+        ll, g = gp.log_likelihood_and_grad()
+        sde, grads = sde_with_grads(k)
+        ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, 0.2, t, y)
+        assert abs(float(ll) - ref[0]) <= 1e-9 * abs(ref[0])
+        assert np.max(np.abs(g - G.contract(ref, sde.H, grads))) <= 1e-7 * max(1.0, float(np.max(np.abs(g))))
