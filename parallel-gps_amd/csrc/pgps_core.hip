@@ -426,6 +426,25 @@ static __global__ void k_widen(long n, const float* in, double* out) {
 static __global__ void k_narrow(long n, const double* in, float* out) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
 }
+// up to eight arrays in one launch (blockIdx.y selects the array): the promoted float32 calls convert seven inputs and four
+// outputs, and a launch costs the host more than converting a short series does
+struct ConvJobs {
+    const void* src[8];
+    void* dst[8];
+    long n[8];
+};
+static __global__ void k_widen_many(ConvJobs j) {
+    const float* in = (const float*)j.src[blockIdx.y];
+    double* out = (double*)j.dst[blockIdx.y];
+    const long n = j.n[blockIdx.y];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (double)in[i];
+}
+static __global__ void k_narrow_many(ConvJobs j) {
+    const double* in = (const double*)j.src[blockIdx.y];
+    float* out = (float*)j.dst[blockIdx.y];
+    const long n = j.n[blockIdx.y];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
 }  // namespace pgps
 
 template <typename T>
@@ -561,15 +580,27 @@ static int f32_run_wide(pgps_ctx* ctx, int d, const ScanArgs<float>& a, Mode mod
         if (rc_) return rc_;
         w[i] = (double*)ctx->wide[i].p;
     }
-    auto grid = [](size_t m) { return dim3((unsigned)std::min<size_t>(8192, (m + 255) / 256)); };
-    auto widen = [&](const float* src, int i) {
-        if (src) hipLaunchKernelGGL(pgps::k_widen, grid(sizes[i]), dim3(256), 0, ctx->stream, (long)sizes[i], src, w[i]);
+    // one conversion launch in, one out
+    auto convert = [&](bool widen_dir, std::initializer_list<std::pair<const void*, int>> jobs) {
+        pgps::ConvJobs cj{};
+        int nj = 0;
+        size_t most = 0;
+        for (auto& jb : jobs) {
+            if (!jb.first) continue;
+            const int i = jb.second;
+            cj.src[nj] = widen_dir ? jb.first : (const void*)w[i];
+            cj.dst[nj] = widen_dir ? (void*)w[i] : const_cast<void*>(jb.first);
+            cj.n[nj] = (long)sizes[i];
+            most = std::max(most, sizes[i]);
+            ++nj;
+        }
+        if (!nj) return;
+        const dim3 g((unsigned)std::min<size_t>(4096, (most + 255) / 256), (unsigned)nj);
+        if (widen_dir) hipLaunchKernelGGL(pgps::k_widen_many, g, dim3(256), 0, ctx->stream, cj);
+        else hipLaunchKernelGGL(pgps::k_narrow_many, g, dim3(256), 0, ctx->stream, cj);
     };
-    auto narrow = [&](float* dst, int i) {
-        if (dst) hipLaunchKernelGGL(pgps::k_narrow, grid(sizes[i]), dim3(256), 0, ctx->stream, (long)sizes[i], (const double*)w[i], dst);
-    };
-    widen(a.P0, 0); widen(a.H, 1); widen(a.Fs, 2); widen(a.Qs, 3); widen(a.ys, 4);
-    if (mode == MODE_PKS) { widen(a.fms, 5); widen(a.fPs, 6); }
+    if (mode == MODE_PKS) convert(true, {{a.P0, 0}, {a.H, 1}, {a.Fs, 2}, {a.Qs, 3}, {a.ys, 4}, {a.fms, 5}, {a.fPs, 6}});
+    else convert(true, {{a.P0, 0}, {a.H, 1}, {a.Fs, 2}, {a.Qs, 3}, {a.ys, 4}});
     ScanArgs<double> b{};
     b.N = a.N; b.seg_first = 1; b.seg_last = 1;
     b.P0 = a.P0 ? w[0] : nullptr; b.H = a.H ? w[1] : nullptr; b.R = (double)a.R;
@@ -577,8 +608,8 @@ static int f32_run_wide(pgps_ctx* ctx, int d, const ScanArgs<float>& a, Mode mod
     b.fms = w[5]; b.fPs = w[6]; b.sms = w[7]; b.sPs = w[8]; b.ll = a.ll;
     int rc_ = dispatch_scan<double>(ctx, d, b, mode);
     if (rc_) return rc_;
-    if (mode != MODE_PKS) { narrow(a.fms, 5); narrow(a.fPs, 6); }
-    narrow(a.sms, 7); narrow(a.sPs, 8);
+    if (mode != MODE_PKS) convert(false, {{a.fms, 5}, {a.fPs, 6}, {a.sms, 7}, {a.sPs, 8}});
+    else convert(false, {{a.sms, 7}, {a.sPs, 8}});
     HIPCHK(ctx, hipGetLastError());
     ctx->host_flags |= PGPS_STATUS_F32_PROMOTED;
     return PGPS_OK;
