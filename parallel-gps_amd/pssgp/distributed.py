@@ -70,6 +70,15 @@ def _run_tag(run_id):
     return hashlib.sha256(str(run_id).encode()).digest()[:16]
 
 
+def _unique_launch(run_id):
+    """True when `run_id` (or the launcher's variables) actually distinguishes this launch from the one before it at the
+    same path: plain `torchrun` gives TORCHELASTIC_RUN_ID = 'none' and the same address / port every time."""
+    if run_id is not None:
+        return True
+    rid = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    return bool(os.environ.get("SLURM_JOB_ID")) or (rid not in ("", "none"))
+
+
 def share_unique_id(rank, path=None, broadcast=None, timeout=120.0, run_id=None):
     """The communicator id of rank 0 on every rank.  Either `broadcast(bytes_or_None) -> bytes` (whatever the launcher
     offers: MPI bcast, a torch.distributed / TCP store, ...) or a file all ranks can see (`path`, written atomically
@@ -84,6 +93,11 @@ def share_unique_id(rank, path=None, broadcast=None, timeout=120.0, run_id=None)
     elif path is not None:
         tag = _run_tag(run_id)
         want = len(_UID_MAGIC) + len(tag) + _backend.COMM_ID_BYTES
+        # Without a launch id that differs from run to run the tag cannot tell this run's file from one a crashed run left
+        # behind: readers then also require the file to be YOUNGER than their own start (rank 0 writes after it started,
+        # the ranks start within minutes of each other: 300 s of slack), so an id left long ago is never joined -- ncclCommInitRank on a dead id would hang.
+        started = time.time() - 1.0
+        fresh_only = not _unique_launch(run_id)
         if rank == 0:
             tmp = f"{path}.tmp.{os.getpid()}"
             with open(tmp, "wb") as fh:
@@ -95,7 +109,8 @@ def share_unique_id(rank, path=None, broadcast=None, timeout=120.0, run_id=None)
                 try:
                     with open(path, "rb") as fh:
                         blob = fh.read()
-                    if len(blob) == want and blob.startswith(_UID_MAGIC + tag):
+                    if len(blob) == want and blob.startswith(_UID_MAGIC + tag) and \
+                            (not fresh_only or os.path.getmtime(path) >= started - 300.0):
                         uid = blob[len(_UID_MAGIC) + len(tag):]
                         break
                 except FileNotFoundError:
