@@ -175,37 +175,32 @@ def sample_prior_observations(P0, Fs, Qs, H, R, rng):
     return b @ h + np.sqrt(R) * rng.standard_normal(n)
 
 
-def dominant_symbol(slot, d, suf, family, segments, n_local):
-    """The device function(s) behind a timing slot (slots are named after the lane-chunk kernels): mirrors
-    dispatch_scan in csrc/pgps_core.hip.  `segments`: the multi-GPU protocol (pgps_seg_*) is what runs."""
-    rc_names = {"k_filter_reduce": "pgps::rc::rc_reduce1<{t}, {d}> + rc_ks_filter<{t}, {d}> levels",
-                "k_filter_apply": "pgps::rc::rc_apply1<{t}, {d}, ...>",
-                "k_smoother_reduce": "pgps::rc::rc_ks_smoother<{t}, {d}> levels",
-                "k_smoother_apply": "pgps::rc::rc_smooth1<{t}, {d}, false>"}
-    wc_names = {"k_filter_reduce": "pgps::wc::wc_reduce1/2 + wc_ks_filter levels", "k_filter_apply": "pgps::wc::wc_apply1",
-                "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels", "k_smoother_apply": "pgps::wc::wc_smooth1"}
+def dominant_symbol(slot, d, suf, fam):
+    """The device function(s) behind a timing slot (slots are named after the lane-chunk kernels), from the family the
+    LIBRARY says the call runs on (pgps_get_family: PGPS_FAMILY_* of include/pgps.h) -- no copy of its dispatch rule here."""
     t = "double" if suf == "f64" else "float"
-    quad_auto = d == 8 or (d == 6 and not segments and (n_local <= (3 << 17) or n_local >= (3 << 19)))
-    if suf == "f32" and ((family == 4 and 5 <= d <= 8) or (family == 0 and quad_auto)):
+    if fam == 4:
         return {"k_filter_reduce": f"pgps::qc::q_reduce1<{d}> + the scan of the chain totals (rc_scan_blk_f / rc_ks_filter<float, {d}>)",
                 "k_filter_apply": f"pgps::qc::q_apply1<{d}, ...>",
                 "k_smoother_reduce": f"the scan of the smoothing totals (rc_scan_blk_s / rc_ks_smoother<float, {d}>)",
                 "k_smoother_apply": f"pgps::qc::q_smooth1<{d}>"}[slot]
-    rc_auto = (d > 6) if (segments or suf == "f32") else (d >= 5)
-    if 2 <= d <= 16 and (family == 3 or (family == 0 and rc_auto)):
-        return rc_names[slot].format(t=t, d=d)
-    if family == 2 or (family in (0, 3) and d > 6):
-        if d > 16 and os.environ.get("PGPS_WC_ROWS2", "15") != "0":
-            # the two-rows level-1 kernels (csrc/pgps_rc2.hip.h), one instantiation per d >= 18; levels 2 and 3 stay wc_*
-            dp = max(d, 18)
-            return {"k_filter_reduce": f"pgps::rc2::rc2_reduce1<{t}, {dp}> + pgps::wc::wc_reduce2 + rc2_ks_filter levels + wc_enter1",
-                    "k_filter_apply": f"pgps::rc2::rc2_apply1<{t}, {dp}, ...>",
-                    "k_smoother_reduce": "pgps::wc::wc_sreduce2 + rc2_ks_smoother levels + wc_senter1",
-                    "k_smoother_apply": f"pgps::rc2::rc2_smooth1<{t}, {dp}, ...>"}[slot]
-        return wc_names[slot]
-    # lane-chunk kernels: whole-series calls run the 128-lane build (suffix _n) except d <= 3 from 2^22 steps
-    narrow = not (d <= 3 and n_local >= (1 << 22))
-    return f"pgps::{slot}{'_n' if narrow else ''}<{t}, {d}, ...>"
+    if fam == 3:
+        return {"k_filter_reduce": "pgps::rc::rc_reduce1<{t}, {d}> + the scan of the chain totals (rc_scan_blk_f / rc_ks_filter<{t}, {d}>)",
+                "k_filter_apply": "pgps::rc::rc_apply1<{t}, {d}, ...>",
+                "k_smoother_reduce": "the scan of the smoothing totals (rc_scan_blk_s / rc_ks_smoother<{t}, {d}>)",
+                "k_smoother_apply": "pgps::rc::rc_smooth1<{t}, {d}, false>"}[slot].format(t=t, d=d)
+    if fam == 5:
+        # the two-rows level-1 kernels (csrc/pgps_rc2.hip.h), one instantiation per d >= 18; levels 2 and 3 stay wc_*
+        dp = max(d, 18)
+        return {"k_filter_reduce": f"pgps::rc2::rc2_reduce1<{t}, {dp}> + pgps::wc::wc_reduce2 + rc2_ks_filter levels + wc_enter1",
+                "k_filter_apply": f"pgps::rc2::rc2_apply1<{t}, {dp}, ...>",
+                "k_smoother_reduce": "pgps::wc::wc_sreduce2 + rc2_ks_smoother levels + wc_senter1",
+                "k_smoother_apply": f"pgps::rc2::rc2_smooth1<{t}, {dp}, ...>"}[slot]
+    if fam == 2:
+        return {"k_filter_reduce": "pgps::wc::wc_reduce1/2 + wc_ks_filter levels", "k_filter_apply": "pgps::wc::wc_apply1",
+                "k_smoother_reduce": "pgps::wc::wc_sreduce2 + wc_ks_smoother levels", "k_smoother_apply": "pgps::wc::wc_smooth1"}[slot]
+    # lane-chunk kernels: the 128-lane build carries the suffix _n
+    return f"pgps::{slot}{'_n' if fam == 11 else ''}<{t}, {d}, ...>"
 
 
 def workload_name(args, d, suf, n_total, n_local, world):
@@ -642,6 +637,9 @@ def main():
 
     ll_val = float(ll_d[0].item())
     status_flags = ctx.status()         # bit 2: float32 calls of this run ran in fp64 arithmetic (dense grid / policy)
+    promoted = suf == "f32" and bool(status_flags & 4)
+    # the kernel family the timed calls ran on, as the library itself reports it (a promoted float32 call: the fp64 family)
+    fam = ctx.get_family(n_local, d, f32=(suf == "f32" and not promoted), what=3 if (world > 1 or args.force_segments) else 2)
 
     # ---- roofline of the dominant kernel -----------------------------------------------------
     dom_ms, dom_n = prof[dominant]
@@ -698,7 +696,8 @@ def main():
                    f"{world} contiguous time segments, 2 all-gathers of segment totals per pass ("
                    + ("RCCL ncclAllGather issued by libpgps on the context's stream" if use_lib_exchange
                       else f"torch.distributed {args.dist_backend}") + ")"},
-        "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": dominant_symbol(dominant, d, suf, args.family, world > 1 or args.force_segments, n_local),
+        "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": dominant_symbol(dominant, d, "f64" if promoted else suf, fam),
+                     "kernel_family": fam,
                      "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src, "traffic_stale": traffic_stale, "slots": slots,
@@ -723,9 +722,7 @@ def main():
         "f32_promoted": bool(status_flags & 4) if suf == "f32" else None,
         "chunk": ctx.get_chunk(n_local),
         # lane-chunk kernels (d <= 6): lanes per workgroup, steps per lane, workgroups of the pass that was timed
-        "lane_geometry": (list(ctx.get_geometry(n_local, d)) if d <= 6 and args.family in (0, 1)
-                          and not any(t in dominant_symbol(dominant, d, suf, args.family, world > 1 or args.force_segments, n_local) for t in ("rc::", "qc::"))
-                          else None),
+        "lane_geometry": list(ctx.get_geometry(n_local, d)) if fam in (1, 11) else None,
     }
 
     if world > 1 or args.force_segments:

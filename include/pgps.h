@@ -111,6 +111,17 @@ int pgps_get_geometry(pgps_ctx* ctx, long N, int d, int* lanes, int* steps_per_l
  * 2 or 4 = steps per lane per staged sub-tile (2: fp64 only).  Tuning / A-B knob. */
 int pgps_set_stage(pgps_ctx* ctx, int steps_per_subtile);
 int pgps_get_chunk(pgps_ctx* ctx, long n_steps, int* steps_per_lane, int* n_workgroups);
+/* Which kernel family a pkf (what = 0) / pks (1) / pkfs (2) call -- or a phase of the segment protocol (3) -- of n_steps at
+ * state dimension d will run on under the context's settings (float32 arithmetic if f32 != 0; a float32 smoother call that
+ * is promoted to fp64 arithmetic, pgps_set_f32_policy, takes the fp64 answer): what a benchmark needs to name the kernels it
+ * timed without repeating the library's dispatch rule. */
+#define PGPS_FAMILY_LANE 1          /* lane-chunk kernels, 256-lane workgroups (d <= 6) */
+#define PGPS_FAMILY_WAVE 2          /* wave-cooperative LDS-tile kernels (d <= 32) */
+#define PGPS_FAMILY_ROW 3           /* row-cooperative kernels (2 <= d <= 16) */
+#define PGPS_FAMILY_QUAD 4          /* quad-cooperative level-1 kernels under the row-cooperative driver (fp32, 5 <= d <= 8) */
+#define PGPS_FAMILY_TWO_ROWS 5      /* two-rows level-1 kernels under the wave-cooperative driver (17 <= d <= 23 fp64, <= 31 fp32) */
+#define PGPS_FAMILY_LANE_NARROW 11  /* lane-chunk kernels, 128-lane workgroups */
+int pgps_get_family(pgps_ctx* ctx, long n_steps, int d, int f32, int what, int* family);
 const char* pgps_last_hip_error(pgps_ctx* ctx);
 /* Diagnostic flags raised since the last call (synchronises; 0 = none; bit 1: a bounded look-back spin of the
  * single-pass filter gave up -- results of that pass are invalid; PGPS_STATUS_F32_PROMOTED: a float32 call ran in fp64

@@ -11,6 +11,7 @@
 
 #include "pgps_internal.h"
 #include "pgps_gradlti.h"
+#include "pgps_wc_args.h"
 
 using namespace pgps;
 
@@ -447,44 +448,63 @@ static __global__ void k_narrow_many(ConvJobs j) {
 }
 }  // namespace pgps
 
+// Which kernel family a scan call of N steps at state dimension d takes (PGPS_FAMILY_*, include/pgps.h): the ONE place
+// that decides -- dispatch_scan launches what this returns, pgps_get_family reports it (bench.py names the measured
+// kernels from it instead of repeating the rule).
 template <typename T>
-static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
+static int choose_family(const pgps_ctx* ctx, int d, long N, Mode mode) {
+    const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
     if constexpr (sizeof(T) == 4) {
         // row-cooperative family in fp32: its own instantiations (16-lane rows, v_fmac_f32_dpp), every mode; automatic
         // above the lane-chunk kernels' range (at d = 6 those still win in fp32: 0.71 against 0.85 ms at 2^20 steps)
-        const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
-        if (rc_ok && (ctx->family == 3 || ((ctx->family == 0 || ctx->family == 4) && d > PGPS_MAX_DIM_LANE))) return launch_scan_rc<float>(ctx, a, d, mode);
+        bool to_rc = rc_ok && (ctx->family == 3 || ((ctx->family == 0 || ctx->family == 4) && d > PGPS_MAX_DIM_LANE));
         // d = 6, whole-series filter / filter + smoother: the quad-cooperative kernels are ahead of the lane-chunk ones
         // except where the latter's geometry fits the chip exactly (same box, ms per pass, lane-chunk / quad:
         // 2^14 0.212 / 0.171, 2^16 0.218 / 0.192, 2^17 0.230 / 0.218, 2^18 0.286 / 0.261, 2^19 0.395 / 0.398,
         // 2^20 0.627 / 0.650, 2^21 1.266 / 1.217, 2^22 2.566 / 2.357)
         if (ctx->family == 0 && d == 6 && (mode == MODE_PKF || mode == MODE_PKFS) && ctx->chunk == 0 && ctx->stage_g < 0 &&
-            (a.N <= (3L << 17) || a.N >= (3L << 19)) && a.N >= 64)
-            return launch_scan_rc<float>(ctx, a, d, mode);
+            (N <= (3L << 17) || N >= (3L << 19)) && N >= 64)
+            to_rc = true;
         // quad-cooperative level-1 kernels under the row-cooperative driver: family 4 (fp32, 5 <= d <= 8)
         if (ctx->family == 4) {
             if (d < qc::kDimMin || d > qc::kDimMax || mode == MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;
-            return launch_scan_rc<float>(ctx, a, d, mode);
+            to_rc = true;
+        }
+        if (to_rc) {
+            // (what scan_rc_entry then decides: the quad level-1 kernels at d = 8 and, where this rule sends it there, d = 6)
+            const bool quad = (ctx->family == 4 || (ctx->family == 0 && (d == 8 || d == 6))) && d >= qc::kDimMin && d <= qc::kDimMax &&
+                              mode != MODE_PKS;
+            return quad ? PGPS_FAMILY_QUAD : PGPS_FAMILY_ROW;
         }
     }
     if constexpr (sizeof(T) == 8) {
         // row-cooperative family: fp64, d <= 16, whole-series filter / filter+smoother
         const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
-        const bool rc_ok = d >= rc::kDimMin && d <= rc::kDimMax;
         // automatic choice from d = 5: at d = 6 the lane-chunk kernels spill (2^18 steps: 1.29 ms against 0.53 ms);
         // the segment protocol (multi-GPU) moves over where the lane-chunk family ends
-        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && (whole ? d >= 5 : d > PGPS_MAX_DIM_LANE))))
-            return launch_scan_rc(ctx, a, d, mode);
+        if (rc_ok && (ctx->family == 3 || (ctx->family == 0 && (whole ? d >= 5 : d > PGPS_MAX_DIM_LANE)))) return PGPS_FAMILY_ROW;
     }
     if (ctx->family == 3) return PGPS_E_UNSUPPORTED_DIM;
-    if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) return launch_scan_wc<T>(ctx, a, d, mode);
+    if (ctx->family == 2 || (ctx->family == 0 && d > PGPS_MAX_DIM_LANE)) {
+        if (d > 32 || mode == MODE_PKS) return PGPS_E_UNSUPPORTED_DIM;
+        return (wc::rc2_covers<T>(d) && ctx->wc_rows2) ? PGPS_FAMILY_TWO_ROWS : PGPS_FAMILY_WAVE;
+    }
+    if (d < 1 || d > PGPS_MAX_DIM_LANE) return PGPS_E_UNSUPPORTED_DIM;
     // Lane-chunk family: whole-series calls run the build with 128-lane workgroups (pgps_inst.hip, PGPS_NARROW) --
     // except the long series of the LDS-staged dimensions: from 2^22 steps there are two waves per SIMD to cover each
     // other's loads, and the narrow build's prefetch registers cost it that (d = 2, 2^22 steps: 0.303 ms against 0.307 for
     // 256 lanes; 2^24: 1.28 against 1.25).  The three phases of the segment protocol follow the same rule (it depends on
     // this rank's N and d only, so they agree with each other: a rank's 2^21 steps of c4 0.152 -> 0.147 ms).
-    const bool narrow = lane_narrow(ctx, d, a.N);
-    if (narrow) {
+    return lane_narrow(ctx, d, N) ? PGPS_FAMILY_LANE_NARROW : PGPS_FAMILY_LANE;
+}
+
+template <typename T>
+static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
+    const int fam = choose_family<T>(ctx, d, a.N, mode);
+    if (fam < 0) return fam;
+    if (fam == PGPS_FAMILY_ROW || fam == PGPS_FAMILY_QUAD) return launch_scan_rc<T>(ctx, a, d, mode);
+    if (fam == PGPS_FAMILY_WAVE || fam == PGPS_FAMILY_TWO_ROWS) return launch_scan_wc<T>(ctx, a, d, mode);
+    if (fam == PGPS_FAMILY_LANE_NARROW) {
         switch (d) {
             case 1: return launch_scan_narrow<T, 1>(ctx, a, mode);
             case 2: return launch_scan_narrow<T, 2>(ctx, a, mode);
@@ -504,6 +524,16 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
         case 6: return launch_scan<T, 6>(ctx, a, mode);
         default: return PGPS_E_UNSUPPORTED_DIM;
     }
+}
+
+// `what`: 0 = pkf, 1 = pks, 2 = pkfs, 3 = a phase of the segment protocol; fp64 unless f32 != 0
+extern "C" int pgps_get_family(pgps_ctx* ctx, long N, int d, int f32, int what, int* family) {
+    if (!ctx || N < 1 || !family || what < 0 || what > 3) return PGPS_E_INVALID;
+    const Mode mode = what == 0 ? MODE_PKF : what == 1 ? MODE_PKS : what == 2 ? MODE_PKFS : MODE_SEG_FILTER;
+    const int fam = f32 ? choose_family<float>(ctx, d, N, mode) : choose_family<double>(ctx, d, N, mode);
+    if (fam < 0) return fam;
+    *family = fam;
+    return PGPS_OK;
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

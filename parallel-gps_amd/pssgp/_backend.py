@@ -170,6 +170,17 @@ class Context:
         level-1 kernels (fp32, 5 <= d <= 8)."""
         check(self, self.lib.pgps_set_family(self.handle, int(family)), "pgps_set_family")
 
+    def get_family(self, n_steps, d, f32=False, what=2):
+        """PGPS_FAMILY_* code of the kernels a pkf (what = 0) / pks (1) / pkfs (2) / segment-phase (3) call will run on
+        (1 lane-chunk 256 lanes, 11 lane-chunk 128 lanes, 2 wave-cooperative, 3 row-cooperative, 4 quad-cooperative, 5 two-rows);
+        None with a library that cannot say."""
+        if not hasattr(self.lib, "pgps_get_family"):
+            return None
+        fam = c_int(0)
+        check(self, self.lib.pgps_get_family(self.handle, c_long(int(n_steps)), c_int(int(d)), c_int(1 if f32 else 0),
+                                             c_int(int(what)), ctypes.byref(fam)), "pgps_get_family")
+        return fam.value
+
     def set_f32_policy(self, policy):
         """float32 series through a smoother (pkfs / pks): 0 = fp64 arithmetic on the float32 arrays where the grid is too
         dense for float32 arithmetic (probed per call on the device; always above d = 16), 1 = float32 arithmetic whatever
