@@ -44,6 +44,10 @@ struct pgps_ctx {
     int f32_policy = 0;                 // float32 series with a smoother: 0 = automatic promotion on dense grids, 1 = always native, 2 = always fp64 arithmetic (pgps_set_f32_policy)
     int* probe_host = nullptr;          // pinned word pair the dense-grid probe of a float32 call writes (and its device alias)
     int* probe_dev = nullptr;
+    hipEvent_t probe_ev = nullptr;      // recorded behind the probe: the host waits for the probe alone, not for the stream
+    hipEvent_t probe_in = nullptr;      // recorded on the context's stream at the call's entry: the probe's stream waits for it
+    hipStream_t probe_stream = nullptr; // the probe runs beside the call's first kernel, not in front of it
+    int f32_last_promoted = 0;          // which way the last probed call went: decides the ORDER of the next one (see pgps_core.hip)
     DevBuf wide[9];                     // fp64 copies of a promoted float32 call's arrays: P0, H, Fs, Qs, ys, fms, fPs, sms, sPs
     void* comm = nullptr;               // ncclComm_t (RCCL) of a series sharded over GPUs: pgps_comm_init (pgps_comm.hip)
     int comm_rank = 0, comm_nranks = 0;
