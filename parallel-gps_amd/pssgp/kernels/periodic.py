@@ -27,7 +27,20 @@ class SquaredExponential(Kernel):
         return self.variance * np.exp(-0.5 * r * r)
 
 
+_OFFLINE_MEMO = {}
+
+
 def _get_offline_coeffs(N):
+    """(memoised by order: the tables hold no hyper-parameter -- an optimiser's or sampler's step re-reads them)"""
+    got = _OFFLINE_MEMO.get(N)
+    if got is None:
+        got = _OFFLINE_MEMO[N] = _offline_coeffs(N)
+        for a in got:
+            a.setflags(write=False)
+    return got
+
+
+def _offline_coeffs(N):
     """Hyper-parameter-free tables (periodic.py:18-38): b[k, j] = 2 C(k, (k-j)/2) for
     j <= k with k - j even (halved at j = 0), K[k, j] = k, div_facto_K = 1 / K!."""
     idx = np.arange(N + 1)
