@@ -2083,7 +2083,9 @@ static int launch_scan_wc_impl(pgps_ctx* ctx, ScanArgs<T> sa, int d, Mode mode, 
     long kg = (a.nchunk + 511) / 512;
     // (PGPS_WC_KGROUP_MIN: diagnostic, the smallest group; read once)
     static const long kgmin_env = [] { const char* e = std::getenv("PGPS_WC_KGROUP_MIN"); return e ? std::atol(e) : 0L; }();
-    const long kgmin = kgmin_env > 0 ? kgmin_env : 4;
+    // (groups of ONE chunk up to 512 chunks: a serial in-group combine costs more than the Kogge-Stone level it saves --
+    // 32 against 26 us at d = 18 -- the CO2 kernel at its 3192 points: ll 526 -> 495 us, ll + gradient 843 -> 808 us)
+    const long kgmin = kgmin_env > 0 ? kgmin_env : 1;
     a.kgroup = (int)(kg < kgmin ? kgmin : (kg > kGroupMax ? kGroupMax : kg));
     a.ngroup = (int)((a.nchunk + a.kgroup - 1) / a.kgroup);
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
