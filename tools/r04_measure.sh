@@ -6,6 +6,13 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r04_final
 mkdir -p $O
 cd $R
+# PMC first: the bench lines below then carry traffic measured on THIS tree's kernels (traffic_stale = false)
+cd $R
+echo "{}" > $R/profiles/r04_traffic.json
+bash tools/pmc.sh pmc_c2_r04 && python3 tools/pmc_traffic.py gpurun_out/pmc_c2_r04 matern32_f64_log2n20 $R/profiles/r04_traffic.json && cp gpurun_out/pmc_c2_r04/summary.txt $O/c2_pmc_summary.txt
+bash tools/pmc.sh pmc_c3_r04 --kernel rbf6 --dtype f32 && python3 tools/pmc_traffic.py gpurun_out/pmc_c3_r04 rbf6_f32_log2n20 $R/profiles/r04_traffic.json 1.22 && cp gpurun_out/pmc_c3_r04/summary.txt $O/c3_pmc_summary.txt
+bash tools/pmc.sh pmc_c5_r04 --kernel c5 && python3 tools/pmc_traffic.py gpurun_out/pmc_c5_r04 c5_f64_log2n20 $R/profiles/r04_traffic.json && cp gpurun_out/pmc_c5_r04/summary.txt $O/c5_pmc_summary.txt
+cp $R/profiles/r04_traffic.json $O/r04_traffic.json
 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 python bench.py --kernel rbf6 --dtype f32 > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --kernel c5 --steps 50 --warmup 10 > $O/bench_c5.json 2> $O/bench_c5.err
@@ -30,9 +37,4 @@ with open(sys.argv[2],"w") as out:
         out.write("%-96s %7s %12.1f %12.1f %12.1f %8s\n"%(r["Name"][:96],r["Calls"],float(r["AverageNs"])/1e3,float(r["MinNs"])/1e3,float(r["MaxNs"])/1e3,r["Percentage"]))
 PY
 done
-cd $R
-echo "{}" > $O/r04_traffic.json
-bash tools/pmc.sh pmc_c2_r04 && python3 tools/pmc_traffic.py gpurun_out/pmc_c2_r04 matern32_f64_log2n20 $O/r04_traffic.json && cp gpurun_out/pmc_c2_r04/summary.txt $O/c2_pmc_summary.txt
-bash tools/pmc.sh pmc_c3_r04 --kernel rbf6 --dtype f32 && python3 tools/pmc_traffic.py gpurun_out/pmc_c3_r04 rbf6_f32_log2n20 $O/r04_traffic.json 1.22 && cp gpurun_out/pmc_c3_r04/summary.txt $O/c3_pmc_summary.txt
-bash tools/pmc.sh pmc_c5_r04 --kernel c5 && python3 tools/pmc_traffic.py gpurun_out/pmc_c5_r04 c5_f64_log2n20 $O/r04_traffic.json && cp gpurun_out/pmc_c5_r04/summary.txt $O/c5_pmc_summary.txt
 echo done
