@@ -14,6 +14,22 @@ from tests.conftest import make_times, relerr, sample_series
 from tests.test_gpu_fuzz import _random_model, _ssm
 
 
+def where(got, want, name):
+    """Which time steps and which state components carry the error: the steps with any entry off by > 1e-8 of the array's
+    scale, as runs, and the components wrong at the first such step."""
+    got = np.asarray(got, float).reshape(got.shape[0], -1); want = np.asarray(want, float).reshape(got.shape)
+    bad = np.abs(got - want) > 1e-8 * np.abs(want).max()
+    steps = np.flatnonzero(bad.any(axis=1))
+    if steps.size == 0:
+        print(f"      {name}: no entry off by more than 1e-8 of the scale", flush=True)
+        return
+    cut = np.flatnonzero(np.diff(steps) > 1)
+    runs = [(int(a), int(b)) for a, b in zip(np.r_[steps[0], steps[cut + 1]], np.r_[steps[cut], steps[-1]])]
+    comps = np.flatnonzero(bad[steps[0]])
+    print(f"      {name}: {steps.size} of {got.shape[0]} steps wrong, runs {runs[:6]}{' ...' if len(runs) > 6 else ''}; at step {steps[0]}: "
+          f"{comps.size} of {got.shape[1]} entries, first {comps[:12].tolist()}", flush=True)
+
+
 def run(ctxname, dims, cases):
     for d in dims:
         rng = np.random.default_rng(4200 + d)
@@ -34,6 +50,10 @@ def run(ctxname, dims, cases):
             flag = "  <-- WRONG" if max(errs) > 1e-6 else ""
             print(f"{ctxname} d={d} n={n} chunk={chunk}: fm {errs[0]:.1e} fP {errs[1]:.1e} sm {errs[2]:.1e} sP {errs[3]:.1e} ll {errs[4]:.1e}{flag}",
                   flush=True)
+            if flag:
+                where(fms, of, "fm")
+                where(fPs.reshape(n, -1), oP.reshape(n, -1), "fP")
+                where(sms, os_, "sm")
     B.get_context().set_chunk(0)
 
 
