@@ -1903,7 +1903,10 @@ int launch_rc_disc(pgps_ctx* ctx, long N, const double* F, const double* Pinf, c
                    double* Qs, int batch, long bs_model) {
     // steps per row: amortises the model load and the norm -- and, on a regular grid, the one transition matrix a row
     // computes (rc_discretise stores it again for every further step with the same dt)
-    const int per = N >= (1L << 16) ? 32 : 8;
+    // -- as long as the launch still has a wave for every SIMD: at the reference's series lengths a row that takes 8 steps
+    // one after the other is 8 Pade evaluations of latency (19 us at d = 6, N = 1000) on 32 of the chip's 1024 SIMDs
+    const long work = N * (long)(batch > 0 ? batch : 1);
+    const int per = N >= (1L << 16) ? 32 : work > (1L << 15) ? 8 : work > (1L << 14) ? 4 : work > (1L << 13) ? 2 : 1;
     const long grid = (N + 4L * per - 1) / (4L * per);
     timed_launch(ctx, PGPS_K_DISCRETISE, rc_discretise<D>, dim3((unsigned)grid, (unsigned)batch), dim3(64), 0u, N, per, F, Pinf,
                  ts, t0, Fs, Qs, bs_model);

@@ -203,6 +203,42 @@ def test_missing_data_patterns():
         _check_all(got, want, TOL64)
 
 
+@pytest.mark.parametrize("d", [2, 3, 6, 11, 18, 24])
+def test_non_stationary_tuples_follow_the_parallel_reference(d):
+    """An LGSSM tuple that does not come from a stationary SDE (F_0 P0 F_0^T + Q_0 != P0).  The reference's two paths differ
+    there and a drop-in has to differ the same way: the parallel filter takes the prior itself as the first predicted state
+    (parallel.py:13-43) but scores the first observation against F_0 P0 F_0^T + Q_0 (parallel.py:134-139); the sequential
+    filter propagates before its first update (sequential.py:16-21).  pkf / pks / pkfs against the oracle's parallel
+    restatement, kf / kfs (product host code) against its sequential one, and the two oracles must disagree."""
+    from pssgp.kalman.parallel import pkf, pkfs
+    from pssgp.kalman.sequential import kf, kfs
+    from pssgp.kalman.base import LGSSM
+    for n in (1, 2, 37, 700):
+        rng = np.random.default_rng(100 * d + n)
+        L = rng.standard_normal((d, d)) * 0.4
+        P0 = L @ L.T + 0.5 * np.eye(d)
+        Fs = np.stack([0.8 * np.eye(d) + 0.15 * rng.standard_normal((d, d)) / np.sqrt(d) for _ in range(n)])
+        Lq = rng.standard_normal((n, d, d)) * 0.2
+        Qs = Lq @ np.transpose(Lq, (0, 2, 1)) + 0.05 * np.eye(d)
+        y = rng.standard_normal(n); y[rng.uniform(size=n) < 0.2] = np.nan
+        y[0] = 0.7 if d % 2 else np.nan
+        ssm = LGSSM(P0, Fs, Qs, rng.standard_normal((1, d)), np.array([[0.3]]))
+        fms, fPs, ll = pkf(ssm, y[:, None], return_loglikelihood=True)
+        sms, sPs = pkfs(ssm, y[:, None])
+        of, oP, oll = O.pkf(ssm, y, True)
+        os_, osP = O.pkfs(ssm, y)
+        assert relerr(fms, of) < TOL64 and relerr(fPs, oP) < TOL64 and relerr(sms, os_) < TOL64 and relerr(sPs, osP) < TOL64
+        assert abs(float(ll) - oll) <= TOL64 * max(1.0, abs(oll))
+        kfm, kfP, kll = kf(ssm, y[:, None], return_loglikelihood=True)
+        ksm, ksP = kfs(ssm, y[:, None])
+        qf, qP, qll = O.kf(ssm, y, True)
+        qs, qsP = O.kfs(ssm, y)
+        assert relerr(kfm, qf) < TOL64 and relerr(kfP, qP) < TOL64 and relerr(ksm, qs) < TOL64 and relerr(ksP, qsP) < TOL64
+        assert abs(float(kll) - qll) <= TOL64 * max(1.0, abs(qll))
+        if n > 1:
+            assert relerr(of, qf) > 1e-4, "the inputs do not separate the two paths"
+
+
 def test_duplicate_times():
     """dt = 0 steps: F = I, Q = 0 (SURVEY 'semantics to preserve')."""
     from pssgp.kernels import Matern32
