@@ -25,6 +25,16 @@ def test_toy_signals_and_data():
     assert tt[0, 0] == 0.0 and tt[-1, 0] == 4.0
 
 
+def test_reference_import_paths_of_the_helpers():
+    """`from pssgp.toymodels import sinu, obs_noise` and `from pssgp.misc_utils import rmse` are what the reference's
+    experiment scripts and notebook write (experiments/toy_models/common.py:8, speed_and_stability.py:18)."""
+    from pssgp.toymodels import sinu, comp_sinu, rect, obs_noise
+    from pssgp.misc_utils import rmse
+    from pssgp.experiments import toy
+    assert sinu is toy.sinu and comp_sinu is toy.comp_sinu and rect is toy.rect and obs_noise is toy.obs_noise
+    assert rmse(np.array([[1.0], [2.0], [3.0]]), np.array([1.0, 2.0, 5.0])) == pytest.approx(np.sqrt(4.0 / 3.0))
+
+
 @pytest.mark.gpu
 def test_sequential_mesh_matches_oracle_posterior():
     """SSGP (sequential host recursion; the discretisation still runs on the GPU) cell of the mesh:
