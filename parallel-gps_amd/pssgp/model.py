@@ -536,7 +536,26 @@ class StateSpaceGP:
                 setattr(owner, name, x0)
         return rows, sizes
 
-    def _adjoint_ll_and_grad(self, wrt=None):
+    # Matern-5/2 (d = 3, three directions): above the one-launch length the dual-number pass is three launches of kernels
+    # three times as heavy as the filter's; the adjoint pass on the general-LTI kernels costs 1.5 likelihoods.  Measured
+    # (tools/grad_methods.py, one MI355X): N = 4096 199 -> 117 us, 32 768 186 -> 151 us, 131 072 320 -> 238 us; a tie at
+    # 1000; Matern-3/2 (d = 2) is better off on duals at every length (79 vs 102 us at 4096).
+    _MATERN52_ADJOINT_FROM = 2048
+
+    def _matern_prepared(self, fused):
+        """(F, Pinf, H, derivatives) of a single Matern kernel from its fused form, for the adjoint pass: the lengthscale
+        scales time (dF = -F / l) and the variance Pinf, as for RBF below -- no get_sde() per optimiser step."""
+        sde_like, (lam, N1, _) = fused
+        k = self.kernel
+        d = N1.shape[0]
+        F = np.ascontiguousarray(np.asarray(N1, np.float64) - lam * np.eye(d))
+        P0 = np.ascontiguousarray(sde_like.P0, np.float64)
+        H = np.ascontiguousarray(np.asarray(sde_like.H, np.float64).reshape(-1))
+        zF, zP, zH = np.zeros_like(F), np.zeros_like(P0), np.zeros((1, H.size))
+        by_name = {"variance": (zF, P0 / float(k.variance), zH), "lengthscales": (-F / float(k.lengthscales), zP, zH)}
+        return (F, P0, H, [by_name[a] for _, a in leaf_parameters(k)])
+
+    def _adjoint_ll_and_grad(self, wrt=None, prepared=None):
         """(ll, grad) by the adjoint pass of the general-LTI device path (pgps_lti_ll_grad_f64): the device returns the
         adjoints of the model (F, Pinf, H, R) from one filter pass and one reverse pass, pssgp.kernels.sde_grads the
         model's derivatives in a frozen state basis; exact (no differences), ONE device call, any number of parameters.
@@ -546,7 +565,9 @@ class StateSpaceGP:
         from .kernels.sde_grads import sde_with_grads
         key = self._param_key()
         memo = getattr(self, "_grads_memo", None)
-        if memo is not None and memo[2] is self.kernel and memo[0] == key:
+        if prepared is not None:
+            pass                                # the caller wrote the model and its derivatives down (Matern family)
+        elif memo is not None and memo[2] is self.kernel and memo[0] == key:
             prepared = memo[1]
         else:
             prepared = None
@@ -610,7 +631,8 @@ class StateSpaceGP:
         """(ll, grad): the marginal log-likelihood and its gradient with respect to
         `trainable_parameters()` -- what the reference obtains from tf.GradientTape over
         maximum_log_likelihood_objective (tests/test_gp_vs_kfs.py:53-78).  parallel=True.  Matern family (d <= 3):
-        ONE pass of the parallel filter on dual numbers, exact.  Every other kernel (RBF, Periodic, sums, products,
+        ONE pass of the parallel filter on dual numbers, exact (Matern-5/2 above 2048 points: the adjoint pass, which
+        is cheaper there).  Every other kernel (RBF, Periodic, sums, products,
         2 <= d <= 32): the ADJOINT pass -- one filter pass and one reverse pass on the device, exact, whatever the number
         of parameters (`_adjoint_ll_and_grad`).  `method`: None = automatic, "adjoint", "dual" (sums / products of Matern
         kernels up to d = 6 on dual numbers) or "differences" (Richardson central differences of batched likelihoods:
@@ -644,6 +666,11 @@ class StateSpaceGP:
             # no dual-number path: batched differences on the general-LTI kernels (d <= 16), one evaluation at a
             # time above that (e.g. the CO2 kernel at its reference order, d = 18)
             return self._lti_ll_and_grad(batched=lti is not None, wrt=wrt)
+        if (method in (None, "adjoint") and type(self.kernel).__name__ == "Matern52" and ts.dtype == np.float64
+                and ts.shape[0] > self._MATERN52_ADJOINT_FROM):
+            out = self._adjoint_ll_and_grad(wrt, prepared=self._matern_prepared(fused))
+            if out is not None:
+                return out
         ser = self._device_series() if ts.dtype == np.float64 else None
         if ser is not None:
             model, d, npar = _backend.pack_grad_model(self._grad_blocks())

@@ -279,3 +279,38 @@ def test_rbf_gradient_through_the_scaled_realisation():
         ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, 0.2, t, y)
         assert abs(float(ll) - ref[0]) <= 1e-9 * abs(ref[0])
         assert np.max(np.abs(g - G.contract(ref, sde.H, grads))) <= 1e-7 * max(1.0, float(np.max(np.abs(g))))
+
+
+def test_matern52_takes_the_adjoint_pass_on_long_series():
+    """Matern-5/2 above the one-launch length: the automatic gradient is the adjoint pass on the general-LTI kernels, with
+    the model and its derivatives written down from the fused form (time / variance scaling) -- the same numbers as the
+    dual-number pass (exact, 1e-9), as the oracle's reverse sweep on the kernel's own get_sde(), and at a new setting
+    every call; below that length and for Matern-3/2 the duals stay."""
+    from pssgp.kernels import Matern32, Matern52
+    from pssgp.kernels.sde_grads import sde_with_grads
+    from pssgp.model import StateSpaceGP
+    t, y = _series(6000, seed=8, nan_frac=0.1)
+    k = Matern52(1.2, 0.6)
+    gp = StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=0.15, parallel=True)
+    calls = []
+    real = gp._adjoint_ll_and_grad
+    gp._adjoint_ll_and_grad = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    for ell, s2 in ((0.6, 1.2), (0.9, 0.7), (0.35, 2.0)):
+        k.lengthscales, k.variance = ell, s2
+        ll, g = gp.log_likelihood_and_grad()
+        lld, gd = gp.log_likelihood_and_grad(method="dual")
+        assert abs(float(ll) - float(lld)) <= 1e-10 * abs(float(lld))
+        assert np.max(np.abs(np.asarray(g) - np.asarray(gd))) <= 1e-9 * max(1.0, float(np.max(np.abs(gd))))
+        sde, grads = sde_with_grads(k)
+        ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, 0.15, t, y)
+        assert np.max(np.abs(np.asarray(g) - G.contract(ref, sde.H, grads))) <= 1e-7 * max(1.0, float(np.max(np.abs(g))))
+    assert len(calls) == 3, "the automatic choice did not take the adjoint pass"
+    # only some directions
+    _, g1 = gp.log_likelihood_and_grad(wrt=[1])
+    _, gall = gp.log_likelihood_and_grad()
+    assert g1[1] == gall[1] and g1[0] == 0.0
+    # short series and Matern-3/2: dual numbers
+    for kern, n in ((Matern52(1.2, 0.6), 1500), (Matern32(1.2, 0.6), 6000)):
+        gp2 = StateSpaceGP((t[:n, None], y[:n, None]), kern, noise_variance=0.15, parallel=True)
+        gp2._adjoint_ll_and_grad = lambda *a, **kw: (_ for _ in ()).throw(AssertionError("adjoint pass taken"))
+        gp2.log_likelihood_and_grad()
