@@ -439,6 +439,18 @@ int pgps_series_gp_ll_f64(pgps_series* s, int d, double lam, const double* N1, c
 int pgps_series_gp_ll_grad_f64(pgps_series* s, int d, int np, const double* model, double* out /* 1 + np */);
 int pgps_series_gp_predict_f64(pgps_series* s, int d, double lam, const double* N1, const double* N2, const double* Pinf,
                                const double* H, double R, double* mean /* K */, double* var /* K */, double* ll /* or NULL */);
+/* Log-likelihood and the ADJOINTS of the fused model by one filter pass and one reverse pass (csrc/pgps_gpadj.hip.h; the
+ * lane-chunk twin of pgps_lti_ll_grad_*): out = [ll | Abar (d d, row-major) | Ubar (d) | Hbar (d) | Rbar], 1 + d d + 2 d + 1
+ * doubles, with  d ll / d theta = <Abar, dF> + Ubar^T dPinf H^T + Hbar . dH + Rbar dR  for every dF that commutes with F -- for
+ * the Matern family: dF = -F / lengthscale, dPinf = Pinf / variance.  What the reference takes from tf.GradientTape over
+ * maximum_log_likelihood_objective (tests/test_gp_vs_kfs.py:53-78; pssgp/kalman/parallel.py:121-152 differentiated), at
+ * the cost of about two likelihoods whatever the number of hyper-parameters.  fp64, d <= 3.  The _dev form takes device
+ * pointers ts, ys, out and is asynchronous on the context's stream. */
+int pgps_series_gp_ll_grad_adj_f64(pgps_series* s, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                                   const double* H, double R, double* out /* 1 + d d + 2 d + 1 */);
+int pgps_gp_ll_grad_adj_dev_f64(pgps_ctx* ctx, long N, int d, double lam, const double* N1, const double* N2,
+                                const double* Pinf, const double* H, double R, const double* ts, double t0, const double* ys,
+                                double* out);
 /* ... and for ANY kernel's LTI model (F, Pinf, H: host pointers; fp64, 2 <= d <= PGPS_MAX_DIM): pgps_lti_ll_f64 /
  * pgps_lti_predict_f64 / pgps_lti_ll_batch_f64 (models: B rows [F | Pinf | H | R], d <= 16) on the resident series and its
  * merged query grid -- the evaluation loop of an optimiser or sampler over an RBF / Periodic / composite kernel. */

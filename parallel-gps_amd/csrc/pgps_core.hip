@@ -93,6 +93,7 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
     if (ctx->comm_buf.p) (void)hipFree(ctx->comm_buf.p);
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
     if (ctx->stamps.p) (void)hipFree(ctx->stamps.p);
+    if (ctx->gadj.p) (void)hipFree(ctx->gadj.p);
     if (ctx->status_word) (void)hipFree(ctx->status_word);
     for (auto& b : ctx->st)
         if (b.p) (void)hipFree(b.p);
@@ -1134,6 +1135,36 @@ static int gp_dev(pgps_ctx* ctx, long N, int d, double lam, const double* N1, co
     }
 }
 
+// ll and the model's adjoints on the fused path: out = [ll | Abar (d d) | Ubar (d) | Hbar (d) | Rbar] on the device
+static int gp_adj_dev(pgps_ctx* ctx, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
+                      const double* H, double R, const double* ts, double t0, const double* ys, double* out) {
+    RoctxRange range_("parallel_filter");
+    if (!ctx || N < 1 || !N1 || !Pinf || !H || !ts || !ys || !out) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    GpArgs<double> g{};
+    g.s.N = N;
+    g.s.R = R;
+    g.s.ys = ys;
+    g.m.lam = lam;
+    for (int i = 0; i < 9; ++i) { g.m.N1[i] = 0; g.m.N2[i] = 0; g.m.Pinf[i] = 0; }
+    for (int i = 0; i < d * d; ++i) { g.m.N1[i] = N1[i]; g.m.N2[i] = N2 ? N2[i] : 0.0; g.m.Pinf[i] = Pinf[i]; }
+    for (int i = 0; i < 3; ++i) g.m.H[i] = i < d ? H[i] : 0.0;
+    g.m.ts = ts;
+    g.m.t_prev = t0;
+    switch (d) {
+        case 1: return launch_gp_adj<double, 1>(ctx, g, out);
+        case 2: return launch_gp_adj<double, 2>(ctx, g, out);
+        case 3: return launch_gp_adj<double, 3>(ctx, g, out);
+        default: return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
+
+extern "C" int pgps_gp_ll_grad_adj_dev_f64(pgps_ctx* ctx, long N, int d, double lam, const double* N1, const double* N2,
+                                           const double* Pinf, const double* H, double R, const double* ts, double t0,
+                                           const double* ys, double* out) {
+    return gp_adj_dev(ctx, N, d, lam, N1, N2, Pinf, H, R, ts, t0, ys, out);
+}
+
 template <typename T>
 static int gp_host(pgps_ctx* ctx, long N, int d, double lam, const double* N1, const double* N2, const double* Pinf,
                    const double* H, double R, const T* ts, double t0, const T* ys, T* fms, T* fPs, T* sms, T* sPs,
@@ -1514,6 +1545,21 @@ extern "C" int pgps_series_gp_ll_grad_f64(pgps_series* s, int d, int np, const d
     if (!s->zero_copy) HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, (size_t)(1 + np) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i <= np; ++i) out[i] = s->host[i];
+    return std::isfinite(out[0]) ? PGPS_OK : PGPS_E_NUMERIC;
+}
+
+// log-likelihood and the model's adjoints (the adjoint pass, pgps_gpadj.hip.h): out = 1 + d d + 2 d + 1 doubles on the host
+extern "C" int pgps_series_gp_ll_grad_adj_f64(pgps_series* s, int d, double lam, const double* N1, const double* N2,
+                                              const double* Pinf, const double* H, double R, double* out) {
+    if (!s || !out) return PGPS_E_INVALID;
+    if (d < 1 || d > 3) return PGPS_E_UNSUPPORTED_DIM;
+    pgps_ctx* ctx = s->ctx;
+    const int n = 1 + d * d + 2 * d + 1;
+    double* const res = s->zero_copy ? s->hdev : s->res;
+    TRY(gp_adj_dev(ctx, s->N, d, lam, N1, N2, Pinf, H, R, s->ts, s->t0, s->ys, res));
+    if (!s->zero_copy) HIPCHK(ctx, hipMemcpyAsync(s->host, s->res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i) out[i] = s->host[i];
     return std::isfinite(out[0]) ? PGPS_OK : PGPS_E_NUMERIC;
 }
 

@@ -20,6 +20,8 @@
 #else
 #include "pgps_discretise.hip.h"
 #include "pgps_fused.hip.h"
+#include "pgps_gpadj.hip.h"
+#include "pgps_gradlti.h"
 #include "pgps_kernels.hip.h"
 #endif
 
@@ -339,6 +341,54 @@ int launch_gp_batch(pgps_ctx* ctx, int B, GpBatchArgs<T> b) {
         return PGPS_E_UNSUPPORTED_DIM;
     }
 }
+
+// ---- fused path: log-likelihood and the model's adjoints (pgps_gpadj.hip.h), fp64 units of d <= 3 ---------------------
+template <typename T, int D>
+int launch_gp_adj(pgps_ctx* ctx, GpArgs<double> g, double* out) {
+    if constexpr (D <= 3 && std::is_same<T, double>::value) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        ScanArgs<double>& a = g.s;
+        geometry(ctx, a.N, &a.Lc, &a.nblocks);
+        const bool one = ctx->one_launch != 0 && ctx->chunk <= 0 &&
+                         a.N <= (ctx->one_launch > 0 ? (long)ctx->one_launch : (long)kOneLaunchAuto);
+        if (one) {
+            long v = (a.N + kBlock - 1) / kBlock;
+            v = (v + 3) / 4 * 4;
+            a.Lc = (int)v;
+            a.nblocks = 1;
+        }
+        a.nlanes = (long)a.nblocks * kBlock;
+        a.seg_first = 1;
+        a.seg_last = 1;
+        int rc = carve_workspace<double, D>(ctx, a);
+        if (rc) return rc;
+        constexpr int NX = D + Dim<D>::SYM, NST = gp_adj_nstat<D>();
+        const size_t n_xs = (size_t)a.Lc * NX * (size_t)a.nlanes, n_gp = (size_t)a.nblocks * NST;
+        rc = ensure(ctx, ctx->gadj, (n_xs + n_gp) * sizeof(double));
+        if (rc) return rc;
+        GpAdjArgs ga{};
+        ga.g = g;
+        ga.xs = (double*)ctx->gadj.p;
+        ga.gpart = ga.xs + n_xs;
+        ga.out = out;
+        const dim3 grid(a.nblocks), block(kBlock);
+        if (one) {
+            timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_gone<D>, dim3(1), block, 0, ga);
+        } else {
+            timed_launch(ctx, PGPS_K_FILTER_REDUCE, k_gp_reduce<double, D>, grid, block, 0, g);
+            timed_launch(ctx, PGPS_K_FILTER_APPLY, k_gp_gfwd<D>, grid, block, 0, ga);
+            timed_launch(ctx, PGPS_K_SMOOTHER_APPLY, k_gp_gback<D>, grid, block, 0, ga);
+            timed_launch(ctx, PGPS_K_LL_FINALIZE, k_grad_lti_finalize, dim3(1 + NST), dim3(256), 0, (long)a.nblocks, (int)NST,
+                         (const double*)a.llpart, (const double*)ga.gpart, out);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        return PGPS_OK;
+    } else {
+        (void)ctx; (void)g; (void)out;
+        return PGPS_E_UNSUPPORTED_DIM;
+    }
+}
+template int launch_gp_adj<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, GpArgs<double>, double*);
 
 template int launch_gp_batch<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, int, GpBatchArgs<PGPS_INST_T>);
 template int launch_gp<PGPS_INST_T, PGPS_INST_D>(pgps_ctx*, GpArgs<PGPS_INST_T>, int, int);

@@ -48,6 +48,7 @@ struct pgps_ctx {
     hipEvent_t probe_in = nullptr;      // recorded on the context's stream at the call's entry: the probe's stream waits for it
     hipStream_t probe_stream = nullptr; // the probe runs beside the call's first kernel, not in front of it
     int f32_last_promoted = 0;          // which way the last probed call went: decides the ORDER of the next one (see pgps_core.hip)
+    DevBuf gadj;                        // fused-path adjoint gradient (pgps_gpadj.hip.h): kept states of the forward pass, workgroup partials
     DevBuf wide[9];                     // fp64 copies of a promoted float32 call's arrays: P0, H, Fs, Qs, ys, fms, fPs, sms, sPs
     void* comm = nullptr;               // ncclComm_t (RCCL) of a series sharded over GPUs: pgps_comm_init (pgps_comm.hip)
     int comm_rank = 0, comm_nranks = 0;
@@ -193,6 +194,10 @@ struct GpArgs {
 
 template <typename T, int D>
 int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed);
+// log-likelihood and the model's adjoints on the fused path (pgps_gpadj.hip.h), fp64, d <= 3: out = 1 + d^2 + 2 d + 1 doubles [device]
+// (T names the unit that holds the instantiation: call it with T = double)
+template <typename T, int D>
+int launch_gp_adj(pgps_ctx* ctx, GpArgs<double> g, double* out);
 
 template <typename T>
 struct GpBatchArgs {

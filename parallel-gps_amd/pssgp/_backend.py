@@ -723,6 +723,9 @@ class Series:
         self.has_lti_grad = hasattr(lib, "pgps_series_lti_ll_grad_f64")
         if self.has_lti_grad:
             lib.pgps_series_lti_ll_grad_f64.argtypes = [P, c_int, P, P, P, c_double, P]
+        self.has_gp_adj = hasattr(lib, "pgps_series_gp_ll_grad_adj_f64")
+        if self.has_gp_adj:
+            lib.pgps_series_gp_ll_grad_adj_f64.argtypes = [P, c_int, c_double, P, P, P, P, c_double, P]
         self.N, self.K = ts_a.shape[0], 0
         self._tq = None
         h = P()
@@ -802,6 +805,24 @@ class Series:
             check(self.ctx, self.ctx.lib.pgps_series_gp_ll_grad_f64(self.handle, d, npar, _ptr(model), _ptr(self._gout)),
                   "pgps_series_gp_ll_grad_f64")
         return float(self._gout[0]), self._gout[1:1 + npar].copy()
+
+    def gp_ll_grad_adj(self, packed, R):
+        """(ll, Abar, Ubar, Hbar, Rbar) of the fused (Matern-family) model by the adjoint pass on the lane-chunk kernels
+        (pgps_series_gp_ll_grad_adj_f64): the same statistics as lti_ll_grad(), contracted by contract_grad_stats()."""
+        lam, N1, N2, Pinf, H, d = packed
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_gp_ll_grad_adj_f64(self.handle, d, lam, _ptr(N1), _ptr(N2), _ptr(Pinf), _ptr(H),
+                                                                        float(R), _ptr(self._gout)), "pgps_series_gp_ll_grad_adj_f64")
+        return split_grad_stats(self._gout[:2 + d * d + 2 * d].copy(), d)
+
+    def gp_ll_grad_adj_raw(self, packed, R):
+        """The same call, results left in the handle's output buffer [ll | Abar | Ubar | Hbar | Rbar] (a view: valid until
+        the next call) -- for callers that contract them in place."""
+        lam, N1, N2, Pinf, H, d = packed
+        with self.ctx.lock:
+            check(self.ctx, self.ctx.lib.pgps_series_gp_ll_grad_adj_f64(self.handle, d, lam, _ptr(N1), _ptr(N2), _ptr(Pinf), _ptr(H),
+                                                                        float(R), _ptr(self._gout)), "pgps_series_gp_ll_grad_adj_f64")
+        return self._gout
 
     def gp_predict(self, packed, R):
         """(mean (K,), var (K,), ll) at the query grid of set_queries()."""

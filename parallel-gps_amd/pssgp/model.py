@@ -555,6 +555,42 @@ class StateSpaceGP:
         by_name = {"variance": (zF, P0 / float(k.variance), zH), "lengthscales": (-F / float(k.lengthscales), zP, zH)}
         return (F, P0, H, [by_name[a] for _, a in leaf_parameters(k)])
 
+    def _fused_adjoint_pays(self, n):
+        """Automatic choice between the dual-number pass and the adjoint pass of the fused path, from measurements on one
+        MI355X (tools/grad_methods.py, microseconds per call, dual / adjoint): Matern-5/2 96 / 78 at N = 200, 198 / 102 at
+        4096, 592 / 147 at 2^20: always the adjoint; Matern-3/2 51 / 54 at 1000 (one launch each), 77 / 64 at 4096, 186 / 92
+        at 2^20: above the one-launch length; Matern-1/2 (two directions, d = 1) 46 / 53: duals."""
+        name = type(self.kernel).__name__
+        return name == "Matern52" or (name == "Matern32" and n > 2048)
+
+    def _fused_adjoint_ll_and_grad(self, fused, wrt=None):
+        """(ll, grad) of a single Matern kernel by the adjoint pass on the fused (closed-form discretisation) kernels
+        (csrc/pgps_gpadj.hip.h): the device returns the model's adjoints [Abar | Ubar | Hbar | Rbar] from one filter pass
+        and one reverse pass over the resident series; the lengthscale scales time (dF = -F / l) and the variance Pinf
+        (dPinf = Pinf / s2), so  d ll / d l = -<Abar, F> / l,  d ll / d s2 = Ubar^T Pinf H^T / s2,  d ll / d R = Rbar.
+        None when the series is not resident or the library has no such entry point."""
+        ser = self._device_series()
+        if ser is None or not getattr(ser, "has_gp_adj", False):
+            return None
+        packed = self._packed_fused(fused)
+        lam, N1, _, Pinf, H, d = packed
+        memo = getattr(self, "_fadj_memo", None)
+        if memo is None or memo[0] is not packed:
+            F = (N1 - lam * np.eye(d)).reshape(-1)
+            memo = self._fadj_memo = (packed, F, Pinf @ H, [a for _, a in leaf_parameters(self.kernel)])
+        _, F, PH, names = memo
+        out = ser.gp_ll_grad_adj_raw(packed, self.noise_variance)
+        dd = d * d
+        k = self.kernel
+        by_name = {"variance": float(out[1 + dd:1 + dd + d] @ PH) / float(k.variance),
+                   "lengthscales": -float(out[1:1 + dd] @ F) / float(k.lengthscales)}
+        g = np.array([by_name[a] for a in names] + [float(out[1 + dd + 2 * d])])
+        if wrt is not None:
+            keep = np.zeros(len(g), bool)
+            keep[[int(i) for i in wrt]] = True
+            g = np.where(keep, g, 0.0)
+        return config.default_float()(out[0]), g
+
     def _adjoint_ll_and_grad(self, wrt=None, prepared=None):
         """(ll, grad) by the adjoint pass of the general-LTI device path (pgps_lti_ll_grad_f64): the device returns the
         adjoints of the model (F, Pinf, H, R) from one filter pass and one reverse pass, pssgp.kernels.sde_grads the
@@ -666,6 +702,11 @@ class StateSpaceGP:
             # no dual-number path: batched differences on the general-LTI kernels (d <= 16), one evaluation at a
             # time above that (e.g. the CO2 kernel at its reference order, d = 18)
             return self._lti_ll_and_grad(batched=lti is not None, wrt=wrt)
+        if method in (None, "adjoint") and ts.dtype == np.float64 and (method == "adjoint" or self._fused_adjoint_pays(ts.shape[0])):
+            # the adjoint pass on the fused path's own kernels (csrc/pgps_gpadj.hip.h)
+            out = self._fused_adjoint_ll_and_grad(fused, wrt)
+            if out is not None:
+                return out
         if (method in (None, "adjoint") and type(self.kernel).__name__ == "Matern52" and ts.dtype == np.float64
                 and ts.shape[0] > self._MATERN52_ADJOINT_FROM):
             out = self._adjoint_ll_and_grad(wrt, prepared=self._matern_prepared(fused))
@@ -674,8 +715,13 @@ class StateSpaceGP:
         ser = self._device_series() if ts.dtype == np.float64 else None
         if ser is not None:
             model, d, npar = _backend.pack_grad_model(self._grad_blocks())
-            return ser.gp_ll_grad(model, d, npar)
-        ll, g = _backend.gp_ll_grad(self._grad_blocks(), ts.reshape(-1), Y.reshape(-1))
+            ll, g = ser.gp_ll_grad(model, d, npar)
+        else:
+            ll, g = _backend.gp_ll_grad(self._grad_blocks(), ts.reshape(-1), Y.reshape(-1))
+        if wrt is not None:                 # (one pass gives every direction; the ones not asked for read 0)
+            keep = np.zeros(len(g), bool)
+            keep[[int(i) for i in wrt]] = True
+            g = np.where(keep, g, 0.0)
         return ll, g
 
     def _lti_ll_and_grad(self, rel_step=1e-3, batched=True, wrt=None):

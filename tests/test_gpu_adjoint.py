@@ -281,36 +281,88 @@ def test_rbf_gradient_through_the_scaled_realisation():
         assert np.max(np.abs(g - G.contract(ref, sde.H, grads))) <= 1e-7 * max(1.0, float(np.max(np.abs(g))))
 
 
-def test_matern52_takes_the_adjoint_pass_on_long_series():
-    """Matern-5/2 above the one-launch length: the automatic gradient is the adjoint pass on the general-LTI kernels, with
-    the model and its derivatives written down from the fused form (time / variance scaling) -- the same numbers as the
-    dual-number pass (exact, 1e-9), as the oracle's reverse sweep on the kernel's own get_sde(), and at a new setting
-    every call; below that length and for Matern-3/2 the duals stay."""
-    from pssgp.kernels import Matern32, Matern52
+def test_matern_family_automatic_choice_between_duals_and_the_adjoint_pass():
+    """Which pass `log_likelihood_and_grad()` takes for a single Matern kernel (measured crossovers, tools/grad_methods.py):
+    Matern-5/2 the adjoint pass of the fused path at every length, Matern-3/2 above the one-launch length, Matern-1/2 and
+    short Matern-3/2 series the dual numbers -- and the same numbers either way (1e-9), also against the oracle's reverse
+    sweep on the kernel's own get_sde(), at a new setting every call, for a subset of the directions, and through the
+    general-LTI kernels when the series is not resident on the device (unsorted times)."""
+    from pssgp.kernels import Matern12, Matern32, Matern52
     from pssgp.kernels.sde_grads import sde_with_grads
     from pssgp.model import StateSpaceGP
     t, y = _series(6000, seed=8, nan_frac=0.1)
+
+    def spy(gp):
+        calls = {"fused": 0, "lti": 0}
+        f, l = gp._fused_adjoint_ll_and_grad, gp._adjoint_ll_and_grad
+        gp._fused_adjoint_ll_and_grad = lambda *a, **kw: (calls.__setitem__("fused", calls["fused"] + 1), f(*a, **kw))[1]
+        gp._adjoint_ll_and_grad = lambda *a, **kw: (calls.__setitem__("lti", calls["lti"] + 1), l(*a, **kw))[1]
+        return calls
+
+    for cls, n, want in ((Matern52, 6000, 1), (Matern52, 400, 1), (Matern32, 6000, 1), (Matern32, 1500, 0), (Matern12, 6000, 0)):
+        k = cls(1.2, 0.6)
+        gp = StateSpaceGP((t[:n, None], y[:n, None]), k, noise_variance=0.15, parallel=True)
+        calls = spy(gp)
+        for ell, s2 in ((0.6, 1.2), (0.9, 0.7), (0.35, 2.0)):
+            k.lengthscales, k.variance = ell, s2
+            ll, g = gp.log_likelihood_and_grad()
+            lld, gd = gp.log_likelihood_and_grad(method="dual")
+            assert abs(float(ll) - float(lld)) <= 1e-10 * abs(float(lld))
+            assert np.max(np.abs(np.asarray(g) - np.asarray(gd))) <= 1e-9 * max(1.0, float(np.max(np.abs(gd))))
+            sde, grads = sde_with_grads(k)
+            ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, 0.15, t[:n], y[:n])
+            assert np.max(np.abs(np.asarray(g) - G.contract(ref, sde.H, grads))) <= 1e-7 * max(1.0, float(np.max(np.abs(g))))
+        assert calls["fused"] == 3 * want and calls["lti"] == 0, (cls.__name__, n, calls)
+        _, g1 = gp.log_likelihood_and_grad(wrt=[1])
+        _, gall = gp.log_likelihood_and_grad()
+        assert g1[1] == gall[1] and g1[0] == 0.0
+    # a series the device does not keep (times not sorted): Matern-5/2 above 2048 points goes through the general-LTI kernels
+    perm = np.random.default_rng(0).permutation(6000)
     k = Matern52(1.2, 0.6)
-    gp = StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=0.15, parallel=True)
-    calls = []
-    real = gp._adjoint_ll_and_grad
-    gp._adjoint_ll_and_grad = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
-    for ell, s2 in ((0.6, 1.2), (0.9, 0.7), (0.35, 2.0)):
-        k.lengthscales, k.variance = ell, s2
-        ll, g = gp.log_likelihood_and_grad()
-        lld, gd = gp.log_likelihood_and_grad(method="dual")
-        assert abs(float(ll) - float(lld)) <= 1e-10 * abs(float(lld))
-        assert np.max(np.abs(np.asarray(g) - np.asarray(gd))) <= 1e-9 * max(1.0, float(np.max(np.abs(gd))))
-        sde, grads = sde_with_grads(k)
-        ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, 0.15, t, y)
-        assert np.max(np.abs(np.asarray(g) - G.contract(ref, sde.H, grads))) <= 1e-7 * max(1.0, float(np.max(np.abs(g))))
-    assert len(calls) == 3, "the automatic choice did not take the adjoint pass"
-    # only some directions
-    _, g1 = gp.log_likelihood_and_grad(wrt=[1])
-    _, gall = gp.log_likelihood_and_grad()
-    assert g1[1] == gall[1] and g1[0] == 0.0
-    # short series and Matern-3/2: dual numbers
-    for kern, n in ((Matern52(1.2, 0.6), 1500), (Matern32(1.2, 0.6), 6000)):
-        gp2 = StateSpaceGP((t[:n, None], y[:n, None]), kern, noise_variance=0.15, parallel=True)
-        gp2._adjoint_ll_and_grad = lambda *a, **kw: (_ for _ in ()).throw(AssertionError("adjoint pass taken"))
-        gp2.log_likelihood_and_grad()
+    gp = StateSpaceGP((t[perm][:, None], y[perm][:, None]), k, noise_variance=0.15, parallel=True)
+    assert gp._device_series() is None
+
+
+@pytest.mark.parametrize("kname", ["m12", "m32", "m52"])
+@pytest.mark.parametrize("n,chunk", [(1, 0), (2, 0), (37, 0), (700, 0), (1300, 0), (2048, 0), (2049, 0), (5000, 0), (70001, 0), (5000, 3), (3000, 1)])
+def test_fused_path_adjoints_match_the_reverse_sweep(kname, n, chunk):
+    """The adjoint pass of the fused (Matern-family) path, csrc/pgps_gpadj.hip.h: the device's [ll | Abar | Ubar | Hbar |
+    Rbar] against the numpy reverse sweep of oracle/np_grad.py on the kernel's own SDE -- one launch (up to 2048 steps) and
+    three, one workgroup and many, every chunk length, 15 % of the observations missing."""
+    from pssgp import _backend as B
+    from pssgp.kernels import Matern12, Matern32, Matern52
+    from pssgp.model import StateSpaceGP
+    k = {"m12": Matern12(1.3, 0.7), "m32": Matern32(1.3, 0.7), "m52": Matern52(1.3, 0.7)}[kname]
+    t, y = _series(n, seed=11 + n, nan_frac=0.15 if n > 2 else 0.0)
+    gp = StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=0.2, parallel=True)
+    ctx = B.get_context()
+    ctx.set_chunk(chunk)
+    try:
+        fused = gp._device_forms()[0]
+        assert fused is not None
+        ser = gp._device_series()
+        assert ser is not None and ser.has_gp_adj
+        dev = ser.gp_ll_grad_adj(gp._packed_fused(fused), 0.2)
+    finally:
+        ctx.set_chunk(0)
+    sde = k.get_sde()
+    ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, 0.2, t, y)
+    _check_stats(dev, ref, 1e-9)
+
+
+@pytest.mark.parametrize("kname", ["m12", "m32", "m52"])
+def test_fused_path_adjoint_gradient_equals_the_dual_number_gradient(kname):
+    from pssgp.kernels import Matern12, Matern32, Matern52
+    from pssgp.model import StateSpaceGP
+    for n in (300, 6000):
+        t, y = _series(n, seed=5 + n, nan_frac=0.1)
+        k = {"m12": Matern12, "m32": Matern32, "m52": Matern52}[kname](0.9, 0.45)
+        gp = StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=0.12, parallel=True)
+        for ell, s2 in ((0.45, 0.9), (1.1, 2.2)):
+            k.lengthscales, k.variance = ell, s2
+            lla, ga = gp.log_likelihood_and_grad(method="adjoint")
+            lld, gd = gp.log_likelihood_and_grad(method="dual")
+            assert abs(float(lla) - float(lld)) <= 1e-10 * abs(float(lld))
+            assert np.max(np.abs(np.asarray(ga) - np.asarray(gd))) <= 1e-9 * max(1.0, float(np.max(np.abs(gd))))
+        _, g1 = gp.log_likelihood_and_grad(wrt=[0], method="adjoint")
+        assert g1[0] == ga[0] and g1[1] == 0.0 and g1[2] == 0.0
