@@ -366,3 +366,34 @@ def test_fused_path_adjoint_gradient_equals_the_dual_number_gradient(kname):
             assert np.max(np.abs(np.asarray(ga) - np.asarray(gd))) <= 1e-9 * max(1.0, float(np.max(np.abs(gd))))
         _, g1 = gp.log_likelihood_and_grad(wrt=[0], method="adjoint")
         assert g1[0] == ga[0] and g1[1] == 0.0 and g1[2] == 0.0
+
+
+def test_device_pointer_entry_points_of_both_adjoint_passes():
+    """pgps_gp_ll_grad_adj_dev_f64 and pgps_lti_ll_grad_dev_f64 (include/pgps.h): series and results on the device,
+    asynchronous on the context's stream -- the same statistics as the resident-series calls and the oracle's sweep."""
+    import ctypes
+    from pssgp import _backend as B
+    from pssgp.kernels import Matern52
+    from tests.test_segments import _Dev
+    L, I, D = ctypes.c_long, ctypes.c_int, ctypes.c_double
+    ctx = B.get_context()
+    n = 3000
+    t, y = _series(n, seed=21, nan_frac=0.1)
+    k = Matern52(1.1, 0.8)
+    sde = k.get_sde()
+    d = sde.F.shape[0]
+    nst = 2 + d * d + 2 * d
+    ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, 0.25, t, y)
+    ts, ys, out = _Dev(ctx, t), _Dev(ctx, y), _Dev(ctx, shape=(nst,))
+    lam, N1, N2 = B.nilpotent_form(sde.F)
+    c = lambda a: np.ascontiguousarray(a, np.float64)
+    N1c, N2c, Pc, Hc = c(N1), c(N2), c(sde.P0), c(np.asarray(sde.H).reshape(-1))
+    pp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ctx.call("pgps_gp_ll_grad_adj_dev_f64", L(n), I(d), D(float(lam)), pp(N1c), pp(N2c), pp(Pc), pp(Hc), D(0.25), ts.p, D(0.0), ys.p, out.p)
+    ctx.synchronize()
+    _check_stats(B.split_grad_stats(out.get(), d), ref, 1e-9)
+    Fc = c(sde.F)
+    out.put(np.zeros(nst))
+    ctx.call("pgps_lti_ll_grad_dev_f64", L(n), I(d), pp(Fc), pp(Pc), pp(Hc), D(0.25), ts.p, ys.p, D(0.0), out.p)
+    ctx.synchronize()
+    _check_stats(B.split_grad_stats(out.get(), d), ref, 1e-9)
