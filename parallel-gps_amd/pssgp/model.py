@@ -124,15 +124,22 @@ class StateSpaceGP:
         self._key_memo = (version, self.kernel, config.NUMBER_OF_BALANCING_STEPS, key)
         return key
 
-    def _device_series(self):
-        """The training series resident on the device (pgps_series_*, fp64 fused path): created at the first call, kept
-        for the model's life -- an optimiser or sampler loop then sends only the model's scalars per evaluation.  None
-        when the data are not sorted or not float64 (the host entry points take those)."""
+    def _device_series(self, force=False):
+        """The training series resident on the device (pgps_series_*, fp64 fused path): created at the SECOND evaluation of
+        the model (or with force=True) and kept for its life -- an optimiser or sampler loop then sends only the model's
+        scalars per evaluation.  The first evaluation goes through the host-array entry points, whose staging buffers belong
+        to the context: a model that is built, evaluated once and dropped -- the reference's speed protocol,
+        experiments/toy_models/speed_and_stability.py:73-87 -- would otherwise pay a set of device and pinned-host
+        allocations per call (measured: Matern-3/2, N = K = 4096, model + predict_f 470 us against 175 us).  None when the
+        data are not sorted or not float64 (the host entry points take those), and at that first evaluation."""
         ser = getattr(self, "_series", None)
         ts, ys = self.data
         if ser is not None and getattr(self, "_series_stamp", None) != self._data_stamp(ts, ys):
             self.invalidate_device_series()         # the arrays were replaced or edited since the copy was made
             ser = None
+        if ser is None and not force and not getattr(self, "_series_wanted", False):
+            self._series_wanted = True
+            return None
         if ser is None:
             from . import _backend
             t = ts.reshape(-1)
@@ -155,6 +162,7 @@ class StateSpaceGP:
             ser.close()
         self._series = None
         self._series_stamp = None
+        self._series_wanted = False
         self._ll_memo = None
 
     def _device_forms(self):

@@ -82,10 +82,14 @@ def test_state_space_gp_dispatches_to_the_lti_path(monkeypatch):
     from pssgp.kernels import RBF
     from pssgp.model import StateSpaceGP
     calls = []
-    # (since round 3 the model keeps its series on the device and calls pgps_series_lti_* through _backend.Series)
+    # (the first evaluation of a model goes through the host-array entry points pgps_lti_*, from the second on the model
+    # keeps its series on the device and calls pgps_series_lti_* through _backend.Series)
     real_ll, real_pr = B.Series.lti_ll, B.Series.lti_predict
-    monkeypatch.setattr(B.Series, "lti_ll", lambda self, *a, **k: calls.append("ll") or real_ll(self, *a, **k))
-    monkeypatch.setattr(B.Series, "lti_predict", lambda self, *a, **k: calls.append("predict") or real_pr(self, *a, **k))
+    host_ll, host_pr = B.lti_ll, B.lti_predict
+    monkeypatch.setattr(B.Series, "lti_ll", lambda self, *a, **k: calls.append("series ll") or real_ll(self, *a, **k))
+    monkeypatch.setattr(B.Series, "lti_predict", lambda self, *a, **k: calls.append("series predict") or real_pr(self, *a, **k))
+    monkeypatch.setattr(B, "lti_ll", lambda *a, **k: calls.append("ll") or host_ll(*a, **k))
+    monkeypatch.setattr(B, "lti_predict", lambda *a, **k: calls.append("predict") or host_pr(*a, **k))
     rng = np.random.RandomState(31415926)
     T, K = 200, 50
     t = np.sort(rng.rand(T))
@@ -99,7 +103,12 @@ def test_state_space_gp_dispatches_to_the_lti_path(monkeypatch):
     mean, var = model.predict_f(query)
     np.testing.assert_allclose(mean[:, 0], mean_gp, atol=1e-2, rtol=1e-2)
     np.testing.assert_allclose(var[:, 0], var_gp, atol=1e-2, rtol=1e-2)
-    assert calls == ["ll", "predict"]
+    ll2 = float(model.maximum_log_likelihood_objective())
+    k2 = RBF(variance=1.1, lengthscales=0.5, order=15, balancing_iter=10)
+    model.kernel = k2
+    model.maximum_log_likelihood_objective()
+    assert calls == ["ll", "series predict", "series ll"], calls      # (the repeated objective is memoised)
+    np.testing.assert_allclose(ll2, ll_gp, atol=1e-2, rtol=1e-2)
 
 
 def test_lti_large_series_vs_c_oracle():

@@ -80,7 +80,10 @@ def test_statespacegp_uses_the_resident_series():
     tq = np.linspace(t[0], t[-1], 700)
     gp = StateSpaceGP((t[:, None], y[:, None]), Matern32(1.0, 0.5), noise_variance=0.1, parallel=True)
     ll = float(gp.maximum_log_likelihood_objective())
-    assert gp._series and gp._series.N == 3000
+    assert not getattr(gp, "_series", None)         # the first evaluation of a model: host-array entry points, no allocations
+    gp.kernel.variance = 1.0                        # (drops the memoised objective)
+    assert float(gp.maximum_log_likelihood_objective()) == pytest.approx(ll, rel=1e-12)
+    assert gp._series and gp._series.N == 3000      # ... from the second on: resident
     sde = gp.kernel.get_sde()
     form = B.nilpotent_form(sde.F)
     assert abs(ll - float(B.gp(form, sde.P0, sde.H, 0.1, t, y)["ll"])) < 1e-10 * abs(ll)
