@@ -96,6 +96,31 @@ class SDEKernelMixin:
     def __init__(self, t0=0., **_kwargs):
         self.t0 = t0
 
+    def __init_subclass__(cls, **kwargs):
+        """Every class's own `get_sde` is memoised per kernel object: the continuous model is rebuilt only after an
+        attribute of SOME kernel has been assigned (`Kernel._version`; conservative: a composite's memo must fall with its
+        children's parameters), the number of balancing sweeps or the default float has changed.  One kernel object shared by
+        many short-lived models -- the reference's speed protocol, experiments/toy_models/speed_and_stability.py:56-87 --
+        then pays for the polynomial roots, balancing sweeps and Lyapunov solve of its SDE once (RBF order 6: 0.25 ms).
+        The returned model is shared: treat its arrays as read-only."""
+        super().__init_subclass__(**kwargs)
+        f = cls.__dict__.get("get_sde")
+        if f is None or getattr(f, "_memoised", False):
+            return
+
+        def get_sde(self, _f=f):
+            key = (Kernel._version, pssgp_config.NUMBER_OF_BALANCING_STEPS, pssgp_config.default_float())
+            memo = self.__dict__.get("_sde_memo")
+            if memo is not None and memo[0] == key:
+                return memo[1]
+            sde = _f(self)
+            object.__setattr__(self, "_sde_memo", (key, sde))          # (not through Kernel.__setattr__: no version bump)
+            return sde
+
+        get_sde._memoised = True
+        get_sde.__doc__ = f.__doc__
+        cls.get_sde = get_sde
+
     def get_sde(self):
         raise NotImplementedError
 

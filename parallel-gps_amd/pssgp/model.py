@@ -44,6 +44,10 @@ def _merge_sorted(a, b, *args):
     return (weave(a, b),) + tuple(weave(i, j) for i, j in args)
 
 
+_MATERN52_CHECKED = {}      # the same key -> the scaled unit form reproduced the kernel's own get_sde() (checked once per process)
+_MATERN52_UNITS = {}        # (class, balancing sweeps, config sweeps) -> (Pinf, H, N, N^2 / 2) of the Matern-5/2 SDE at lam = 1, s2 = 1
+
+
 class _StructureChanged(Exception):
     """_grad_rows_composite: the block partition of the drift is not the same at the perturbed parameters."""
 
@@ -217,17 +221,25 @@ class StateSpaceGP:
                     (lam, np.array([[lam, 1.0], [-lam * lam, -lam]]), np.zeros((2, 2))))
         unit = getattr(self, "_matern52_unit", None)
         if unit is None:
+            # (shared by every model of the process: a model built per evaluation -- the reference's speed protocol -- would
+            # otherwise balance and solve the unit SDE once per call)
+            ukey = (type(k), getattr(k, "_balancing_iter", None), config.NUMBER_OF_BALANCING_STEPS)
+            unit = _MATERN52_UNITS.get(ukey)
+        if unit is None:
             from . import _backend
             sde1 = type(k)(1.0, np.sqrt(5.0), **({"balancing_iter": k._balancing_iter} if hasattr(k, "_balancing_iter") else {})).get_sde()
             form1 = _backend.nilpotent_form(sde1.F)
             if form1 is None or abs(form1[0] - 1.0) > 1e-12:
                 self._matern_fast = False
                 return None
-            unit = self._matern52_unit = (np.asarray(sde1.P0, np.float64), np.asarray(sde1.H, np.float64).reshape(1, -1),
-                                          np.asarray(form1[1], np.float64), np.asarray(form1[2], np.float64))
+            unit = _MATERN52_UNITS[ukey] = (np.asarray(sde1.P0, np.float64), np.asarray(sde1.H, np.float64).reshape(1, -1),
+                                            np.asarray(form1[1], np.float64), np.asarray(form1[2], np.float64))
+        self._matern52_unit = unit
         lam = np.sqrt(5.0) / ell
         out = (SimpleNamespace(P0=s2 * unit[0], H=unit[1]), (lam, lam * unit[2], (lam * lam) * unit[3]))
-        if getattr(self, "_matern_fast", None) is None:            # first use: against the kernel's own get_sde()
+        if getattr(self, "_matern_fast", None) is None:
+            self._matern_fast = _MATERN52_CHECKED.get((type(k), getattr(k, "_balancing_iter", None), config.NUMBER_OF_BALANCING_STEPS))
+        if getattr(self, "_matern_fast", None) is None:            # first use in the process: against the kernel's own get_sde()
             from . import _backend
             sde = k.get_sde()
             form = _backend.nilpotent_form(sde.F)
@@ -235,6 +247,7 @@ class StateSpaceGP:
             self._matern_fast = bool(form is not None and close(out[1][0], form[0]) and close(out[1][1], form[1])
                                      and close(out[1][2], form[2]) and close(out[0].P0, sde.P0)
                                      and close(out[0].H, np.asarray(sde.H).reshape(1, -1)))
+            _MATERN52_CHECKED[(type(k), getattr(k, "_balancing_iter", None), config.NUMBER_OF_BALANCING_STEPS)] = self._matern_fast
             if not self._matern_fast:
                 return None
         return out

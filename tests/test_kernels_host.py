@@ -194,3 +194,33 @@ def test_toy_signals():
         assert f(t).shape == t.shape and np.all(np.isfinite(f(t)))
     y = obs_noise(sinu(t), 0.1, 7)
     assert y.shape == t.shape and np.all(y == obs_noise(sinu(t), 0.1, 7))
+
+
+def test_get_sde_is_memoised_per_kernel_object_until_a_parameter_moves():
+    """One kernel object shared by many short-lived models (the reference's speed protocol) builds its SDE once; an
+    assignment to any kernel's attribute, another number of balancing sweeps or another default float rebuilds it."""
+    from pssgp import config
+    from pssgp.kernels import Matern32, Matern52, Periodic, RBF, SquaredExponential
+    k = RBF(1.0, 0.5, order=6, balancing_iter=10)
+    a = k.get_sde()
+    assert k.get_sde() is a
+    k.lengthscales = 0.7
+    b = k.get_sde()
+    assert b is not a and np.max(np.abs(np.asarray(b.F) - np.asarray(a.F))) > 0
+    k.lengthscales = 0.5
+    c = k.get_sde()
+    assert c is not a and np.array_equal(np.asarray(c.F), np.asarray(a.F)) and np.array_equal(np.asarray(c.P0), np.asarray(a.P0))
+    q = Periodic(SquaredExponential(1.0, 1.0), period=1.0, order=2) * Matern32(1.0, 1.0) + Matern52(1.0, 1.0)
+    s1 = q.get_sde()
+    assert q.get_sde() is s1
+    q.kernels[1].variance = 2.0                  # a leaf two levels down
+    s2 = q.get_sde()
+    assert s2 is not s1 and abs(np.max(np.abs(np.asarray(s2.P0) - np.asarray(s1.P0))) - 1.0) < 1e-9
+    m = Matern52(1.0, 1.0)
+    s3 = m.get_sde()
+    old = config.NUMBER_OF_BALANCING_STEPS
+    try:
+        config.set_number_balancing_steps(old + 3)
+        assert m.get_sde() is not s3
+    finally:
+        config.set_number_balancing_steps(old)
