@@ -236,3 +236,47 @@ def test_random_adjoint_statistics(seed):
     finally:
         ctx.set_family(0)
         ctx.set_chunk(0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_fused_path_adjoint_statistics(seed):
+    """pgps_series_gp_ll_grad_adj_f64 (the adjoint pass on the fused Matern-family kernels) at random hyper-parameters,
+    lengths ragged against random chunk lengths, one launch and three, any share of missing observations, duplicate time
+    stamps: log-likelihood and the model's adjoints against the numpy reverse sweep (oracle/np_grad.py) on the kernel's own SDE."""
+    from oracle import np_grad as G
+    from pssgp import _backend as B
+    from pssgp.kernels import Matern12, Matern32, Matern52
+    from pssgp.model import StateSpaceGP
+    rng = np.random.default_rng(9000 + seed)
+    ctx = B.get_context()
+    try:
+        for case in range(6):
+            cls = [Matern12, Matern32, Matern52][int(rng.integers(0, 3))]
+            k = cls(float(rng.uniform(0.3, 3.0)), float(rng.uniform(0.1, 2.0)))
+            n = int(rng.choice([1, 2, 3, 5, 17, 64, 257, 700, 2048, 2049, 5000, 9001]))
+            chunk = int(rng.choice([0, 0, 1, 2, 3, 5, 8, 13]))
+            one = int(rng.choice([-1, -1, 0]))
+            R = float(rng.uniform(0.01, 1.0))
+            t = make_times(n, seed=seed * 100 + case)
+            if n > 20:
+                t[7:10] = t[7]                          # dt = 0 steps
+            y = np.sin(t) + 0.3 * rng.standard_normal(n)
+            if n > 3:
+                y[rng.uniform(size=n) < float(rng.choice([0.0, 0.2, 0.6]))] = np.nan
+            if np.all(np.isnan(y)):
+                y[0] = 0.1
+            gp = StateSpaceGP((t[:, None], y[:, None]), k, noise_variance=R, parallel=True)
+            ctx.set_chunk(chunk)
+            ctx.set_one_launch(one)
+            ser = gp._device_series(force=True)
+            dev = ser.gp_ll_grad_adj(gp._packed_fused(gp._device_forms()[0]), R)
+            sde = k.get_sde()
+            ref = G.ll_grad_stats(sde.F, sde.P0, sde.H, R, t, y)
+            tag = f"seed={seed} {cls.__name__} n={n} chunk={chunk} one_launch={one}"
+            assert abs(dev[0] - ref[0]) <= 1e-9 * abs(ref[0]) + 1e-12, tag
+            for name, a, b in zip(("Abar", "Ubar", "Hbar", "Rbar"), dev[1:], ref[1:]):
+                err = float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) / max(1e-6, float(np.max(np.abs(b))))
+                assert err < 1e-8, (tag, name, err)
+    finally:
+        ctx.set_chunk(0)
+        ctx.set_one_launch(-1)
