@@ -105,7 +105,8 @@ def main():
     for seed in range(first, first + count):
         for name, fn in (("rc", T.test_random_models_sizes_and_chains), ("rc_fp32", T.test_random_models_fp32_row_cooperative),
                          ("quad_fp32", T.random_quad_case), ("large_d", large_d_case), ("two_rows", two_rows_case),
-                         ("segments", T.random_segments_case), ("adjoint", T.test_random_adjoint_statistics)):
+                         ("segments", T.random_segments_case), ("adjoint", T.test_random_adjoint_statistics),
+                         ("fused_adjoint", T.test_random_fused_path_adjoint_statistics)):
             if only and name not in only:
                 continue
             try:
