@@ -773,6 +773,23 @@ def main():
             r_.update({"timesteps_per_s": n_local / r_["ms_per_step"] * 1e3, "log_likelihood": float(g_d[0].item()),
                        "gradient": [float(v) for v in g_d[1:1 + npar].tolist()]})
             fused["log-lik + gradient (3 hyper-parameters, forward-mode duals)"] = r_
+            if hasattr(ctx.lib, "pgps_gp_ll_grad_adj_dev_f64"):
+                # the adjoint pass of the fused path (csrc/pgps_gpadj.hip.h): [ll | Abar | Ubar | Hbar | Rbar], contracted here
+                a_d = torch.zeros((2 + d * d + 2 * d,), dtype=torch.float64, device=dev)
+
+                def adj_step():
+                    ctx.call("pgps_gp_ll_grad_adj_dev_f64", ctypes.c_long(n_local), ctypes.c_int(d), ctypes.c_double(lam), HP(N1),
+                             HP(N2), HP(Pinf_h), HP(H_h), ctypes.c_double(noise), P(ts_d), ctypes.c_double(t_prev), P(ys_d), P(a_d))
+
+                r2 = timed_rounds(adj_step, stream, sync, reps=reps, rounds=rounds)
+                st = a_d.cpu().numpy()
+                Fm = np.asarray(N1, np.float64).reshape(d, d) - lam * np.eye(d)
+                g_adj = [float(st[1 + d * d:1 + d * d + d] @ (Pinf_h @ H_h)) / float(kern.variance),
+                         -float(st[1:1 + d * d] @ Fm.reshape(-1)) / float(kern.lengthscales), float(st[1 + d * d + 2 * d])]
+                r2.update({"timesteps_per_s": n_local / r2["ms_per_step"] * 1e3, "log_likelihood": float(st[0]), "gradient": g_adj,
+                           "max_rel_diff_to_duals": float(np.max(np.abs(np.array(g_adj) - np.array(r_["gradient"])))
+                                                          / max(1e-300, float(np.max(np.abs(r_["gradient"])))))})
+                fused["log-lik + gradient (adjoint pass: one filter pass, one reverse pass)"] = r2
         # predict_f on the device: N training steps + N/4 query times (merge + filter + smoother + projection)
         kq = max(1, n_local // 4)
         tq_d = (torch.rand(kq, dtype=torch.float64, device=dev) * float(ts_d[-1].item())).sort().values.to(dtype_t)
