@@ -2,7 +2,8 @@
 """One evaluation scenario at the reference's series lengths, for `rocprofv3 --kernel-trace --stats -- python3
 tools/trace_small.py <scenario> [calls]`: which launches an evaluation is made of and what each one costs.
 Scenarios: rbf6_ll, rbf6_grad, rbf6_predict (RBF order 6, N = 1000), rbf15_grad, per2_grad, c5_grad (N = 4096),
-co2_ll, co2_grad (the reference's CO2 kernel, d = 18, N = 3192), m32_grad (Matern-3/2, N = 1000).
+co2_ll, co2_grad (the reference's CO2 kernel, d = 18, N = 3192), m32_grad (Matern-3/2, N = 1000), c1_ll / c1_grad / c1_predict
+(Matern-3/2, N = 4096; 1024 query points).
 Prints the wall-clock microseconds per call as well."""
 import os, sys, time
 import numpy as np
@@ -20,7 +21,7 @@ def make(name):
         t = np.cumsum(rng.uniform(0.5, 1.5, n)) * (1.0 / 52.0)
         y = 0.3 * np.sin(2 * np.pi * t) + 0.01 * t + 0.05 * rng.standard_normal(n)
         return StateSpaceGP((t[:, None], y[:, None]), co2_covariance(3), 0.05, parallel=True), t
-    n = 4096 if name.startswith("c5") else 1000
+    n = 4096 if name.startswith(("c5", "c1")) else 1000
     t = np.sort(rng.uniform(0, 10, n)); y = np.sin(t) + 0.3 * rng.standard_normal(n)
     if name.startswith("rbf6"):
         k = RBF(1., 0.5, order=6, balancing_iter=5)
