@@ -1,5 +1,6 @@
 # c3 with the dense-grid probe (automatic policy) against float32 arithmetic without it (policy 1), interleaved on one box.
-# PGPS_PROBE_TEST (a temporary switch of the experiment): 1 = events without the system-scope fence, 2 = 512 samples, 3 = both
+# (the third run of profiles/r04_experiments.txt item 2 also set PGPS_PROBE_TEST = 1 / 2 / 3 -- events without the system-scope
+# fence, 512 samples, both -- through a switch that existed in pgps_core.hip for that run only; the library ignores it now)
 cd $GRAFT_REPO_ROOT
 for i in 1 2 3 4; do
 for v in "1:0" "0:0" "0:1" "0:2" "0:3"; do
