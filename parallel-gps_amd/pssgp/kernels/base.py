@@ -61,6 +61,10 @@ class Kernel:
     # Bumped by every assignment to an attribute of any kernel object: what StateSpaceGP memoises per hyper-parameter
     # setting is revalidated only when this has moved (an evaluation repeated at the same setting costs one comparison).
     _version = 0
+    # ... and this one only by assignments that can change the STRUCTURE of a kernel (anything but a new value of a
+    # hyper-parameter that already had one): the list of leaf parameters and the classes / orders of the nodes are
+    # rebuilt only when it has moved -- a sampler's step assigns three floats and pays for three floats.
+    _struct_version = 0
     _PARAMETERS = ("variance", "lengthscales", "period")
 
     def __setattr__(self, name, value):
@@ -71,6 +75,8 @@ class Kernel:
             if arr.ndim == 0 and arr.dtype.kind in "fiu":
                 value = float(arr)
         Kernel._version += 1
+        if not (name in Kernel._PARAMETERS and isinstance(value, float) and isinstance(self.__dict__.get(name), float)):
+            Kernel._struct_version += 1
         object.__setattr__(self, name, value)
 
     def K(self, X, X2=None):

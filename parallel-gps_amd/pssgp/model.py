@@ -116,15 +116,17 @@ class StateSpaceGP:
                 and quick[2] == config.NUMBER_OF_BALANCING_STEPS):
             return quick[3]             # no kernel attribute has been assigned since the key was built
         version = Kernel._version
-        vals = tuple(float(getattr(o, n)) for o, n in leaf_parameters(self.kernel))
+        struct = getattr(self, "_struct_memo", None)
+        if struct is None or struct[0] != Kernel._struct_version or struct[1] is not self.kernel:
+            def shape_of(k):
+                sub = tuple(shape_of(x) for x in getattr(k, "kernels", ()))
+                base = getattr(k, "base_kernel", None)
+                return (type(k).__name__, getattr(k, "_order", None), getattr(k, "_balancing_iter", None), sub,
+                        None if base is None else type(base).__name__)
 
-        def shape_of(k):
-            sub = tuple(shape_of(x) for x in getattr(k, "kernels", ()))
-            base = getattr(k, "base_kernel", None)
-            return (type(k).__name__, getattr(k, "_order", None), getattr(k, "_balancing_iter", None), sub,
-                    None if base is None else type(base).__name__)
-
-        key = (shape_of(self.kernel), config.NUMBER_OF_BALANCING_STEPS) + vals
+            struct = self._struct_memo = (Kernel._struct_version, self.kernel, leaf_parameters(self.kernel), shape_of(self.kernel))
+        vals = tuple([float(o.__dict__[n]) for o, n in struct[2]])
+        key = (struct[3], config.NUMBER_OF_BALANCING_STEPS) + vals
         self._key_memo = (version, self.kernel, config.NUMBER_OF_BALANCING_STEPS, key)
         return key
 
