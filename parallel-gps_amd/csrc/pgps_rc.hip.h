@@ -628,8 +628,11 @@ __device__ __forceinline__ RcArgsT<Real> model_view(const RcArgsT<Real>& a) {
 // step (F = I, Q = 0 there) and / or its last one (the fetch a step ahead runs off the end of the arrays: descriptor cut,
 // index clamped) -- the same road, a handful of selects.  The general body is for ragged ends only: it is slower, and in a
 // one-round grid its wave is what the kernel waits for (c5: 563 against 511 us with the edge waves switched off).
-template <typename Real, int D, bool FAST, bool EDGE = false>
-__device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
+// IMPQ (the process noise is implicit, below) is a compile-time flavour: with the flag read at run time both Q and Pinf stay
+// live through the step loop -- 22 registers at d = 11 fp64, exactly what kept the kernel from two waves per SIMD (268
+// registers; either flavour alone: two waves, no scratch).
+template <typename Real, int D, bool FAST, bool EDGE, bool IMPQ>
+__device__ __forceinline__ void reduce1_body_q(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
     static_assert(FAST || !EDGE, "EDGE is a flavour of the FAST body");
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;        // row 0's first step
@@ -654,7 +657,7 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
     zero<D>(Fc); zero<D>(Fr); zero<D>(Q);
     // Implicit process noise (general-LTI log-likelihood calls): Q_k = Pinf - F_k Pinf F_k^T is never formed --
     // F C F^T + Q = F (C - Pinf) F^T + Pinf -- so the (N, d, d) array Qs does not exist; F = I gives Q = 0 by itself.
-    const bool impq = a.implicit_q != 0;         // bit 0: Qs absent; bit 1: Qs there, but P0 known stationary -- skip reading it
+    constexpr bool impq = IMPQ;                  // (a.implicit_q: bit 0: Qs absent; bit 1: Qs there, but P0 known stationary -- skip reading it)
     Real Pinf[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) Pinf[i] = (impq && lv) ? Real(0.5) * (a.P0[i * D + lane] + a.P0[lane * D + i]) : Real(0.0);
@@ -769,6 +772,12 @@ __device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch
         rec[3 * dd + lane] = b;
         rec[3 * dd + D + lane] = eta;
     }
+}
+
+template <typename Real, int D, bool FAST, bool EDGE = false>
+__device__ __forceinline__ void reduce1_body(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
+    if (a.implicit_q != 0) reduce1_body_q<Real, D, FAST, EDGE, true>(a, patch, wslots, lane, row);
+    else reduce1_body_q<Real, D, FAST, EDGE, false>(a, patch, wslots, lane, row);
 }
 
 template <typename Real, int D>
