@@ -693,6 +693,16 @@ class LtiLlStream:
             ctx.close()
 
 
+class _Packed(tuple):
+    """(lam, N1, N2, Pinf, H, d) of Series.pack with the arrays' ctypes pointers made once (`.ptrs`: four data_as() calls are
+    3 us of a 36 us evaluation)."""
+
+    def __new__(cls, items):
+        self = super().__new__(cls, items)
+        self.ptrs = tuple(_ptr(a) for a in items[1:5])
+        return self
+
+
 class Series:
     """A series kept on the device across calls (pgps_series_*, include/pgps.h): what an optimiser or sampler loop
     evaluates thousands of times is ONE (ts, ys) at changing hyper-parameters, and predict_f on a fixed grid.  The
@@ -736,6 +746,7 @@ class Series:
         self._ll = c_double(0.0)
         self._llp = ctypes.cast(ctypes.byref(self._ll), P)
         self._gout = np.zeros(32, np.float64)
+        self._goutp = _ptr(self._gout)
 
     def set_queries(self, tq):
         """The (sorted) query times of predict(); merged with the series on the device once."""
@@ -756,12 +767,13 @@ class Series:
         c = lambda a, shape: a if (type(a) is np.ndarray and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == shape) \
             else _prep(a, np.float64, shape)
         Hv = np.asarray(H, np.float64).reshape(-1)
-        return (float(lam), c(N1, (d, d)), c(N2, (d, d)), c(Pinf, (d, d)), c(Hv, (d,)), d)
+        return _Packed((float(lam), c(N1, (d, d)), c(N2, (d, d)), c(Pinf, (d, d)), c(Hv, (d,)), d))
 
     def gp_ll(self, packed, R):
         lam, N1, N2, Pinf, H, d = packed
+        p1, p2, p3, p4 = packed.ptrs if hasattr(packed, "ptrs") else (_ptr(N1), _ptr(N2), _ptr(Pinf), _ptr(H))
         with self.ctx.lock:
-            check(self.ctx, self.ctx.lib.pgps_series_gp_ll_f64(self.handle, d, lam, _ptr(N1), _ptr(N2), _ptr(Pinf), _ptr(H),
+            check(self.ctx, self.ctx.lib.pgps_series_gp_ll_f64(self.handle, d, lam, p1, p2, p3, p4,
                                                                float(R), self._llp), "pgps_series_gp_ll_f64")
         return self._ll.value
 
@@ -819,18 +831,20 @@ class Series:
         """The same call, results left in the handle's output buffer [ll | Abar | Ubar | Hbar | Rbar] (a view: valid until
         the next call) -- for callers that contract them in place."""
         lam, N1, N2, Pinf, H, d = packed
+        p1, p2, p3, p4 = packed.ptrs if hasattr(packed, "ptrs") else (_ptr(N1), _ptr(N2), _ptr(Pinf), _ptr(H))
         with self.ctx.lock:
-            check(self.ctx, self.ctx.lib.pgps_series_gp_ll_grad_adj_f64(self.handle, d, lam, _ptr(N1), _ptr(N2), _ptr(Pinf), _ptr(H),
-                                                                        float(R), _ptr(self._gout)), "pgps_series_gp_ll_grad_adj_f64")
+            check(self.ctx, self.ctx.lib.pgps_series_gp_ll_grad_adj_f64(self.handle, d, lam, p1, p2, p3, p4,
+                                                                        float(R), self._goutp), "pgps_series_gp_ll_grad_adj_f64")
         return self._gout
 
     def gp_predict(self, packed, R):
         """(mean (K,), var (K,), ll) at the query grid of set_queries()."""
         lam, N1, N2, Pinf, H, d = packed
+        p1, p2, p3, p4 = packed.ptrs if hasattr(packed, "ptrs") else (_ptr(N1), _ptr(N2), _ptr(Pinf), _ptr(H))
         mean, var = np.empty(self.K, np.float64), np.empty(self.K, np.float64)
         with self.ctx.lock:
-            check(self.ctx, self.ctx.lib.pgps_series_gp_predict_f64(self.handle, d, lam, _ptr(N1), _ptr(N2), _ptr(Pinf),
-                                                                    _ptr(H), float(R), _ptr(mean), _ptr(var), self._llp),
+            check(self.ctx, self.ctx.lib.pgps_series_gp_predict_f64(self.handle, d, lam, p1, p2, p3,
+                                                                    p4, float(R), _ptr(mean), _ptr(var), self._llp),
                   "pgps_series_gp_predict_f64")
         return mean, var, self._ll.value
 
