@@ -657,7 +657,11 @@ class StateSpaceGP:
                 ok = (_backend.LTI_DIM_MIN <= F.shape[0] <= _backend.LTI_DIM_MAX and np.all(np.isfinite(F)) and np.all(np.isfinite(P0))
                       and np.max(np.abs(F @ P0 + P0 @ F.T + LQL)) <= 1e-8 * max(1.0, float(np.max(np.abs(LQL)))))
                 for dF, dP, dH in grads if ok else ():
-                    if not (np.all(np.isfinite(dF)) and np.all(np.isfinite(dP))) or \
+                    if not np.all(np.isfinite(dP)):
+                        ok = False
+                    if not dF.any():
+                        continue                    # (most parameters move Pinf or H only: nothing to commute)
+                    if not np.all(np.isfinite(dF)) or \
                             np.max(np.abs(F @ dF - dF @ F)) > 1e-9 * fmax * max(1.0, float(np.max(np.abs(dF)))):
                         ok = False
                 if ok:
