@@ -96,6 +96,16 @@ def _pairwise_dist(X, X2):
     return np.abs(X[:, None] - X2[None, :])
 
 
+def _tree_ids(k):
+    """The identities of a kernel's nodes: a part swapped IN PLACE (`k.kernels[0] = ...`, no attribute assignment, so no
+    version bump) must not find the old tree's memoised SDE."""
+    subs = getattr(k, "kernels", None)
+    base = getattr(k, "base_kernel", None)
+    if not subs and base is None:
+        return id(k)
+    return (id(k), tuple(_tree_ids(x) for x in subs) if subs else (), id(base) if base is not None else 0)
+
+
 class SDEKernelMixin:
     """`get_sde()` -> continuous model; `get_ssm(ts, R, t0)` -> LGSSM (base.py:50-103)."""
 
@@ -115,7 +125,7 @@ class SDEKernelMixin:
             return
 
         def get_sde(self, _f=f):
-            key = (Kernel._version, pssgp_config.NUMBER_OF_BALANCING_STEPS, pssgp_config.default_float())
+            key = (Kernel._version, pssgp_config.NUMBER_OF_BALANCING_STEPS, pssgp_config.default_float(), _tree_ids(self))
             memo = self.__dict__.get("_sde_memo")
             if memo is not None and memo[0] == key:
                 return memo[1]

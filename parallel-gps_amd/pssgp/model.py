@@ -10,7 +10,7 @@ the scan kernels) instead of TensorFlow autodiff.
 import numpy as np
 
 from . import config
-from .kernels.base import Kernel
+from .kernels.base import Kernel, _tree_ids
 from .kernels.sde_grads import leaf_parameters
 from .kalman.parallel import pkf, pkfs
 from .kalman.sequential import kf, kfs
@@ -112,22 +112,23 @@ class StateSpaceGP:
         shapes the SDE (order, balancing sweeps, the class of every node).  The memo keeps a reference to the kernel it
         was made for and is compared by identity (`is`), so a new kernel object never finds an old one's forms."""
         quick = getattr(self, "_key_memo", None)
+        tree = _tree_ids(self.kernel)   # (a part swapped in place -- `kernel.kernels[0] = ...` -- assigns no attribute)
         if (quick is not None and quick[0] == Kernel._version and quick[1] is self.kernel
-                and quick[2] == config.NUMBER_OF_BALANCING_STEPS):
+                and quick[2] == config.NUMBER_OF_BALANCING_STEPS and quick[4] == tree):
             return quick[3]             # no kernel attribute has been assigned since the key was built
         version = Kernel._version
         struct = getattr(self, "_struct_memo", None)
-        if struct is None or struct[0] != Kernel._struct_version or struct[1] is not self.kernel:
+        if struct is None or struct[0] != Kernel._struct_version or struct[1] is not self.kernel or struct[4] != tree:
             def shape_of(k):
                 sub = tuple(shape_of(x) for x in getattr(k, "kernels", ()))
                 base = getattr(k, "base_kernel", None)
                 return (type(k).__name__, getattr(k, "_order", None), getattr(k, "_balancing_iter", None), sub,
                         None if base is None else type(base).__name__)
 
-            struct = self._struct_memo = (Kernel._struct_version, self.kernel, leaf_parameters(self.kernel), shape_of(self.kernel))
+            struct = self._struct_memo = (Kernel._struct_version, self.kernel, leaf_parameters(self.kernel), shape_of(self.kernel), tree)
         vals = tuple([float(o.__dict__[n]) for o, n in struct[2]])
         key = (struct[3], config.NUMBER_OF_BALANCING_STEPS) + vals
-        self._key_memo = (version, self.kernel, config.NUMBER_OF_BALANCING_STEPS, key)
+        self._key_memo = (version, self.kernel, config.NUMBER_OF_BALANCING_STEPS, key, tree)
         return key
 
     def _device_series(self, force=False):

@@ -224,3 +224,13 @@ def test_get_sde_is_memoised_per_kernel_object_until_a_parameter_moves():
         assert m.get_sde() is not s3
     finally:
         config.set_number_balancing_steps(old)
+
+
+def test_get_sde_memo_sees_a_part_swapped_in_place():
+    from pssgp.kernels import Matern12, Matern32, Matern52
+    q = Matern32(1.0, 1.0) + Matern52(1.0, 1.0)
+    a = q.get_sde()
+    assert q.get_sde() is a
+    q.kernels[0] = Matern12(1.0, 1.0)           # no attribute of any kernel is assigned
+    b = q.get_sde()
+    assert b is not a and np.asarray(b.F).shape == (4, 4) and np.asarray(a.F).shape == (5, 5)
