@@ -697,10 +697,34 @@ class _Packed(tuple):
     """(lam, N1, N2, Pinf, H, d) of Series.pack with the arrays' ctypes pointers made once (`.ptrs`: four data_as() calls are
     3 us of a 36 us evaluation)."""
 
-    def __new__(cls, items):
+    def __new__(cls, items, ptrs=None):
         self = super().__new__(cls, items)
-        self.ptrs = tuple(_ptr(a) for a in items[1:5])
+        self.ptrs = tuple(_ptr(a) for a in items[1:5]) if ptrs is None else ptrs
         return self
+
+
+class PackBuffer:
+    """One model's (N1, N2, Pinf, H) in a buffer that lives as long as the model: a new hyper-parameter setting copies 30
+    doubles into it and reuses the four ctypes pointers (making them is ~10 us of a 40 us evaluation at a new setting).
+    The tuple `pack()` returns is valid until the next `pack()`: the series calls are synchronous, nothing keeps an older one."""
+
+    def __init__(self, d):
+        self.d = d
+        self.buf = np.zeros(3 * d * d + d, np.float64)
+        dd = d * d
+        self.views = (self.buf[0:dd].reshape(d, d), self.buf[dd:2 * dd].reshape(d, d), self.buf[2 * dd:3 * dd].reshape(d, d),
+                      self.buf[3 * dd:3 * dd + d])
+        base = self.buf.ctypes.data
+        self.ptrs = (c_void_p(base), c_void_p(base + 8 * dd), c_void_p(base + 16 * dd), c_void_p(base + 24 * dd))
+
+    def pack(self, form, Pinf, H):
+        lam, N1, N2 = form
+        v = self.views
+        v[0][...] = N1
+        v[1][...] = N2
+        v[2][...] = Pinf
+        v[3][...] = np.asarray(H).reshape(-1)
+        return _Packed((float(lam), v[0], v[1], v[2], v[3], self.d), self.ptrs)
 
 
 class Series:

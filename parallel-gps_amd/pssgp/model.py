@@ -188,7 +188,11 @@ class StateSpaceGP:
             return memo[1]
         from . import _backend
         sde, form = fused
-        packed = _backend.Series.pack(form, sde.P0, sde.H)
+        d = form[1].shape[0]
+        pb = getattr(self, "_pack_buffer", None)
+        if pb is None or pb.d != d:
+            pb = self._pack_buffer = _backend.PackBuffer(d)
+        packed = pb.pack(form, sde.P0, sde.H)       # (views into the model's own buffer: valid until the next setting)
         self._packed_memo = (fused, packed)
         return packed
 
