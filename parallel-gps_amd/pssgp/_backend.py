@@ -771,6 +771,7 @@ class Series:
         self._llp = ctypes.cast(ctypes.byref(self._ll), P)
         self._gout = np.zeros(32, np.float64)
         self._goutp = _ptr(self._gout)
+        self._lti_slots = {}
 
     def set_queries(self, tq):
         """The (sorted) query times of predict(); merged with the series on the device once."""
@@ -782,6 +783,7 @@ class Series:
                   "pgps_series_set_queries_f64")
         self._tq, self.K = tq_a.copy(), tq_a.shape[0]
         self._mean, self._var = np.empty(self.K, np.float64), np.empty(self.K, np.float64)
+        self._meanp, self._varp = _ptr(self._mean), _ptr(self._var)
 
     @staticmethod
     def pack(form, Pinf, H):
@@ -802,28 +804,47 @@ class Series:
         return self._ll.value
 
     # -- any kernel's LTI model (F, Pinf, H), fp64, 2 <= d <= 32: pgps_series_lti_* ------------------------------
+    def _lti_slot(self, F, Pinf, H):
+        """(d, pF, pPinf, pH, out, pout): the model copied into this handle's buffer for its state dimension -- the ctypes
+        pointers of a dimension are made once (three data_as() calls and an output array per evaluation were ~10 us)."""
+        F = np.asarray(F)
+        d = F.shape[0]
+        slot = self._lti_slots.get(d)
+        if slot is None:
+            if F.ndim != 2 or F.shape[1] != d or not (LTI_DIM_MIN <= d <= LTI_DIM_MAX):
+                raise ValueError(f"the general-LTI device path covers state dimensions {LTI_DIM_MIN}..{LTI_DIM_MAX}, got {F.shape}")
+            dd = d * d
+            buf = np.zeros(2 * dd + d, np.float64)
+            out = np.zeros(2 + dd + 2 * d, np.float64)
+            base = buf.ctypes.data
+            slot = self._lti_slots[d] = (buf, buf[0:dd].reshape(d, d), buf[dd:2 * dd].reshape(d, d), buf[2 * dd:2 * dd + d],
+                                         c_void_p(base), c_void_p(base + 8 * dd), c_void_p(base + 16 * dd), out, _ptr(out))
+        slot[1][...] = F
+        slot[2][...] = Pinf
+        slot[3][...] = np.asarray(H).reshape(-1)
+        return d, slot[4], slot[5], slot[6], slot[7], slot[8]
+
     def lti_ll(self, F, Pinf, H, R):
-        F, Pinf, H, d = _lti_model(F, Pinf, H)
+        d, pF, pP, pH, _, _ = self._lti_slot(F, Pinf, H)
         with self.ctx.lock:
-            check(self.ctx, self.ctx.lib.pgps_series_lti_ll_f64(self.handle, d, _ptr(F), _ptr(Pinf), _ptr(H), float(R), self._llp),
+            check(self.ctx, self.ctx.lib.pgps_series_lti_ll_f64(self.handle, d, pF, pP, pH, float(R), self._llp),
                   "pgps_series_lti_ll_f64")
         return self._ll.value
 
     def lti_ll_grad(self, F, Pinf, H, R):
         """(ll, Abar, Ubar, Hbar, Rbar): the log-likelihood and the model's adjoints (pgps_series_lti_ll_grad_f64)."""
-        F, Pinf, H, d = _lti_model(F, Pinf, H)
-        out = np.zeros(2 + d * d + 2 * d, np.float64)
+        d, pF, pP, pH, out, pout = self._lti_slot(F, Pinf, H)
         with self.ctx.lock:
-            check(self.ctx, self.ctx.lib.pgps_series_lti_ll_grad_f64(self.handle, d, _ptr(F), _ptr(Pinf), _ptr(H), float(R), _ptr(out)),
+            check(self.ctx, self.ctx.lib.pgps_series_lti_ll_grad_f64(self.handle, d, pF, pP, pH, float(R), pout),
                   "pgps_series_lti_ll_grad_f64")
         return split_grad_stats(out, d)
 
     def lti_predict(self, F, Pinf, H, R):
         """(mean (K,), var (K,), ll) at the query grid of set_queries()."""
-        F, Pinf, H, d = _lti_model(F, Pinf, H)
+        d, pF, pP, pH, _, _ = self._lti_slot(F, Pinf, H)
         with self.ctx.lock:
-            check(self.ctx, self.ctx.lib.pgps_series_lti_predict_f64(self.handle, d, _ptr(F), _ptr(Pinf), _ptr(H), float(R),
-                                                                    _ptr(self._mean), _ptr(self._var), self._llp),
+            check(self.ctx, self.ctx.lib.pgps_series_lti_predict_f64(self.handle, d, pF, pP, pH, float(R),
+                                                                    self._meanp, self._varp, self._llp),
                   "pgps_series_lti_predict_f64")
         return self._mean.copy(), self._var.copy(), self._ll.value
 
