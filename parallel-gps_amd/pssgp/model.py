@@ -688,7 +688,19 @@ class StateSpaceGP:
             raise
         except RuntimeError:
             return None
-        g = _backend.contract_grad_stats(stats, H, grads)
+        # contraction <Abar, dF> + Ubar^T dPinf H^T + Hbar . dH per parameter, the identically-zero components skipped (a
+        # parameter moves one of F, Pinf, H: one dot product each instead of three products on zeros -- `_backend.
+        # contract_grad_stats` is the plain form the tests check this against)
+        fast = getattr(self, "_contract_memo", None)
+        if fast is None or fast[0] is not grads:
+            h = H.reshape(-1)
+            rows = [(dF.reshape(-1) if np.any(dF) else None, (np.asarray(dP) @ h) if np.any(dP) else None,
+                     np.asarray(dH).reshape(-1) if np.any(dH) else None) for dF, dP, dH in grads]
+            fast = self._contract_memo = (grads, rows)
+        _, Abar, Ubar, Hbar, Rbar = stats
+        Av = Abar.reshape(-1)
+        g = np.array([(0.0 if a is None else float(Av @ a)) + (0.0 if u is None else float(Ubar @ u))
+                      + (0.0 if hh is None else float(Hbar @ hh)) for a, u, hh in fast[1]] + [float(Rbar)])
         if wrt is not None:
             keep = np.zeros(len(g), bool)
             keep[[int(i) for i in wrt]] = True
