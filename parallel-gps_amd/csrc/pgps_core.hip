@@ -94,6 +94,8 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
     if (ctx->stamps.p) (void)hipFree(ctx->stamps.p);
     if (ctx->gadj.p) (void)hipFree(ctx->gadj.p);
+    if (ctx->pin_d.p) (void)hipFree(ctx->pin_d.p);
+    if (ctx->pin_h) (void)hipHostFree(ctx->pin_h);
     if (ctx->status_word) (void)hipFree(ctx->status_word);
     for (auto& b : ctx->st)
         if (b.p) (void)hipFree(b.p);
@@ -821,6 +823,51 @@ static int stage_out(pgps_ctx* ctx, T* host, const T* dev, size_t n) {
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+// A call whose host arrays are small -- the first evaluation of a model at the reference's series lengths, the whole of its
+// speed protocol (experiments/toy_models/speed_and_stability.py:73-87) -- pays for every hipMemcpy from pageable memory (a
+// staged, host-synchronous copy of ~10 us whatever its size).  SmallStage lays the call's inputs out in one pinned arena
+// (plain memcpy), sends them with ONE asynchronous copy, and brings the outputs back with ONE: three inputs and three
+// outputs of pgps_gp_predict_f64 at N = K = 4096 were six such copies (model + predict_f 178 -> 140 us).
+constexpr size_t kPinArena = 2u << 20;
+struct SmallStage {
+    pgps_ctx* ctx;
+    size_t in_bytes = 0, out_bytes = 0, in_cap, out_off;
+    bool ok = false;
+    struct Out { void* host; size_t off, bytes; } outs[4];
+    int nout = 0;
+    // in_total / out_total: bytes of all inputs / outputs (each rounded up to 16)
+    SmallStage(pgps_ctx* c, size_t in_total, size_t out_total) : ctx(c), in_cap(in_total), out_off(in_total) {
+        if (in_total + out_total > kPinArena) return;
+        if (!ctx->pin_h && hipHostMalloc((void**)&ctx->pin_h, kPinArena, hipHostMallocDefault) != hipSuccess) { ctx->pin_h = nullptr; return; }
+        if (ensure(ctx, ctx->pin_d, kPinArena) != PGPS_OK) return;
+        ok = true;
+    }
+    static size_t up(size_t b) { return (b + 15) / 16 * 16; }
+    template <typename T> T* in(const T* host, size_t n) {          // -> device pointer of the staged copy
+        T* dev = (T*)((char*)ctx->pin_d.p + in_bytes);
+        memcpy(ctx->pin_h + in_bytes, host, n * sizeof(T));
+        in_bytes += up(n * sizeof(T));
+        return dev;
+    }
+    template <typename T> T* out(T* host, size_t n) {               // -> device pointer the call writes, copied back by finish()
+        T* dev = (T*)((char*)ctx->pin_d.p + out_off + out_bytes);
+        outs[nout++] = {(void*)host, out_off + out_bytes, n * sizeof(T)};
+        out_bytes += up(n * sizeof(T));
+        return dev;
+    }
+    int send() {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_d.p, ctx->pin_h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        return PGPS_OK;
+    }
+    int finish() {                                                  // one copy back, the synchronisation, the scatter
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_h + out_off, (char*)ctx->pin_d.p + out_off, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < nout; ++i)
+            if (outs[i].host) memcpy(outs[i].host, ctx->pin_h + outs[i].off, outs[i].bytes);
+        return PGPS_OK;
+    }
+};
+
 template <typename T>
 static int pkf_host(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, const T* Qs, const T* H, T R,
                     const T* ys, T* fms, T* fPs, double* ll) {
@@ -1377,6 +1424,24 @@ static int gp_predict_host(pgps_ctx* ctx, long N, long K, int d, double lam, con
                            const T* tq, T* mean, T* var, double* ll) {
     if (!ctx || N < 1 || K < 1 || !ts || !ys || !tq || !mean || !var) return PGPS_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        SmallStage st(ctx, 2 * SmallStage::up((size_t)N * sizeof(T)) + SmallStage::up((size_t)K * sizeof(T)),
+                      2 * SmallStage::up((size_t)K * sizeof(T)) + 16);
+        if (st.ok) {
+            double llh = 0.0;
+            T* dts = st.in(ts, (size_t)N);
+            T* dys = st.in(ys, (size_t)N);
+            T* dtq = st.in(tq, (size_t)K);
+            double* dll = st.out(&llh, 1);
+            T* dmean = st.out(mean, (size_t)K);
+            T* dvar = st.out(var, (size_t)K);
+            TRY(st.send());
+            TRY(gp_predict_dev<T>(ctx, N, K, d, lam, N1, N2, Pinf, H, R, dts, dys, t0, dtq, dmean, dvar, dll));
+            TRY(st.finish());
+            if (ll) *ll = llh;
+            return std::isfinite(llh) ? PGPS_OK : PGPS_E_NUMERIC;
+        }
+    }
     T *dts, *dys, *dtq, *dmean, *dvar;
     double* dll;
     TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
@@ -1865,6 +1930,23 @@ static int lti_host(pgps_ctx* ctx, long N, long K, int d, const double* F, const
     if (!ctx || N < 1 || K < 0 || !ts || !ys) return PGPS_E_INVALID;
     if (K > 0 && (!tq || !mean || !var)) return PGPS_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        SmallStage st(ctx, 2 * SmallStage::up((size_t)N * 8) + SmallStage::up((size_t)K * 8), 2 * SmallStage::up((size_t)K * 8) + 16);
+        if (st.ok) {
+            double llh = 0.0;
+            double* dts_ = st.in(ts, (size_t)N);
+            double* dys_ = st.in(ys, (size_t)N);
+            double* dtq_ = K > 0 ? st.in(tq, (size_t)K) : nullptr;
+            double* dll_ = st.out(&llh, 1);
+            double* dmean_ = K > 0 ? st.out(mean, (size_t)K) : nullptr;
+            double* dvar_ = K > 0 ? st.out(var, (size_t)K) : nullptr;
+            TRY(st.send());
+            TRY(lti_dev(ctx, N, K, d, F, Pinf, H, R, dts_, dys_, t0, dtq_, dmean_, dvar_, dll_));
+            TRY(st.finish());
+            if (ll) *ll = llh;
+            return std::isfinite(llh) ? PGPS_OK : PGPS_E_NUMERIC;
+        }
+    }
     double *dts, *dys, *dtq = nullptr, *dmean = nullptr, *dvar = nullptr, *dll;
     TRY(stage_in(ctx, ctx->st[10], ts, (size_t)N, &dts));
     TRY(stage_in(ctx, ctx->st[4], ys, (size_t)N, &dys));

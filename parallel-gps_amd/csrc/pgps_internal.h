@@ -48,6 +48,9 @@ struct pgps_ctx {
     hipEvent_t probe_in = nullptr;      // recorded on the context's stream at the call's entry: the probe's stream waits for it
     hipStream_t probe_stream = nullptr; // the probe runs beside the call's first kernel, not in front of it
     int f32_last_promoted = 0;          // which way the last probed call went: decides the ORDER of the next one (see pgps_core.hip)
+    // small host-array calls (pgps_gp_predict_*, pgps_lti_predict_f64, ...): one pinned arena, ONE copy in and ONE copy out
+    char* pin_h = nullptr;              // hipHostMalloc, kPinArena bytes, made at the first small call
+    DevBuf pin_d;                       // its device twin
     DevBuf gadj;                        // fused-path adjoint gradient (pgps_gpadj.hip.h): kept states of the forward pass, workgroup partials
     DevBuf wide[9];                     // fp64 copies of a promoted float32 call's arrays: P0, H, Fs, Qs, ys, fms, fPs, sms, sPs
     void* comm = nullptr;               // ncclComm_t (RCCL) of a series sharded over GPUs: pgps_comm_init (pgps_comm.hip)
