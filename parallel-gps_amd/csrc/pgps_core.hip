@@ -1221,6 +1221,20 @@ static int gp_host(pgps_ctx* ctx, long N, int d, double lam, const double* N1, c
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)N, dd = (size_t)d * d;
     const bool wf = fms || fPs || sms || sPs, wsm = sms || sPs;
+    if (!wf) {                  // log-likelihood only (a model's first objective): the small-call road
+        SmallStage st(ctx, 2 * SmallStage::up(n * sizeof(T)), 16);
+        if (st.ok) {
+            double llh = 0.0;
+            T* dys_ = st.in(ys, n);
+            T* dts_ = st.in(ts, n);
+            double* dll_ = st.out(&llh, 1);
+            TRY(st.send());
+            TRY(gp_dev<T>(ctx, N, d, lam, N1, N2, Pinf, H, R, dts_, t0, dys_, nullptr, nullptr, nullptr, nullptr, dll_));
+            TRY(st.finish());
+            if (ll) *ll = llh;
+            return std::isfinite(llh) ? PGPS_OK : PGPS_E_NUMERIC;
+        }
+    }
     T *dts, *dys, *dfms = nullptr, *dfPs = nullptr, *dsms = nullptr, *dsPs = nullptr;
     double* dll;
     TRY(stage_in(ctx, ctx->st[4], ys, n, &dys));
