@@ -431,7 +431,8 @@ class StateSpaceGP:
         lengthscale and period (the reference's gpflow Parameters: the Matern / RBF kernels' variance /
         lengthscales, Periodic's period and its base kernel's parameters, the leaves of sums and products in order),
         then the observation-noise variance (pssgp/model.py:68)."""
-        return leaf_parameters(self.kernel) + [(self, "noise_variance")]
+        self._param_key()                           # (validates the memoised structure of the kernel)
+        return list(self._struct_memo[2]) + [(self, "noise_variance")]
 
     def _grad_blocks_matern(self):
         """_grad_blocks() of a single Matern-1/2, -3/2 or -5/2 kernel in closed form, from the memoised get_sde() of the
@@ -604,8 +605,10 @@ class StateSpaceGP:
         lam, N1, _, Pinf, H, d = packed
         memo = getattr(self, "_fadj_memo", None)
         if memo is None or memo[0] is not packed:
-            F = (N1 - lam * np.eye(d)).reshape(-1)
-            memo = self._fadj_memo = (packed, F, Pinf @ H, [a for _, a in leaf_parameters(self.kernel)])
+            F = N1.reshape(-1).copy()
+            F[::d + 1] -= lam                       # F = N1 - lam I
+            self._param_key()
+            memo = self._fadj_memo = (packed, F, Pinf @ H, [a for _, a in self._struct_memo[2]])
         _, F, PH, names = memo
         out = ser.gp_ll_grad_adj_raw(packed, self.noise_variance)
         dd = d * d
