@@ -69,6 +69,17 @@ int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
 /* Single-pass filter kernel (d <= 2, 16 steps per lane, whole series on one GPU): mode -1 = automatic,
  * 0 = off (three-launch reduce-then-scan), 1 = on; window = tiles per look-back window (1..256, 0 = keep). */
 int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
+/* Filter + log-likelihood + smoother of a whole series in ONE resident launch (csrc/pgps_resident.hip.h): fp64, d = 2,
+ * series of up to 4096 steps per compute unit (2^20 on MI355X); taken by pgps_pkfs_dev_f64 / pgps_pkfs_f64 and by
+ * pgps_gp_dev_f64 / pgps_gp_f64 when smoothed moments are asked for.  Fs, Qs, ys are read once and every output is
+ * written once (the reference's pkf + pks contract, pssgp/kalman/parallel.py:121-201); the launch needs every workgroup
+ * resident, so another stream's kernel holding compute units makes it give up (bounded spins) with bit 1 of
+ * pgps_status set and undefined outputs.  mode -1 = automatic (from 2^18 steps), 0 = never (three launches),
+ * 1 = wherever the series fits, 2 = as 1 with in-kernel phase stamps kept for pgps_resident_stamps (diagnostics). */
+int pgps_set_resident(pgps_ctx* ctx, int mode);
+/* Diagnostics: cycle stamps of the last resident launch made under mode 2: out = (n_blocks, 16) long long (host), at most
+ * max_blocks rows copied; out may be NULL to ask for n_blocks only. */
+int pgps_resident_stamps(pgps_ctx* ctx, long long* out, int max_blocks, int* n_blocks);
 /* Kernel family: 0 = automatic (lane-chunk for d <= 4 and for fp32 up to PGPS_MAX_DIM_LANE; row-cooperative for
  * fp64 with 5 <= d <= 16 and fp32 with 7 <= d <= 16, segments use it above d = 6; quad-cooperative for whole fp32
  * series at d = 8 and, up to 3 * 2^17 and from 3 * 2^19 steps, at d = 6; wave-cooperative otherwise, d <= 32),

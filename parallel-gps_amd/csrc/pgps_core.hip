@@ -76,7 +76,8 @@ extern "C" int pgps_create(int device, pgps_ctx** out) {
     if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->n_cu = 0;
     if (const char* e = std::getenv("PGPS_WC_ROWS2")) ctx->wc_rows2 = std::atoi(e) & 15;            // diagnostic, see pgps_wc.hip
     if (const char* e = std::getenv("PGPS_WC_SERIAL3")) ctx->wc_serial3 = (e[0] == '1');      // diagnostic, see pgps_wc.hip
-    if (hipMalloc((void**)&ctx->status_word, 256) != hipSuccess || hipMemset(ctx->status_word, 0, 256) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->status_word, pgps::kStatusBytes) != hipSuccess ||
+        hipMemset(ctx->status_word, 0, pgps::kStatusBytes) != hipSuccess) {
         (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return PGPS_E_NOMEM;
@@ -93,6 +94,7 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
     if (ctx->comm_buf.p) (void)hipFree(ctx->comm_buf.p);
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
     if (ctx->stamps.p) (void)hipFree(ctx->stamps.p);
+    if (ctx->res_stamps.p) (void)hipFree(ctx->res_stamps.p);
     if (ctx->gadj.p) (void)hipFree(ctx->gadj.p);
     if (ctx->pin_d.p) (void)hipFree(ctx->pin_d.p);
     if (ctx->pin_h) (void)hipHostFree(ctx->pin_h);
@@ -170,6 +172,23 @@ extern "C" int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window) {
     if (!ctx || mode < -1 || mode > 1 || window < 0 || window > 256) return PGPS_E_INVALID;
     ctx->single_pass = mode;
     if (window > 0) ctx->lookback_window = window;
+    return PGPS_OK;
+}
+
+extern "C" int pgps_set_resident(pgps_ctx* ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 2) return PGPS_E_INVALID;
+    ctx->resident = mode;
+    return PGPS_OK;
+}
+
+// diagnostics: the cycle stamps of the last resident launch made with pgps_set_resident(ctx, 2): (workgroups, 16) long long
+extern "C" int pgps_resident_stamps(pgps_ctx* ctx, long long* out, int max_blocks, int* n_blocks) {
+    if (!ctx || !n_blocks) return PGPS_E_INVALID;
+    *n_blocks = ctx->res_stamp_blocks;
+    if (!out || max_blocks <= 0 || !ctx->res_stamps.p) return PGPS_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int n = ctx->res_stamp_blocks < max_blocks ? ctx->res_stamp_blocks : max_blocks;
+    HIPCHK(ctx, hipMemcpy(out, ctx->res_stamps.p, (size_t)n * 16 * sizeof(long long), hipMemcpyDeviceToHost));
     return PGPS_OK;
 }
 
@@ -409,6 +428,20 @@ namespace pgps {
 // which of the two builds of the lane-chunk scan a call (or a rank's segment) of N steps at state dimension d takes
 static bool lane_narrow(const pgps_ctx* ctx, int d, long N) {
     return ctx->block != 256 && (ctx->block == kBlockNarrow || !(d <= 3 && N >= (1L << 22)));
+}
+}  // namespace pgps
+
+namespace pgps {
+// The resident launch (pgps_resident.hip.h) serves whole-series filter + smoother calls at d = 2 in fp64 whose
+// 256 x 16-step workgroups are all resident at once (one per CU); automatic from kResAutoMin steps, where the scan's
+// streaming outweighs the two grid barriers (below that the narrow build's smaller chunks cover more of the chip).
+constexpr long kResAutoMin = 1L << 18;
+bool resident_fits(const pgps_ctx* ctx, long N, int d, bool f32) {
+    if (f32 || d != 2 || ctx->resident == 0 || ctx->n_cu <= 0) return false;
+    if (ctx->chunk > 0 || ctx->block != 0 || ctx->stage_g >= 0 || ctx->single_pass > 0 || ctx->dma > 0) return false;   // a pinned geometry or variant of the three-launch path was asked for
+    if (ctx->family != 0 && ctx->family != 1) return false;
+    if (N > (long)kBlock * kResLc * ctx->n_cu) return false;
+    return ctx->resident > 0 || N >= kResAutoMin;
 }
 }  // namespace pgps
 
@@ -757,7 +790,14 @@ static int pkfs_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, cons
     a.P0 = P0; a.H = H; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys;
     a.fms = fms; a.fPs = fPs; a.sms = sms; a.sPs = sPs; a.ll = ll;
     if constexpr (sizeof(T) == 4) return f32_smoother_call(ctx, d, a, MODE_PKFS);
-    else return dispatch_scan<T>(ctx, d, a, MODE_PKFS);
+    else {
+        if (resident_fits(ctx, N, d, false) && aligned16(ys)) {
+            ResArgs<double> ra{};
+            ra.s = a;
+            return launch_resident<double, 2>(ctx, ra, false);
+        }
+        return dispatch_scan<T>(ctx, d, a, MODE_PKFS);
+    }
 }
 
 template <typename T>
@@ -1174,6 +1214,14 @@ static int gp_dev(pgps_ctx* ctx, long N, int d, double lam, const double* N1, co
     for (int i = 0; i < 3; ++i) g.m.H[i] = i < d ? (T)H[i] : T(0);
     g.m.ts = ts;
     g.m.t_prev = (T)t0;
+    if constexpr (sizeof(T) == 8) {
+        if (sms != nullptr && resident_fits(ctx, N, d, false) && aligned16(ts) && aligned16(ys)) {
+            ResArgs<double> ra{};
+            ra.s = g.s;
+            ra.m = g.m;
+            return launch_resident<double, 2>(ctx, ra, true);
+        }
+    }
     switch (d) {
         case 1: return launch_gp<T, 1>(ctx, g, fms != nullptr, sms != nullptr);
         case 2: return launch_gp<T, 2>(ctx, g, fms != nullptr, sms != nullptr);

@@ -30,6 +30,10 @@ struct pgps_ctx {
     long grad_pack = -1;                // gradient at d <= 2: one direction per model up to this many steps (-1 = automatic, 0 = never)
     int rc_scan = -1;                   // scans of the chain totals (row- / quad-cooperative families): -1 = auto, 0 = one launch per Kogge-Stone level, 1 = blocked (pgps_set_rc_scan)
     int dma = -1;                       // LDS-DMA ring in the Kalman pass (d = 2 fp64, 128-lane build): -1 = auto, 0 = off, 1 = on
+    int resident = -1;                  // one resident launch for filter + smoother (pgps_resident.hip.h): -1 = auto, 0 = off, 1 = on where it fits, 2 = on + phase stamps
+    unsigned res_epoch = 0;             // launches of the resident kernel so far: picks the barrier's counter set
+    DevBuf res_stamps;                  // diagnostics: (workgroups, 16) cycle stamps of the last resident launch
+    int res_stamp_blocks = 0;
     int family = 0;                     // 0 = auto (lane-chunk d <= 6; row-cooperative fp64 d <= 16; else wave-cooperative), 1 = lane, 2 = wave, 3 = row
     std::string hip_err;
     DevBuf ws;                          // scratch of the scan kernels
@@ -197,6 +201,23 @@ struct GpArgs {
 
 template <typename T, int D>
 int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed);
+
+// filter + log-likelihood + smoother of a whole series in one resident launch (pgps_resident.hip.h, pgps_res_inst.hip)
+template <typename T>
+struct ResArgs {
+    ScanArgs<T> s;          // N, nblocks, model, series, outputs, spine / sspine / llpart, status, ll
+    GpModel<T> m;           // fused form: the Matern model (F = -lam I + N) and the time stamps
+    int* bar;               // this launch's 8 counter shards (32 ints apart), zero on entry
+    int* bar_next;          // the next launch's: zeroed by this one
+    long long* stamps;      // diagnostics (pgps_set_resident(ctx, 2)): (nblocks, 16) cycle stamps, else null
+};
+constexpr int kResLc = 16;                  // steps per lane: the chunk lives in registers
+constexpr int kStatusBytes = 8192;          // the context's status buffer: word 0 flags, 16.. tickets, 512.. the resident kernel's barrier counters
+constexpr int kResBarWord = 512;            // two sets of 8 shards x 32 ints
+// does a whole-series filter + smoother call of N steps at dimension d (fp64 when !f32) take the resident launch?
+bool resident_fits(const pgps_ctx* ctx, long N, int d, bool f32);
+template <typename T, int D>
+int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused);
 // log-likelihood and the model's adjoints on the fused path (pgps_gpadj.hip.h), fp64, d <= 3: out = 1 + d^2 + 2 d + 1 doubles [device]
 // (T names the unit that holds the instantiation: call it with T = double)
 template <typename T, int D>

@@ -1,0 +1,54 @@
+// pgps_res_inst.hip -- the resident filter + smoother launch (pgps_resident.hip.h) instantiated for one (dtype, d):
+// array form (Fs, Qs given: pgps_pkfs_dev_*) and fused form (Matern model + time stamps: pgps_gp_dev_*).
+#include "pgps_resident.hip.h"
+
+#ifndef PGPS_RES_T
+#error "compile with -DPGPS_RES_T=<float|double> -DPGPS_RES_D=<d>"
+#endif
+
+namespace pgps {
+
+template <typename T, int D>
+int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ScanArgs<T>& a = ra.s;
+    a.Lc = kResLc;
+    a.nblocks = (int)((a.N + (long)kBlock * kResLc - 1) / ((long)kBlock * kResLc));
+    if (a.nblocks < 1 || a.nblocks > ctx->n_cu) return PGPS_E_INVALID;      // every workgroup must be resident
+    a.nlanes = (long)a.nblocks * kBlock;
+    a.seg_first = 1;
+    a.seg_last = 1;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t nb = (size_t)a.nblocks;
+    size_t off = 0;
+    const size_t o_spine = off;  off = up(off + nb * Dim<D>::NFILT * sizeof(T));
+    const size_t o_sspine = off; off = up(off + nb * Dim<D>::NSMTH * sizeof(T));
+    const size_t o_ll = off;     off = up(off + nb * sizeof(double));
+    int rc = ensure(ctx, ctx->ws, off);
+    if (rc) return rc;
+    ctx->ws_epoch++;
+    char* base = (char*)ctx->ws.p;
+    a.spine = (T*)(base + o_spine);
+    a.sspine = (T*)(base + o_sspine);
+    a.llpart = (double*)(base + o_ll);
+    a.status = ctx->status_word;
+    const unsigned e = ctx->res_epoch++;
+    ra.bar = ctx->status_word + kResBarWord + (e & 1u) * 256;
+    ra.bar_next = ctx->status_word + kResBarWord + ((e + 1u) & 1u) * 256;
+    ra.stamps = nullptr;
+    if (ctx->resident == 2) {
+        rc = ensure(ctx, ctx->res_stamps, nb * 16 * sizeof(long long));
+        if (rc) return rc;
+        ra.stamps = (long long*)ctx->res_stamps.p;
+        ctx->res_stamp_blocks = a.nblocks;
+    }
+    const dim3 grid(a.nblocks), block(kBlock);
+    if (fused) timed_launch(ctx, PGPS_K_FILTER_APPLY, k_pkfs_resident<T, D, kResLc, true>, grid, block, 0, ra);
+    else timed_launch(ctx, PGPS_K_FILTER_APPLY, k_pkfs_resident<T, D, kResLc, false>, grid, block, 0, ra);
+    HIPCHK(ctx, hipGetLastError());
+    return PGPS_OK;
+}
+
+template int launch_resident<PGPS_RES_T, PGPS_RES_D>(pgps_ctx*, ResArgs<PGPS_RES_T>, bool);
+
+}  // namespace pgps

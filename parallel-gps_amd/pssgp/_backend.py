@@ -52,6 +52,9 @@ def _declare(lib):
     lib.pgps_set_block.argtypes = [P, c_int]
     if hasattr(lib, "pgps_set_dma"):
         lib.pgps_set_dma.argtypes = [P, c_int]
+    if hasattr(lib, "pgps_set_resident"):       # (absent from libraries built before round 5: A/B runs load those)
+        lib.pgps_set_resident.argtypes = [P, c_int]
+        lib.pgps_resident_stamps.argtypes = [P, P, c_int, ctypes.POINTER(c_int)]
     if hasattr(lib, "pgps_set_rc_scan"):
         lib.pgps_set_rc_scan.argtypes = [P, c_int]
     if hasattr(lib, "pgps_set_one_launch"):
@@ -197,6 +200,20 @@ class Context:
         """LDS-DMA ring in the Kalman pass (d = 2 fp64, 128-lane build): -1 automatic, 0 off, 1 on (pgps_set_dma)."""
         if hasattr(self.lib, "pgps_set_dma"):
             check(self, self.lib.pgps_set_dma(self.handle, int(mode)), "pgps_set_dma")
+
+    def set_resident(self, mode):
+        """Filter + smoother in ONE resident launch (fp64, d = 2, up to 4096 steps per CU): -1 automatic (from 2^18 steps),
+        0 never, 1 wherever the series fits, 2 = 1 + in-kernel phase stamps (pgps_set_resident)."""
+        if hasattr(self.lib, "pgps_set_resident"):
+            check(self, self.lib.pgps_set_resident(self.handle, int(mode)), "pgps_set_resident")
+
+    def resident_stamps(self):
+        """(workgroups, 16) cycle stamps of the last resident launch made under set_resident(2) (diagnostics)."""
+        n = c_int(0)
+        check(self, self.lib.pgps_resident_stamps(self.handle, None, 0, ctypes.byref(n)), "pgps_resident_stamps")
+        out = np.zeros((max(n.value, 1), 16), np.int64)
+        check(self, self.lib.pgps_resident_stamps(self.handle, _ptr(out), n.value, ctypes.byref(n)), "pgps_resident_stamps")
+        return out[:n.value]
 
     def set_one_launch(self, max_steps):
         """Fused calls of short series in ONE launch up to max_steps steps: -1 automatic (2048 steps: kOneLaunchAuto), 0 never."""
