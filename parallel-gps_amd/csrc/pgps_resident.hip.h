@@ -37,6 +37,8 @@
 // reference's last element (0, m, P) (parallel.py:155-156), and stores beyond N are predicated off -- one code path.
 #pragma once
 
+#include <type_traits>
+
 #include "pgps_fused.hip.h"
 #include "pgps_kernels.hip.h"
 
@@ -52,10 +54,21 @@ struct ResCfg {
     using GM = StageGeom<D * W, G>;                 // m records
     static constexpr int SLOT = LC * MAT * W + 16;  // a lane's LDS slot (LC matrix records) + 16 B: conflict-free owner reads
     static constexpr int SLOTS = kWave * SLOT;      // per wave
-    static constexpr int MST = GM::BYTES;           // per wave: staging of the means of one sub-tile
+    static constexpr int MST = GM::BYTES > 5120 ? GM::BYTES : 5120;     // per wave: staging of the means of one sub-tile / of 64 B per lane of y, t
     static constexpr int NSCAN = kWaves * Dim<D>::NFILT * W;
     static constexpr int BYTES = kWaves * (SLOTS + MST) + NSCAN + kWaves * 8;
 };
+
+// Ordering of a wave's own LDS accesses (one lane writes what another lane of the SAME wave reads next): the LDS executes a
+// wave's instructions in issue order, so the hardware needs nothing -- only the compiler must keep the accesses in program
+// order.  wave_lds_sync() of pgps_kernels.hip.h fences at WORKGROUP scope, which on gfx950 also drains every vector-memory
+// operation of the wave (s_waitcnt vmcnt(0)): each sub-tile then waited for its prefetched loads and for the previous
+// sub-tile's output stores (18 such waits in the Kalman pass alone).  Wavefront scope orders without waiting.
+__device__ __forceinline__ void res_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 #define PGPS_RSTAMP(IDX)                                                                              \
     do {                                                                                              \
@@ -77,26 +90,28 @@ __device__ __forceinline__ V4 res_pad_piece(int kind, int pos_in_rec) {
     return v;
 }
 
-// global -> registers: the pieces of sub-tile `sb` of one matrix array of this wave (piece q = v * 64 + lane belongs to
-// owner q / NV).  `lim` = bytes of the array from the wave's first record on; pieces at or beyond it are padded.
-template <typename T, int D, typename GEO>
-__device__ __forceinline__ void res_issue(const char* __restrict__ g, int sb, long lane_pitch, long lim, bool full, int kind,
-                                          V4* r) {
+// Addressing of the transposing copies.  Piece q = v * 64 + lane of a sub-tile belongs to owner q / NV, position q % NV;
+// with OPI = 64 / NV owners per wave-instruction that is owner v * OPI + lane / NV, position lane % NV: ONE lane-dependent
+// 32-bit offset per array kind and a wave-uniform (scalar) part per instruction -- written out so, because left to the
+// compiler every instruction of every sub-tile kept a vector address of its own alive across the phases (scratch).
+//
+// global -> registers: the pieces of sub-tile `sb` of one matrix array of this wave; `lim` = bytes of the array from the
+// wave's first record on: pieces at or beyond it are padded with the identity step.
+template <typename T, int D, typename GEO, int PITCH>
+__device__ __forceinline__ void res_issue(const char* __restrict__ g /*wave-uniform*/, int sb, long lim, bool full, int kind, V4* r) {
     const int lane = threadIdx.x & (kWave - 1);
+    constexpr int NV = GEO::NV, OPI = kWave / NV;
     constexpr int PPR = D * D * (int)sizeof(T) / 16 > 0 ? D * D * (int)sizeof(T) / 16 : 1;     // pieces per record
+    const unsigned loff = (unsigned)(lane / NV) * PITCH + (unsigned)(lane % NV) * 16u;
     if (full) {
 #pragma unroll
-        for (int v = 0; v < GEO::NV; ++v) {
-            const int q = v * kWave + lane;
-            r[v] = *reinterpret_cast<const V4*>(g + (long)(q / GEO::NV) * lane_pitch + (long)sb * GEO::SEG + (q % GEO::NV) * 16);
-        }
+        for (int v = 0; v < NV; ++v) r[v] = *reinterpret_cast<const V4*>(g + ((long)sb * GEO::SEG + (long)v * OPI * PITCH) + loff);
     } else {
 #pragma unroll
-        for (int v = 0; v < GEO::NV; ++v) {
-            const int q = v * kWave + lane;
-            const long off = (long)(q / GEO::NV) * lane_pitch + (long)sb * GEO::SEG + (q % GEO::NV) * 16;
+        for (int v = 0; v < NV; ++v) {
+            const long off = (long)sb * GEO::SEG + (long)v * OPI * PITCH + loff;
             if (off < lim) r[v] = *reinterpret_cast<const V4*>(g + off);
-            else r[v] = res_pad_piece<T, D>(kind, (q % GEO::NV) % PPR);
+            else r[v] = res_pad_piece<T, D>(kind, (lane % NV) % PPR);
         }
     }
 }
@@ -104,34 +119,37 @@ __device__ __forceinline__ void res_issue(const char* __restrict__ g, int sb, lo
 template <typename GEO, int SLOT>
 __device__ __forceinline__ void res_commit(char* slots, int sb, const V4* r) {
     const int lane = threadIdx.x & (kWave - 1);
+    constexpr int NV = GEO::NV, OPI = kWave / NV;
+    char* base = slots + (lane / NV) * SLOT + (lane % NV) * 16;
 #pragma unroll
-    for (int v = 0; v < GEO::NV; ++v) {
-        const int q = v * kWave + lane;
-        *reinterpret_cast<V4*>(slots + (q / GEO::NV) * SLOT + sb * GEO::SEG + (q % GEO::NV) * 16) = r[v];
-    }
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<V4*>(base + sb * GEO::SEG + v * OPI * SLOT) = r[v];
 }
 // the owners' slots -> global (coalesced), pieces at or beyond `lim` dropped
-template <typename GEO, int SLOT>
-__device__ __forceinline__ void res_drain(char* __restrict__ g, int sb, long lane_pitch, long lim, bool full, const char* slots) {
+template <typename GEO, int SLOT, int PITCH>
+__device__ __forceinline__ void res_drain(char* __restrict__ g /*wave-uniform*/, int sb, long lim, bool full, const char* slots) {
     const int lane = threadIdx.x & (kWave - 1);
+    constexpr int NV = GEO::NV, OPI = kWave / NV;
+    const char* base = slots + (lane / NV) * SLOT + (lane % NV) * 16;
+    const unsigned loff = (unsigned)(lane / NV) * PITCH + (unsigned)(lane % NV) * 16u;
 #pragma unroll
-    for (int v = 0; v < GEO::NV; ++v) {
-        const int q = v * kWave + lane;
-        const V4 x = *reinterpret_cast<const V4*>(slots + (q / GEO::NV) * SLOT + sb * GEO::SEG + (q % GEO::NV) * 16);
-        const long off = (long)(q / GEO::NV) * lane_pitch + (long)sb * GEO::SEG + (q % GEO::NV) * 16;
-        if (full || off < lim) *reinterpret_cast<V4*>(g + off) = x;
+    for (int v = 0; v < NV; ++v) {
+        const V4 x = *reinterpret_cast<const V4*>(base + sb * GEO::SEG + v * OPI * SLOT);
+        const long off = (long)sb * GEO::SEG + (long)v * OPI * PITCH + loff;
+        if (full || off < lim) *reinterpret_cast<V4*>(g + ((long)sb * GEO::SEG + (long)v * OPI * PITCH) + loff) = x;
     }
 }
 // the means of one sub-tile: staging buffer (one sub-tile deep) -> global
-template <typename GEO>
-__device__ __forceinline__ void res_drain_m(char* __restrict__ g, int sb, long lane_pitch, long lim, bool full, const char* mst) {
+template <typename GEO, int PITCH>
+__device__ __forceinline__ void res_drain_m(char* __restrict__ g /*wave-uniform*/, int sb, long lim, bool full, const char* mst) {
     const int lane = threadIdx.x & (kWave - 1);
+    constexpr int NV = GEO::NV, OPI = kWave / NV;
+    const char* base = mst + (lane / NV) * GEO::STRIDE + (lane % NV) * 16;
+    const unsigned loff = (unsigned)(lane / NV) * PITCH + (unsigned)(lane % NV) * 16u;
 #pragma unroll
-    for (int v = 0; v < GEO::NV; ++v) {
-        const int q = v * kWave + lane;
-        const V4 x = *reinterpret_cast<const V4*>(mst + (q / GEO::NV) * GEO::STRIDE + (q % GEO::NV) * 16);
-        const long off = (long)(q / GEO::NV) * lane_pitch + (long)sb * GEO::SEG + (q % GEO::NV) * 16;
-        if (full || off < lim) *reinterpret_cast<V4*>(g + off) = x;
+    for (int v = 0; v < NV; ++v) {
+        const V4 x = *reinterpret_cast<const V4*>(base + v * OPI * GEO::STRIDE);
+        const long off = (long)sb * GEO::SEG + (long)v * OPI * PITCH + loff;
+        if (full || off < lim) *reinterpret_cast<V4*>(g + ((long)sb * GEO::SEG + (long)v * OPI * PITCH) + loff) = x;
     }
 }
 
@@ -146,25 +164,198 @@ __device__ __forceinline__ void res_grid_barrier(int* bar, int tile, int nblocks
     __syncthreads();
 }
 
-// smoothing element of step k_next - 1 from the predict of step k_next (parallel.py:159-166), or the series' last
-// element (k_next == N, parallel.py:155-156), or the identity (padding beyond the series)
+// ---------------------------------------------------------------------------------------------
+// Branch-free forms of the lane-serial steps (same arithmetic, same rounding as filt_extend / kf_step of pgps_math.h for
+// finite operands): a missing observation multiplies the gain by zero instead of branching around the update, so the 16
+// unrolled steps of a phase are ONE basic block and the scheduler can run a step's update chain beside the previous step's
+// smoothing element and hoist the next step's LDS reads -- with the branches every step was four small blocks and each
+// LDS read was waited for where it was issued (25 k cycles for the Kalman pass of 16 steps at d = 2: 3074 vector
+// instructions, half of the time stalls).
+// ---------------------------------------------------------------------------------------------
 template <typename T, int D>
-__device__ __forceinline__ void res_element(long k_next, long N, bool tail, const MeanCov<T, D>& prev, const T* mp, const T* Pp,
-                                            const T* FP, SmthElem<T, D>& e) {
-    smth_element(prev, mp, Pp, FP, e);
-    if (tail) {
-        constexpr int MAT = D * D, SYM = Dim<D>::SYM;
-        const bool last = (k_next == N), pad = (k_next > N);
-        if (last || pad) {
+__device__ __forceinline__ void res_filt_extend(FiltElem<T, D>& e, const T* F, const T* Q /*sym*/, T y, const T* h, T R) {
+    T Ap[D * D], bp[D], FC[D * D], Cp[Dim<D>::SYM];
+    mat_mul<T, D>(F, e.A, Ap);
+    mat_vec<T, D>(F, e.b, bp);
+    predict_cov<T, D>(F, e.C, Q, FC, Cp);
+    const bool obs = !is_nan(y);
+    T u[D], v[D];
+    sym_vec<T, D>(Cp, h, u);
+    mat_t_vec<T, D>(Ap, h, v);
+    T S = R, hb = T(0);
 #pragma unroll
-            for (int i = 0; i < MAT; ++i) e.E[i] = (pad && (i / D == i % D)) ? T(1) : T(0);
+    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; hb += h[i] * bp[i]; }
+    const T inv = obs ? recip(S) : T(0);
+    const T res = obs ? y - hb : T(0);
 #pragma unroll
-            for (int i = 0; i < D; ++i) e.g[i] = last ? prev.m[i] : T(0);
+    for (int i = 0; i < D; ++i) {
+        const T Ki = u[i] * inv;
 #pragma unroll
-            for (int i = 0; i < SYM; ++i) e.L[i] = last ? prev.P[i] : T(0);
+        for (int j = 0; j < D; ++j) e.A[i * D + j] = Ap[i * D + j] - Ki * v[j];
+        e.b[i] = bp[i] + Ki * res;
+        e.eta[i] += v[i] * (res * inv);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            e.C[symi<D>(i, j)] = Cp[symi<D>(i, j)] - u[i] * u[j] * inv;
+            e.J[symi<D>(i, j)] += v[i] * v[j] * inv;
         }
+}
+
+// one Kalman step (not the first of the series) with its log-likelihood term; mp, Pp, FP = the predict, for the smoother
+template <typename T, int D>
+__device__ __forceinline__ void res_kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, const T* h, T R, LogLik& ll,
+                                            T* mp, T* Pp, T* FP) {
+    mat_vec<T, D>(F, s.m, mp);
+    predict_cov<T, D>(F, s.P, Q, FP, Pp);
+    const bool obs = !is_nan(y);
+    T u[D];
+    sym_vec<T, D>(Pp, h, u);
+    T S = R, mu = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; mu += h[i] * mp[i]; }
+    const T rinv = recip(S);
+    {
+        // LogLik::add without the branch: a missing step contributes r = 0, S = 1 (mantissa product and exponent unchanged)
+        const double r = obs ? ll_diff(y, mu) : 0.0;
+        const double Sw = obs ? ll_wide(S) : 1.0;
+        ll.quad += r * r * (obs ? double(rinv) : 0.0);
+        int e;
+        ll.mant = std::frexp(ll.mant * Sw, &e);
+        ll.expo += e;
+        ll.count += obs ? 1 : 0;
+    }
+    const T inv = obs ? rinv : T(0);
+    const T res = obs ? y - mu : T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) s.m[i] = mp[i] + u[i] * (res * inv);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] = Pp[symi<D>(i, j)] - u[i] * u[j] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Workgroup scans whose cross-wave level runs on LANES: the four wave totals sit in lanes 0..3 of every wave and are
+// scanned by two DPP steps (two combines) and the wave's own prefix is read with v_readlane; block_scan_exclusive of
+// pgps_kernels.hip.h walks the four totals one after the other, twice (six combines, every lane the same work).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float res_readlane(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+__device__ __forceinline__ double res_readlane(double x, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+template <typename E>
+__device__ __forceinline__ E res_readlane_elem(const E& e, int l) {
+    using TR = ElemTraits<E>;
+    typename TR::Scalar v[TR::N];
+    pack(e, v);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) v[i] = res_readlane(v[i], l);
+    E r;
+    unpack(v, r);
+    return r;
+}
+// inclusive scan of the values lanes 0..3 hold (identity elsewhere), in place: lanes 0..3 end with the prefixes (FORWARD)
+// or the suffixes of the four
+template <typename E, bool FORWARD>
+__device__ __forceinline__ void res_scan4(E& x, int lane) {
+    using TR = ElemTraits<E>;
+    const int r = lane & 15;
+    auto step = [&](const E& other, bool act) {
+        E t;
+        if (FORWARD) TR::combine(other, x, t); else TR::combine(x, other, t);
+        if (act) x = t;
+    };
+    if constexpr (FORWARD) {
+        step(dpp_elem<kDppRowShr + 1, 0xf>(x), r >= 1);
+        step(dpp_elem<kDppRowShr + 2, 0xf>(x), r >= 2);
+    } else {
+        step(dpp_elem<kDppRowShl + 1, 0xf>(x), r + 1 < 16);
+        step(dpp_elem<kDppRowShl + 2, 0xf>(x), r + 2 < 16);
     }
 }
+template <typename E, bool FORWARD>
+__device__ __forceinline__ void res_block_scan_exclusive(const E& mine, E& excl, E& total, typename ElemTraits<E>::Scalar* lds) {
+    using TR = ElemTraits<E>;
+    static_assert(kWaves == 4, "four wave totals in lanes 0..3");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    E incl = mine;
+    wave_scan_inclusive<E, FORWARD>(incl, lane);
+    E wex = wave_shift1<E, FORWARD>(incl);
+    if (FORWARD ? (lane == 0) : (lane == kWave - 1)) TR::identity(wex);
+    if (FORWARD ? (lane == kWave - 1) : (lane == 0)) rec_store(lds + wave * TR::N, incl);
+    __syncthreads();
+    E t;
+    TR::identity(t);
+    if (lane < kWaves) rec_load(lds + lane * TR::N, t);
+    res_scan4<E, FORWARD>(t, lane);
+    if (FORWARD) {
+        total = res_readlane_elem(t, kWaves - 1);
+        if (wave > 0) { const E p = res_readlane_elem(t, wave - 1); TR::combine(p, wex, excl); } else excl = wex;
+    } else {
+        total = res_readlane_elem(t, 0);
+        if (wave < kWaves - 1) { const E p = res_readlane_elem(t, wave + 1); TR::combine(wex, p, excl); } else excl = wex;
+    }
+    __syncthreads();
+}
+// ordered reduction of one element per lane over the workgroup (lane order = time order), result in every lane
+template <typename E>
+__device__ __forceinline__ void res_block_reduce_ordered(const E& mine, E& total, typename ElemTraits<E>::Scalar* lds) {
+    using TR = ElemTraits<E>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    E acc = mine;
+    wave_scan_inclusive<E, true>(acc, lane);
+    if (lane == kWave - 1) rec_store(lds + wave * TR::N, acc);
+    __syncthreads();
+    E t;
+    TR::identity(t);
+    if (lane < kWaves) rec_load(lds + lane * TR::N, t);
+    res_scan4<E, true>(t, lane);
+    total = res_readlane_elem(t, kWaves - 1);
+    __syncthreads();
+}
+
+// the lane's LC values of a vector array (ys, ts), loaded coalesced and transposed through the wave's staging buffer
+// (64 bytes per lane and round); whole waves only.  issue() first, other loads may follow, finish() waits for these alone.
+template <typename T, int LC>
+struct ResLaneValues {
+    using GY = StageGeom<64, 1>;
+    static constexpr int PER = 64 / (int)sizeof(T);             // values per lane and round
+    static constexpr int R = LC / PER > 0 ? LC / PER : 1;
+    static_assert(LC % PER == 0, "whole rounds");
+    V4 r[R][GY::NV];
+    __device__ __forceinline__ void issue(const T* __restrict__ g /*the wave's first value*/) {
+        const int lane = threadIdx.x & (kWave - 1);
+        constexpr int NV = GY::NV, OPI = kWave / NV, PITCH = LC * (int)sizeof(T);
+        const unsigned loff = (unsigned)(lane / NV) * PITCH + (unsigned)(lane % NV) * 16u;
+#pragma unroll
+        for (int rd = 0; rd < R; ++rd)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                r[rd][v] = *reinterpret_cast<const V4*>(reinterpret_cast<const char*>(g) + ((long)rd * 64 + (long)v * OPI * PITCH) + loff);
+    }
+    __device__ __forceinline__ void finish(char* mst, T* out) {
+        const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+        for (int rd = 0; rd < R; ++rd) {
+            res_wave_sync();
+            constexpr int NV = GY::NV, OPI = kWave / NV;
+            char* base = mst + (lane / NV) * GY::STRIDE + (lane % NV) * 16;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) *reinterpret_cast<V4*>(base + v * OPI * GY::STRIDE) = r[rd][v];
+            res_wave_sync();
+            load_rec<T, PER>(reinterpret_cast<const T*>(mst + lane * GY::STRIDE), out + rd * PER);
+        }
+        res_wave_sync();
+    }
+};
 
 template <typename T, int D, int LC, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
@@ -177,17 +368,19 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT, NS = Dim<D>::NSMTH, G = CFG::G, S = CFG::S;
     constexpr int SLOT = CFG::SLOT;
     static_assert(kBlock == 256, "one workgroup of four waves per CU");
+    static_assert(D <= 2, "resident pass: d <= 2");
     const ScanArgs<T>& a = ra.s;
 
     __shared__ __attribute__((aligned(16))) char smem[CFG::BYTES];
     const int tile = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));    // a scalar: the wave's addresses stay scalar
     char* slots = smem + wave * CFG::SLOTS;                                 // this wave's 64 slots
     char* mst = smem + kWaves * CFG::SLOTS + wave * CFG::MST;               // this wave's staging of the means
     T* lds = reinterpret_cast<T*>(smem + kWaves * (CFG::SLOTS + CFG::MST));   // the workgroup scans' scratch
     double* lds_ll = reinterpret_cast<double*>(smem + kWaves * (CFG::SLOTS + CFG::MST) + CFG::NSCAN);
     char* myslot = slots + lane * SLOT;
+    T* myrec = reinterpret_cast<T*>(myslot);
 
     PGPS_RSTAMP(0);
     if (tile == 0 && threadIdx.x < 8) ra.bar_next[threadIdx.x * 32] = 0;
@@ -197,12 +390,10 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
     const long k0 = gt * LC;
     const long wbase = ((long)tile * kBlock + wave * kWave) * LC;
     const bool full = (wbase + (long)kWave * LC <= N);                      // wave-uniform: no padding, no predicates
-    const bool tail = (wbase + (long)kWave * LC + 1 > N);                   // wave-uniform: holds step N - 1 or padding
-    const long pitchF = (long)LC * MAT * sizeof(T), pitchM = (long)LC * D * sizeof(T);
+    constexpr int PF = LC * MAT * (int)sizeof(T), PM = LC * D * (int)sizeof(T);        // a lane's bytes of a matrix / vector array
     const long limF = (N - wbase) * MAT * (long)sizeof(T), limM = (N - wbase) * D * (long)sizeof(T);
 
     T h[D], P0[SYM];
-    T Rn;
     if constexpr (FUSED) {
         gp_prior<T, D>(ra.m, h, P0);
     } else {
@@ -213,28 +404,41 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
 #pragma unroll
         for (int i = 0; i < D; ++i) h[i] = a.H[i];
     }
-    Rn = a.R;
+    const T Rn = a.R;
 
     // ---------------------------------------------------------------------------------------------
     // phase 1: the chunk comes on chip and is reduced
     // ---------------------------------------------------------------------------------------------
     T Freg[LC][MAT];            // F_k; from phase 2 on: E_k
-    T yreg[LC];                 // y_k (FUSED: first the time stamps); from phase 2 on g_k[0]
-    T greg[LC];                 // g_k[1..] (D = 2: one value)  -- D - 1 values per step, D <= 2
-    static_assert(D <= 2, "resident pass: d <= 2");
+    T yreg[LC];                 // y_k; from phase 2 on the last component of g_k (the others travel with L_k in the slot)
+    constexpr int GL = MAT - SYM;       // components of g that fit beside L in a step's 'matrix record' of the slot (d = 2: one, d = 1: none)
+    static_assert(D - GL == 1, "one component of g per step stays in registers");
     FE agg;
     filt_identity(agg);
+    auto reduce_step = [&](int j, const T* Qf) {
+        T Q[SYM];
+        sym_from_full<T, D>(Qf, Q);
+        if (j == 0) {
+            if (k0 == 0) filt_first(agg, P0, yreg[0], h, Rn);
+            else res_filt_extend(agg, Freg[0], Q, yreg[0], h, Rn);
+        } else {
+            res_filt_extend(agg, Freg[j], Q, yreg[j], h, Rn);
+        }
+    };
     {
         const T nanv = T(__builtin_nan(""));
         if constexpr (FUSED) {
-            // time stamps and observations straight from global memory (LC contiguous values per lane)
             T tv[LC];
             const T* tp = ra.m.ts;
             T tprev;
             if (full) {
-                load_rec<T, LC>(tp + k0, tv);
-                load_rec<T, LC>(a.ys + k0, yreg);
-                tprev = (k0 > 0) ? tp[k0 - 1] : ra.m.t_prev;
+                ResLaneValues<T, LC> lt, ly;
+                lt.issue(tp + wbase);
+                ly.issue(a.ys + wbase);
+                lt.finish(mst, tv);
+                ly.finish(mst, yreg);
+                tprev = wshfl_up(tv[LC - 1], 1);
+                if (lane == 0) tprev = (k0 > 0) ? tp[k0 - 1] : ra.m.t_prev;
             } else {
                 const T tl = tp[N - 1];
 #pragma unroll
@@ -250,61 +454,65 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
                 T Qf[MAT];
                 lti_step<T, D>(ra.m, tv[j] - tprev, Freg[j], Qf);
                 tprev = tv[j];
-                store_rec<T, MAT>(reinterpret_cast<T*>(myslot) + j * MAT, Qf);
-                if (k0 + j == 0) {
-                    filt_first(agg, P0, yreg[j], h, Rn);
-                } else {
-                    T Q[SYM];
-                    sym_from_full<T, D>(Qf, Q);
-                    filt_extend(agg, Freg[j], Q, yreg[j], h, Rn);
-                }
+                store_rec<T, MAT>(myrec + j * MAT, Qf);
+                reduce_step(j, Qf);
             }
         } else {
             const char* gF = reinterpret_cast<const char*>(a.Fs + wbase * MAT);
             const char* gQ = reinterpret_cast<const char*>(a.Qs + wbase * MAT);
-            V4 rF[GF::NV], rQ[GF::NV];
-            res_issue<T, D, GF>(gF, 0, pitchF, limF, full, 0, rF);
-            res_issue<T, D, GF>(gQ, 0, pitchF, limF, full, 1, rQ);
-            if (full) {
-                load_rec<T, LC>(a.ys + k0, yreg);
-            } else {
+            // two sub-tiles of F and of Q in flight per wave (128 KiB per CU): one did not keep the memory path busy
+            // (9.2 B/clk per CU in this phase against 11 - 13 in the three-launch kernels' loops)
+            // whole waves and ragged ones run two copies of the loop: inside one copy every wait counts exactly the loads
+            // it needs (a full / ragged choice per load made hipcc drain the whole prefetch at each join: s_waitcnt vmcnt(0))
+            auto stream = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                V4 rF[2][GF::NV], rQ[2][GF::NV];
+                ResLaneValues<T, LC> ly;
+                if constexpr (FULL) ly.issue(a.ys + wbase);
+                res_issue<T, D, GF, PF>(gF, 0, limF, FULL, 0, rF[0]);
+                res_issue<T, D, GF, PF>(gQ, 0, limF, FULL, 1, rQ[0]);
+                if (S > 1) {
+                    res_issue<T, D, GF, PF>(gF, 1, limF, FULL, 0, rF[1]);
+                    res_issue<T, D, GF, PF>(gQ, 1, limF, FULL, 1, rQ[1]);
+                }
+                if constexpr (FULL) {
+                    ly.finish(mst, yreg);
+                } else {
 #pragma unroll
-                for (int j = 0; j < LC; ++j) yreg[j] = (k0 + j < N) ? a.ys[k0 + j < N ? k0 + j : 0] : nanv;
-            }
+                    for (int j = 0; j < LC; ++j) yreg[j] = (k0 + j < N) ? a.ys[k0 + j < N ? k0 + j : 0] : nanv;
+                }
 #pragma unroll
-            for (int sb = 0; sb < S; ++sb) {
-                // F of the sub-tile through the slots into registers, then Q into the same place, where it stays
-                wave_lds_sync();
-                res_commit<GF, SLOT>(slots, sb, rF);
-                if (sb + 1 < S) res_issue<T, D, GF>(gF, sb + 1, pitchF, limF, full, 0, rF);
-                wave_lds_sync();
+                for (int sb = 0; sb < S; ++sb) {
+                    const int p = sb & 1;
+                    // F of the sub-tile through the slots into registers, then Q into the same place, where it stays
+                    res_wave_sync();
+                    res_commit<GF, SLOT>(slots, sb, rF[p]);
+                    if (sb + 2 < S) res_issue<T, D, GF, PF>(gF, sb + 2, limF, FULL, 0, rF[p]);
+                    res_wave_sync();
 #pragma unroll
-                for (int i = 0; i < G; ++i) load_rec<T, MAT>(reinterpret_cast<const T*>(myslot) + (sb * G + i) * MAT, Freg[sb * G + i]);
-                wave_lds_sync();
-                res_commit<GF, SLOT>(slots, sb, rQ);
-                if (sb + 1 < S) res_issue<T, D, GF>(gQ, sb + 1, pitchF, limF, full, 1, rQ);
-                wave_lds_sync();
+                    for (int i = 0; i < G; ++i) load_rec<T, MAT>(myrec + (sb * G + i) * MAT, Freg[sb * G + i]);
+                    res_wave_sync();
+                    res_commit<GF, SLOT>(slots, sb, rQ[p]);
+                    if (sb + 2 < S) res_issue<T, D, GF, PF>(gQ, sb + 2, limF, FULL, 1, rQ[p]);
+                    res_wave_sync();
 #pragma unroll
-                for (int i = 0; i < G; ++i) {
-                    const int j = sb * G + i;
-                    T Qf[MAT];
-                    load_rec<T, MAT>(reinterpret_cast<const T*>(myslot) + j * MAT, Qf);
-                    if (k0 + j == 0) {
-                        filt_first(agg, P0, yreg[j], h, Rn);
-                    } else {
-                        T Q[SYM];
-                        sym_from_full<T, D>(Qf, Q);
-                        filt_extend(agg, Freg[j], Q, yreg[j], h, Rn);
+                    for (int i = 0; i < G; ++i) {
+                        const int j = sb * G + i;
+                        T Qf[MAT];
+                        load_rec<T, MAT>(myrec + j * MAT, Qf);
+                        reduce_step(j, Qf);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-            }
+            };
+            if (full) stream(std::true_type{}); else stream(std::false_type{});
         }
     }
     PGPS_RSTAMP(1);
     FE excl;
     {
         FE total;
-        block_scan_exclusive<FE, true>(agg, excl, total, lds);
+        res_block_scan_exclusive<FE, true>(agg, excl, total, lds);
         PGPS_RSTAMP(2);
         if (threadIdx.x == 0) {
             T v[NF];
@@ -334,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
             for (int i = 0; i < NF; ++i) v[i] = pub_load(a.spine + (long)threadIdx.x * NF + i);
             unpack(v, mine);
         }
-        block_reduce_ordered(mine, left, lds);
+        res_block_reduce_ordered(mine, left, lds);
         filt_apply(s, left);
     }
     filt_apply(s, excl);
@@ -346,13 +554,13 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
     // F, Q of the step after the chunk: the next lane's first step (its registers / its slot); the wave's last lane
     // reads global memory (the next wave's or workgroup's first step), or pads
     T Fh[MAT], Qh[MAT];
+    T Qn[MAT];
+    load_rec<T, MAT>(myrec, Qn);
     {
-        T Q0f[MAT];
-        load_rec<T, MAT>(reinterpret_cast<const T*>(myslot), Q0f);
 #pragma unroll
         for (int i = 0; i < MAT; ++i) {
             Fh[i] = wshfl_down(Freg[0][i], 1);
-            Qh[i] = wshfl_down(Q0f[i], 1);
+            Qh[i] = wshfl_down(Qn[i], 1);
         }
         if (lane == kWave - 1) {
             const long k1 = k0 + LC;
@@ -369,54 +577,78 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
             }
         }
     }
+    // smoothing element of step k_next - 1 from the predict of step k_next (parallel.py:159-166).  k_next == N: the series'
+    // last element (0, m, P) (parallel.py:155-156) -- which is what the formulas give for F P = 0 (E = 0, g = m, L = P).
+    // Beyond N the padded steps (F = I, Q = 0) give the identity element up to rounding, to the RIGHT of an element whose
+    // E is exactly zero: they reach nothing.
+    auto element = [&](long k_next, const MC& prev, const T* mp, const T* Pp, T* FP, SE& e) {
+        const bool last = (k_next == N);
+#pragma unroll
+        for (int q = 0; q < MAT; ++q) FP[q] = last ? T(0) : FP[q];
+        smth_element(prev, mp, Pp, FP, e);
+    };
     const bool store_f = (a.fms != nullptr);
     char* gP = reinterpret_cast<char*>(a.fPs + wbase * MAT);
     char* gM = reinterpret_cast<char*>(a.fms + wbase * D);
-    T Lhold[SYM];
+    T Lhold[MAT];               // [L | leading components of g] of a step, until the step's slot record has been drained
 #pragma unroll
     for (int sb = 0; sb < S; ++sb) {
-        T Lnew[G][SYM];
+        T Lnew[G][MAT];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int j = sb * G + i;
-            const long k = k0 + j;
-            T Qf[MAT], Q[SYM];
-            load_rec<T, MAT>(reinterpret_cast<const T*>(myslot) + j * MAT, Qf);
-            sym_from_full<T, D>(Qf, Q);
+            T Q[SYM];
+            sym_from_full<T, D>(Qn, Q);
+#ifndef PGPS_RES_NOQPF
+            if (j + 1 < LC) load_rec<T, MAT>(myrec + (j + 1) * MAT, Qn);       // the next step's Q: requested a step ahead
+#endif
+#ifdef PGPS_RES_NOQPF
+            if (j + 1 < LC) load_rec<T, MAT>(myrec + (j + 1) * MAT, Qn);
+#endif
             MC prev = s;
             T mp[D], Pp[SYM], FP[MAT];
-            kf_step(s, Freg[j], Q, yreg[j], h, Rn, k == 0, ll, mp, Pp, FP);
-            if (j > 0) {
+            if (j == 0) {
+                if (k0 == 0) kf_step(s, Freg[0], Q, yreg[0], h, Rn, true, ll, mp, Pp, FP);
+                else res_kf_step(s, Freg[0], Q, yreg[0], h, Rn, ll, mp, Pp, FP);
+            } else {
+#ifndef PGPS_RES_BRANCHFREE
+                kf_step(s, Freg[j], Q, yreg[j], h, Rn, false, ll, mp, Pp, FP);
+#else
+                res_kf_step(s, Freg[j], Q, yreg[j], h, Rn, ll, mp, Pp, FP);
+#endif
                 // element of step j - 1: E, g take the registers F_{j-1}, y_{j-1} have left; L waits for its slot
                 SE e, r;
-                res_element<T, D>(k, N, tail, prev, mp, Pp, FP, e);
+                element(k0 + j, prev, mp, Pp, FP, e);
                 smth_combine(sagg, e, r);
                 sagg = r;
 #pragma unroll
                 for (int q = 0; q < MAT; ++q) Freg[j - 1][q] = e.E[q];
-                yreg[j - 1] = e.g[0];
-                if constexpr (D == 2) greg[j - 1] = e.g[1];
+                yreg[j - 1] = e.g[D - 1];
 #pragma unroll
-                for (int q = 0; q < SYM; ++q) {
-                    if (i == 0) Lhold[q] = e.L[q]; else Lnew[i - 1][q] = e.L[q];
+                for (int q = 0; q < MAT; ++q) {
+                    const T x = q < SYM ? e.L[q < SYM ? q : 0] : e.g[q < SYM ? 0 : q - SYM];
+                    if (i == 0) Lhold[q] = x; else Lnew[i - 1][q] = x;
                 }
             }
             // filtered moments of step j: P into the slot Q_j has left, m into the staging buffer
             T Pf[MAT];
             full_from_sym<T, D>(s.P, Pf);
-            store_rec<T, MAT>(reinterpret_cast<T*>(myslot) + j * MAT, Pf);
+            store_rec<T, MAT>(myrec + j * MAT, Pf);
             store_rec<T, D>(reinterpret_cast<T*>(mst + lane * GM::STRIDE) + i * D, s.m);
+#ifndef PGPS_RES_NOSB
+            __builtin_amdgcn_sched_barrier(0);          // steps stay apart: across them the scheduler only lengthens live ranges (scratch)
+#endif
         }
-        wave_lds_sync();
+        res_wave_sync();
         if (store_f) {
-            res_drain<GF, SLOT>(gP, sb, pitchF, limF, full, slots);
-            res_drain_m<GM>(gM, sb, pitchM, limM, full, mst);
+            res_drain<GF, SLOT, PF>(gP, sb, limF, full, slots);
+            res_drain_m<GM, PM>(gM, sb, limM, full, mst);
         }
-        wave_lds_sync();
+        res_wave_sync();
         // L of steps 4 sb - 1 .. 4 sb + 2 into their slots (drained above; LDS keeps a wave's accesses in order)
-        if (sb > 0) store_rec<T, SYM>(reinterpret_cast<T*>(myslot) + (sb * G - 1) * MAT, Lhold);
+        if (sb > 0) store_rec<T, MAT>(myrec + (sb * G - 1) * MAT, Lhold);
 #pragma unroll
-        for (int i = 0; i + 1 < G; ++i) store_rec<T, SYM>(reinterpret_cast<T*>(myslot) + (sb * G + i) * MAT, Lnew[i]);
+        for (int i = 0; i + 1 < G; ++i) store_rec<T, MAT>(myrec + (sb * G + i) * MAT, Lnew[i]);
     }
     {
         // element of the chunk's last step from the step after the chunk
@@ -426,14 +658,16 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
         mat_vec<T, D>(Fh, s.m, mp);
         predict_cov<T, D>(Fh, s.P, Q, FP, Pp);
         SE e, r;
-        res_element<T, D>(k0 + LC, N, tail, s, mp, Pp, FP, e);
+        element(k0 + LC, s, mp, Pp, FP, e);
         smth_combine(sagg, e, r);
         sagg = r;
 #pragma unroll
         for (int q = 0; q < MAT; ++q) Freg[j][q] = e.E[q];
-        yreg[j] = e.g[0];
-        if constexpr (D == 2) greg[j] = e.g[1];
-        store_rec<T, SYM>(reinterpret_cast<T*>(myslot) + j * MAT, e.L);
+        yreg[j] = e.g[D - 1];
+        T Lg[MAT];
+#pragma unroll
+        for (int q = 0; q < MAT; ++q) Lg[q] = q < SYM ? e.L[q < SYM ? q : 0] : e.g[q < SYM ? 0 : q - SYM];
+        store_rec<T, MAT>(myrec + j * MAT, Lg);
     }
     PGPS_RSTAMP(5);
     SE sexcl;
@@ -441,7 +675,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
         const double v = ll.value();
         const double t = block_sum_double(v, lds_ll);
         SE stotal;
-        block_scan_exclusive<SE, false>(sagg, sexcl, stotal, lds);
+        res_block_scan_exclusive<SE, false>(sagg, sexcl, stotal, lds);
         PGPS_RSTAMP(6);
         if (threadIdx.x == 0) {
             T vv[NS];
@@ -472,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
             for (int i = 0; i < NS; ++i) v[i] = pub_load(a.sspine + (long)b * NS + i);
             unpack(v, mine);
         }
-        block_reduce_ordered(mine, right, lds);
+        res_block_reduce_ordered(mine, right, lds);
         smth_apply(right, s);
     }
     smth_apply(sexcl, s);
@@ -485,6 +719,8 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
     }
     char* oP = reinterpret_cast<char*>(a.sPs + wbase * MAT);
     char* oM = reinterpret_cast<char*>(a.sms + wbase * D);
+    T Ln[MAT];
+    load_rec<T, MAT>(myrec + (LC - 1) * MAT, Ln);
 #pragma unroll
     for (int sb = S - 1; sb >= 0; --sb) {
 #pragma unroll
@@ -493,19 +729,22 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
             SE e;
 #pragma unroll
             for (int q = 0; q < MAT; ++q) e.E[q] = Freg[j][q];
-            e.g[0] = yreg[j];
-            if constexpr (D == 2) e.g[1] = greg[j];
-            load_rec<T, SYM>(reinterpret_cast<const T*>(myslot) + j * MAT, e.L);
+            e.g[D - 1] = yreg[j];
+#pragma unroll
+            for (int q = 0; q < SYM; ++q) e.L[q] = Ln[q];
+#pragma unroll
+            for (int q = SYM; q < MAT; ++q) e.g[q - SYM] = Ln[q];
+            if (j > 0) load_rec<T, MAT>(myrec + (j - 1) * MAT, Ln);            // the next step's L: requested a step ahead
             smth_apply(e, s);
             T Pf[MAT];
             full_from_sym<T, D>(s.P, Pf);
-            store_rec<T, MAT>(reinterpret_cast<T*>(myslot) + j * MAT, Pf);
+            store_rec<T, MAT>(myrec + j * MAT, Pf);
             store_rec<T, D>(reinterpret_cast<T*>(mst + lane * GM::STRIDE) + i * D, s.m);
         }
-        wave_lds_sync();
-        res_drain<GF, SLOT>(oP, sb, pitchF, limF, full, slots);
-        res_drain_m<GM>(oM, sb, pitchM, limM, full, mst);
-        wave_lds_sync();
+        res_wave_sync();
+        res_drain<GF, SLOT, PF>(oP, sb, limF, full, slots);
+        res_drain_m<GM, PM>(oM, sb, limM, full, mst);
+        res_wave_sync();
     }
     PGPS_RSTAMP(9);
 }
