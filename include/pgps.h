@@ -84,7 +84,9 @@ int pgps_resident_stamps(pgps_ctx* ctx, long long* out, int max_blocks, int* n_b
  * fp64 with 5 <= d <= 16 and fp32 with 7 <= d <= 16, segments use it above d = 6; quad-cooperative for whole fp32
  * series at d = 8 and, up to 3 * 2^17 and from 3 * 2^19 steps, at d = 6; wave-cooperative otherwise, d <= 32),
  * 1 = lane-chunk (d <= PGPS_MAX_DIM_LANE), 2 = wave-cooperative, 3 = row-cooperative (fp64 and fp32, 2 <= d <= 16),
- * 4 = quad-cooperative level-1 kernels under the row-cooperative driver (fp32 only, 5 <= d <= 8; pkf / pkfs / segments). */
+ * 4 = quad-cooperative level-1 kernels under the row-cooperative driver (fp32 only, 5 <= d <= 8; pkf / pkfs / segments:
+ * outside that range, for fp64 and for pks a forced family 4 returns PGPS_E_UNSUPPORTED_DIM -- until round 3 it fell
+ * back to the row-cooperative kernels there). */
 int pgps_set_family(pgps_ctx* ctx, int family);
 /* Lanes per workgroup of the lane-chunk kernels (d <= PGPS_MAX_DIM_LANE): 0 = automatic (128 -- half the scan tree per
  * step at the same number of workgroups -- except d <= 3 from 2^22 steps of this call / this rank's segment), 128, 256.
@@ -132,10 +134,11 @@ int pgps_get_chunk(pgps_ctx* ctx, long n_steps, int* steps_per_lane, int* n_work
 #define PGPS_FAMILY_QUAD 4          /* quad-cooperative level-1 kernels under the row-cooperative driver (fp32, 5 <= d <= 8) */
 #define PGPS_FAMILY_TWO_ROWS 5      /* two-rows level-1 kernels under the wave-cooperative driver (17 <= d <= 23 fp64, <= 31 fp32) */
 #define PGPS_FAMILY_LANE_NARROW 11  /* lane-chunk kernels, 128-lane workgroups */
+#define PGPS_FAMILY_RESIDENT 12     /* filter + smoother in one resident launch (pkfs, fp64, d = 2, up to 4096 steps per CU: pgps_set_resident) */
 int pgps_get_family(pgps_ctx* ctx, long n_steps, int d, int f32, int what, int* family);
 const char* pgps_last_hip_error(pgps_ctx* ctx);
-/* Diagnostic flags raised since the last call (synchronises; 0 = none; bit 1: a bounded look-back spin of the
- * single-pass filter gave up -- results of that pass are invalid; PGPS_STATUS_F32_PROMOTED: a float32 call ran in fp64
+/* Diagnostic flags raised since the last call (synchronises; 0 = none; bit 1: a bounded spin of the single-pass filter
+ * or of the resident launch's grid barrier gave up -- results of that pass are invalid; PGPS_STATUS_F32_PROMOTED: a float32 call ran in fp64
  * arithmetic, see pgps_set_f32_policy). */
 #define PGPS_STATUS_F32_PROMOTED 4
 int pgps_status(pgps_ctx* ctx, int* flags);
@@ -146,7 +149,12 @@ int pgps_status(pgps_ctx* ctx, int* flags);
  * ill-conditioned solve).  policy 0 (default): such calls probe a sample of the transition matrices on the device and,
  * where the grid is that dense, run in fp64 arithmetic on the float32 arrays (widened into scratch, results rounded
  * back; state dimensions above 16 always do) -- the arrays, the entry points and the tolerances stay the float32 ones;
- * 1: float32 arithmetic whatever the grid; 2: always fp64 arithmetic.  pgps_status tells which way the calls went. */
+ * 1: float32 arithmetic whatever the grid; 2: always fp64 arithmetic.  pgps_status tells which way the calls went.
+ * Under policy 0 a float32 smoother call is NOT asynchronous: the host waits for the probe's verdict (an event on a
+ * stream of the library's own, ordered behind everything already queued on the context's stream), so such a call must
+ * not be made while the caller's stream is being captured into a hipGraph -- use policy 1 or 2 there -- and the outputs
+ * of pgps_pks_* must not alias its inputs (a promoted call reads fms / fPs after the float32 pass may have written
+ * sms / sPs). */
 int pgps_set_f32_policy(pgps_ctx* ctx, int policy);
 
 /* ---- device memory helpers (for hosts without a device-array library) ----------------- */
@@ -162,7 +170,8 @@ int pgps_memcpy_d2h(pgps_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 #define PGPS_K_SMOOTHER_APPLY 3
 #define PGPS_K_LL_FINALIZE 4
 #define PGPS_K_DISCRETISE 5
-#define PGPS_K_COUNT 6
+#define PGPS_K_RESIDENT 6           /* the one-launch filter + smoother pass (pgps_set_resident) */
+#define PGPS_K_COUNT 7
 /* mask: bit i set = record a hipEvent pair around every launch of slot i; 0 = off. */
 int pgps_profile_enable(pgps_ctx* ctx, int mask);
 /* Time only every n-th launch of an enabled slot (default 1): keeps the events' own cost

@@ -264,7 +264,7 @@ extern "C" int pgps_memcpy_d2h(pgps_ctx* ctx, void* dst, const void* src, size_t
 // profiling
 // ---------------------------------------------------------------------------------------------
 static const char* kKernelNames[PGPS_K_COUNT] = {"k_filter_reduce", "k_filter_apply", "k_smoother_reduce",
-                                                 "k_smoother_apply", "k_ll_finalize", "k_discretise"};
+                                                 "k_smoother_apply", "k_ll_finalize", "k_discretise", "k_pkfs_resident"};
 extern "C" const char* pgps_kernel_name(int slot) {
     return (slot >= 0 && slot < PGPS_K_COUNT) ? kKernelNames[slot] : "";
 }
@@ -517,6 +517,8 @@ static int choose_family(const pgps_ctx* ctx, int d, long N, Mode mode) {
         }
     }
     if constexpr (sizeof(T) == 8) {
+        // filter + smoother of a whole series that fits the chip: one resident launch (pgps_resident.hip.h)
+        if (mode == MODE_PKFS && resident_fits(ctx, N, d, false)) return PGPS_FAMILY_RESIDENT;
         // row-cooperative family: fp64, d <= 16, whole-series filter / filter+smoother
         const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
         // automatic choice from d = 5: at d = 6 the lane-chunk kernels spill (2^18 steps: 1.29 ms against 0.53 ms);
@@ -537,10 +539,22 @@ static int choose_family(const pgps_ctx* ctx, int d, long N, Mode mode) {
     return lane_narrow(ctx, d, N) ? PGPS_FAMILY_LANE_NARROW : PGPS_FAMILY_LANE;
 }
 
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 template <typename T>
 static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) {
-    const int fam = choose_family<T>(ctx, d, a.N, mode);
+    int fam = choose_family<T>(ctx, d, a.N, mode);
     if (fam < 0) return fam;
+    if constexpr (sizeof(T) == 8) {
+        if (fam == PGPS_FAMILY_RESIDENT) {
+            if (aligned16(a.ys)) {
+                ResArgs<double> ra{};
+                ra.s = a;
+                return launch_resident<double, 2>(ctx, ra, false);
+            }
+            fam = lane_narrow(ctx, d, a.N) ? PGPS_FAMILY_LANE_NARROW : PGPS_FAMILY_LANE;      // (a misaligned ys: three launches)
+        }
+    }
     if (fam == PGPS_FAMILY_ROW || fam == PGPS_FAMILY_QUAD) return launch_scan_rc<T>(ctx, a, d, mode);
     if (fam == PGPS_FAMILY_WAVE || fam == PGPS_FAMILY_TWO_ROWS) return launch_scan_wc<T>(ctx, a, d, mode);
     if (fam == PGPS_FAMILY_LANE_NARROW) {
@@ -575,7 +589,6 @@ extern "C" int pgps_get_family(pgps_ctx* ctx, long N, int d, int f32, int what, 
     return PGPS_OK;
 }
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---------------------------------------------------------------------------------------------
 // float32 series on DENSE grids: fp64 arithmetic behind float32 arrays, chosen per call.
@@ -790,14 +803,7 @@ static int pkfs_dev(pgps_ctx* ctx, long N, int d, const T* P0, const T* Fs, cons
     a.P0 = P0; a.H = H; a.R = R; a.Fs = Fs; a.Qs = Qs; a.ys = ys;
     a.fms = fms; a.fPs = fPs; a.sms = sms; a.sPs = sPs; a.ll = ll;
     if constexpr (sizeof(T) == 4) return f32_smoother_call(ctx, d, a, MODE_PKFS);
-    else {
-        if (resident_fits(ctx, N, d, false) && aligned16(ys)) {
-            ResArgs<double> ra{};
-            ra.s = a;
-            return launch_resident<double, 2>(ctx, ra, false);
-        }
-        return dispatch_scan<T>(ctx, d, a, MODE_PKFS);
-    }
+    else return dispatch_scan<T>(ctx, d, a, MODE_PKFS);
 }
 
 template <typename T>

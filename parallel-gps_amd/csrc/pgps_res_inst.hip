@@ -43,8 +43,8 @@ int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused) {
         ctx->res_stamp_blocks = a.nblocks;
     }
     const dim3 grid(a.nblocks), block(kBlock);
-    if (fused) timed_launch(ctx, PGPS_K_FILTER_APPLY, k_pkfs_resident<T, D, kResLc, true>, grid, block, 0, ra);
-    else timed_launch(ctx, PGPS_K_FILTER_APPLY, k_pkfs_resident<T, D, kResLc, false>, grid, block, 0, ra);
+    if (fused) timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, kResLc, true>, grid, block, 0, ra);
+    else timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, kResLc, false>, grid, block, 0, ra);
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

@@ -279,6 +279,7 @@ __device__ __forceinline__ void res_scan4(E& x, int lane) {
         step(dpp_elem<kDppRowShl + 2, 0xf>(x), r + 2 < 16);
     }
 }
+// `total` is valid in lane kWaves - 1 (FORWARD) / lane 0 (backward) of every wave only
 template <typename E, bool FORWARD>
 __device__ __forceinline__ void res_block_scan_exclusive(const E& mine, E& excl, E& total, typename ElemTraits<E>::Scalar* lds) {
     using TR = ElemTraits<E>;
@@ -295,13 +296,24 @@ __device__ __forceinline__ void res_block_scan_exclusive(const E& mine, E& excl,
     TR::identity(t);
     if (lane < kWaves) rec_load(lds + lane * TR::N, t);
     res_scan4<E, FORWARD>(t, lane);
-    if (FORWARD) {
-        total = res_readlane_elem(t, kWaves - 1);
-        if (wave > 0) { const E p = res_readlane_elem(t, wave - 1); TR::combine(p, wex, excl); } else excl = wex;
-    } else {
-        total = res_readlane_elem(t, 0);
-        if (wave < kWaves - 1) { const E p = res_readlane_elem(t, wave + 1); TR::combine(wex, p, excl); } else excl = wex;
+    // the workgroup's total stays where the scan left it: lane 3 (FORWARD) / lane 0 of every wave -- the one lane that
+    // publishes it reads it there (kResTotalLane); broadcasting it costs 28 v_readlane and as many registers for nothing
+    total = t;
+    // (no branch on the wave's position: the first / last wave combines with the identity, which is exact)
+    typename TR::Scalar pv[TR::N], iv[TR::N];
+    {
+        E id;
+        TR::identity(id);
+        pack(id, iv);
+        pack(t, pv);
     }
+    const bool edge = FORWARD ? (wave == 0) : (wave == kWaves - 1);
+    const int src = FORWARD ? (edge ? 0 : wave - 1) : (edge ? 0 : wave + 1);
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) { const typename TR::Scalar x = res_readlane(pv[i], src); pv[i] = edge ? iv[i] : x; }
+    E p;
+    unpack(pv, p);
+    if (FORWARD) TR::combine(p, wex, excl); else TR::combine(wex, p, excl);
     __syncthreads();
 }
 // ordered reduction of one element per lane over the workgroup (lane order = time order), result in every lane
@@ -514,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
         FE total;
         res_block_scan_exclusive<FE, true>(agg, excl, total, lds);
         PGPS_RSTAMP(2);
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == kWaves - 1) {            // the lane the forward scan leaves the workgroup's total in
             T v[NF];
             pack(total, v);
 #pragma unroll
@@ -538,8 +550,9 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
         filt_identity(mine);
         if ((int)threadIdx.x < tile) {
             T v[NF];
+            const T* rec = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.spine) + threadIdx.x * (unsigned)(NF * sizeof(T)));
 #pragma unroll
-            for (int i = 0; i < NF; ++i) v[i] = pub_load(a.spine + (long)threadIdx.x * NF + i);
+            for (int i = 0; i < NF; ++i) v[i] = pub_load(rec + i);
             unpack(v, mine);
         }
         res_block_reduce_ordered(mine, left, lds);
@@ -677,7 +690,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
         SE stotal;
         res_block_scan_exclusive<SE, false>(sagg, sexcl, stotal, lds);
         PGPS_RSTAMP(6);
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0) {                     // (the backward scan leaves its total in lane 0)
             T vv[NS];
             pack(stotal, vv);
 #pragma unroll
@@ -702,8 +715,10 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
         const int b = tile + 1 + (int)threadIdx.x;
         if (b < a.nblocks) {
             T v[NS];
+            const T* rec = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.sspine + (long)(tile + 1) * NS) +
+                                                      threadIdx.x * (unsigned)(NS * sizeof(T)));
 #pragma unroll
-            for (int i = 0; i < NS; ++i) v[i] = pub_load(a.sspine + (long)b * NS + i);
+            for (int i = 0; i < NS; ++i) v[i] = pub_load(rec + i);
             unpack(v, mine);
         }
         res_block_reduce_ordered(mine, right, lds);

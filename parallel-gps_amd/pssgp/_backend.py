@@ -259,7 +259,7 @@ class Context:
     def synchronize(self):
         check(self, self.lib.pgps_synchronize(self.handle), "pgps_synchronize")
 
-    def profile_enable(self, mask=0x3f):
+    def profile_enable(self, mask=0x7f):
         """mask: bit i = time every launch of kernel slot i (PGPS_K_*); 0 = off."""
         check(self, self.lib.pgps_profile_enable(self.handle, int(mask)), "pgps_profile_enable")
 
@@ -273,9 +273,11 @@ class Context:
         return v.value
 
     def profile_read(self, reset=True):
-        k = 6
-        ms = (c_double * k)()
-        cnt = (c_long * k)()
+        k = 0                                   # slots of THIS library (PGPS_K_COUNT: 6 until round 4, 7 with the resident launch)
+        while k < 16 and self.lib.pgps_kernel_name(k):
+            k += 1
+        ms = (c_double * 16)()
+        cnt = (c_long * 16)()
         check(self, self.lib.pgps_profile_read(self.handle, ms, cnt, int(bool(reset))), "pgps_profile_read")
         return {self.lib.pgps_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(k)}
 

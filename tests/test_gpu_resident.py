@@ -1,0 +1,264 @@
+"""The resident one-launch filter + smoother (csrc/pgps_resident.hip.h: fp64, d = 2, up to 4096 steps per CU) through the
+C ABI against the CPU oracle and against the three-launch path: array form (pgps_pkfs_*: the reference's pkf + pks
+contract, pssgp/kalman/parallel.py:121-201) and fused form (pgps_gp_*: the StateSpaceGP road, pssgp/model.py:92-117).
+
+Tolerance: the north star's 1e-5 relative in fp64; asserted at 1e-9 (observed ~1e-15: same algebra, other bracketing)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from oracle import c_oracle as C
+from tests.conftest import make_times, relerr, sample_series, sample_series_fast
+
+pytestmark = pytest.mark.gpu
+TOL64 = 1e-9
+PGPS_FAMILY_RESIDENT = 12
+
+
+def _B():
+    from pssgp import _backend
+    return _backend
+
+
+@pytest.fixture()
+def ctx():
+    c = _B().get_context()
+    c.set_resident(1)
+    yield c
+    c.set_resident(-1)
+    assert c.status() == 0
+
+
+def _m32(ls=1.0, var=1.0):
+    from pssgp.kernels import Matern32
+    return Matern32(variance=var, lengthscales=ls)
+
+
+def _oracle_all(ssm, y):
+    fms, fPs, ll = O.kf(ssm, y, True)
+    sms, sPs = O.kfs(ssm, y)
+    return dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([ll]))
+
+
+def _array_all(ssm, y):
+    sms, sPs, fms, fPs, ll = _B().pkfs(tuple(np.asarray(a, np.float64) for a in ssm), np.asarray(y, np.float64),
+                                       return_filtered=True, return_loglikelihood=True)
+    return dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([float(ll)]))
+
+
+def _fused_all(sde, t, y, r):
+    B = _B()
+    out = B.gp(B.nilpotent_form(sde.F), sde.P0, np.asarray(sde.H).reshape(-1), r, t, y, want_filtered=True, want_smoothed=True)
+    return dict(fms=out["fms"], fPs=out["fPs"], sms=out["sms"], sPs=out["sPs"], ll=np.array([float(out["ll"])]))
+
+
+def _check(got, want, tol=TOL64):
+    for name in want:
+        e = relerr(got[name], want[name])
+        assert e < tol, f"{name}: rel err {e:.3e} >= {tol}"
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 3 * 4096 + 17, 20000])
+def test_resident_array_and_fused_match_oracle_at_ragged_lengths(ctx, n):
+    """Lengths around the lane (16 steps), wave (1024) and workgroup (4096) boundaries: padding steps, the series' last
+    element inside a chunk / at a chunk's end / at a wave's end, one workgroup and several; 20 % missing observations."""
+    sde = _m32(0.7).get_sde()
+    t = make_times(n, seed=n)
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series(ssm, seed=n, nan_frac=0.2 if n > 4 else 0.0)
+    assert ctx.get_family(n, 2) == PGPS_FAMILY_RESIDENT
+    want = _oracle_all(ssm, y)
+    _check(_array_all(ssm, y), want)
+    _check(_fused_all(sde, t, y, 0.1), want)
+
+
+def test_resident_matches_the_parallel_oracle_and_the_dense_gp(ctx):
+    """The reference's own equivalence pin (tests/test_gp_vs_kfs.py:45-99): log-likelihood against the dense GP, and the
+    parallel restatement (oracle O3: elements + operators, tree bracketing) on every output."""
+    n = 700
+    sde = _m32(0.5).get_sde()
+    rng = np.random.default_rng(3)
+    t = np.sort(rng.uniform(0, 1, n)) * 6.0
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series(ssm, seed=4)
+    got = _array_all(ssm, y)
+    fms, fPs, ll = O.pkf(ssm, y, True)
+    sms, sPs = O.pks(ssm, fms, fPs)
+    _check(got, dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([ll])))
+    ll_dense = O.dense_gp(("matern32", 1.0, 0.5), t, y, 0.1)
+    assert abs(got["ll"][0] - ll_dense) < 1e-8 * abs(ll_dense)
+
+
+@pytest.mark.parametrize("pattern", ["all", "first", "last", "every-other", "block"])
+def test_resident_missing_observations(ctx, pattern):
+    """NaN observation = pure predict, no log-likelihood term (parallel.py:46-53, 147-149) -- including the first and the
+    last step of the series and a whole chunk of a lane."""
+    n = 5000
+    sde = _m32().get_sde()
+    t = make_times(n, seed=2)
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series(ssm, seed=2)
+    if pattern == "all":
+        y[:] = np.nan
+    elif pattern == "first":
+        y[:40] = np.nan
+    elif pattern == "last":
+        y[-40:] = np.nan
+    elif pattern == "every-other":
+        y[::2] = np.nan
+    else:
+        y[1000:3000] = np.nan
+    want = _oracle_all(ssm, y)
+    got = _array_all(ssm, y)
+    if pattern == "all":
+        assert got["ll"][0] == 0.0
+        want.pop("ll"), got.pop("ll")
+    _check(got, want)
+    gotf = _fused_all(sde, t, y, 0.1)
+    if pattern == "all":
+        gotf.pop("ll")
+    _check(gotf, want)
+
+
+def test_resident_equals_three_launch_path_and_is_deterministic(ctx):
+    """Same algebra, other bracketing: round-off apart (1e-12); and bit-identical from run to run (fixed geometry, fixed
+    combine order, barriers instead of arrival-ordered hand-offs)."""
+    n = (1 << 18) + 333
+    sde = _m32().get_sde()
+    t = make_times(n, seed=5)
+    ssm = O.get_ssm(sde, t, 0.1)
+    y = sample_series_fast(ssm, seed=5, nan_frac=0.1)
+    a = _array_all(ssm, y)
+    b = _array_all(ssm, y)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    ctx.set_resident(0)
+    assert ctx.get_family(n, 2) != PGPS_FAMILY_RESIDENT
+    c = _array_all(ssm, y)
+    ctx.set_resident(1)
+    _check(a, c, 1e-12)
+
+
+def test_resident_full_size_against_c_oracle(ctx):
+    """Config c2 itself: 2^20 steps = 256 workgroups, every CU of the chip, against the C restatement of sequential.py."""
+    n = 1 << 20
+    sde = _m32().get_sde()
+    t = make_times(n, seed=11)
+    ssm = tuple(np.asarray(a, np.float64) for a in O.get_ssm(sde, t, 0.1))
+    y = sample_series_fast(ssm, seed=11, nan_frac=0.05)
+    assert ctx.get_family(n, 2) == PGPS_FAMILY_RESIDENT
+    got = _array_all(ssm, y)
+    fms, fPs, sms, sPs, ll = C.kfs(ssm, y)
+    _check(got, dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([ll])))
+    gotf = _fused_all(sde, t, y, 0.1)
+    _check(gotf, dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([ll])))
+
+
+def test_resident_automatic_choice_and_its_limits(ctx):
+    """Automatic from 2^18 steps, never beyond 4096 steps per CU, never for other dimensions / float32 / pinned geometries /
+    filter-only or smoother-only calls; a misaligned observation array takes the three launches and still answers."""
+    B = _B()
+    ctx.set_resident(-1)
+    assert ctx.get_family((1 << 18) - 1, 2) != PGPS_FAMILY_RESIDENT
+    assert ctx.get_family(1 << 18, 2) == PGPS_FAMILY_RESIDENT
+    assert ctx.get_family(1 << 20, 2) == PGPS_FAMILY_RESIDENT
+    assert ctx.get_family((1 << 20) + 1, 2) != PGPS_FAMILY_RESIDENT           # 257 workgroups do not fit 256 CUs
+    assert ctx.get_family(1 << 19, 3) != PGPS_FAMILY_RESIDENT
+    assert ctx.get_family(1 << 19, 2, f32=True) != PGPS_FAMILY_RESIDENT
+    assert ctx.get_family(1 << 19, 2, what=0) != PGPS_FAMILY_RESIDENT         # pkf
+    assert ctx.get_family(1 << 19, 2, what=1) != PGPS_FAMILY_RESIDENT         # pks
+    ctx.set_chunk(8)
+    try:
+        assert ctx.get_family(1 << 19, 2) != PGPS_FAMILY_RESIDENT
+    finally:
+        ctx.set_chunk(0)
+    ctx.set_resident(1)
+    # misaligned ys (8 bytes off a 16-byte boundary) on device pointers
+    n = 6000
+    sde = _m32().get_sde()
+    t = make_times(n, seed=8)
+    ssm = tuple(np.asarray(a, np.float64) for a in O.get_ssm(sde, t, 0.1))
+    y = sample_series(ssm, seed=8, nan_frac=0.1)
+    P0, Fs, Qs, H, R = ssm
+    bufs = {}
+    for name, arr in (("P0", P0), ("Fs", Fs), ("Qs", Qs), ("H", np.asarray(H, np.float64).reshape(-1)), ("ys", np.concatenate([[0.0], y]))):
+        arr = np.ascontiguousarray(arr, np.float64)
+        bufs[name] = ctx.malloc(arr.nbytes)
+        ctx.h2d(bufs[name], arr)
+    outs = {k: ctx.malloc(n * m * 8) for k, m in (("fms", 2), ("fPs", 4), ("sms", 2), ("sPs", 4))}
+    ll = ctx.malloc(8)
+    try:
+        ctx.call("pgps_pkfs_dev_f64", ctypes.c_long(n), ctypes.c_int(2), bufs["P0"], bufs["Fs"], bufs["Qs"], bufs["H"],
+                 ctypes.c_double(float(R)), ctypes.c_void_p(bufs["ys"] + 8), outs["fms"], outs["fPs"], outs["sms"], outs["sPs"], ll)
+        sms = np.empty((n, 2))
+        ctx.d2h(sms, outs["sms"])
+        sm_o, _ = O.kfs(ssm, y)
+        assert relerr(sms, sm_o) < TOL64
+    finally:
+        for p in list(bufs.values()) + list(outs.values()) + [ll]:
+            ctx.free(p)
+    assert B is not None
+
+
+def test_resident_hand_offs_under_back_to_back_launches(ctx):
+    """Forty launches back to back on device-resident arrays whose inputs change every launch (consumers' caches warm with the
+    previous launch's totals): every launch must reproduce the three-launch path's log-likelihood and smoothed means -- a
+    stale total in either grid-wide hand-off would show as an O(1) error in the workgroups behind it."""
+    n = 1 << 19
+    sde = _m32().get_sde()
+    t = make_times(n, seed=21)
+    ssm = tuple(np.asarray(a, np.float64) for a in O.get_ssm(sde, t, 0.1))
+    P0, Fs, Qs, H, R = ssm
+    dev = {}
+    for name, arr in (("P0", P0), ("Fs", Fs), ("Qs", Qs), ("H", np.asarray(H, np.float64).reshape(-1))):
+        arr = np.ascontiguousarray(arr, np.float64)
+        dev[name] = ctx.malloc(arr.nbytes)
+        ctx.h2d(dev[name], arr)
+    dev["ys"] = ctx.malloc(n * 8)
+    outs = {k: ctx.malloc(n * m * 8) for k, m in (("fms", 2), ("fPs", 4), ("sms", 2), ("sPs", 4))}
+    ll_d = ctx.malloc(8)
+    rng = np.random.default_rng(0)
+    base = sample_series_fast(ssm, seed=21)
+
+    def run():
+        ctx.call("pgps_pkfs_dev_f64", ctypes.c_long(n), ctypes.c_int(2), dev["P0"], dev["Fs"], dev["Qs"], dev["H"],
+                 ctypes.c_double(float(R)), dev["ys"], outs["fms"], outs["fPs"], outs["sms"], outs["sPs"], ll_d)
+        sms = np.empty((n, 2))
+        llv = np.empty(1)
+        ctx.d2h(sms, outs["sms"])
+        ctx.d2h(llv, ll_d)
+        return sms, llv[0]
+
+    try:
+        for it in range(40):
+            y = base * (1.0 + 0.5 * it) + rng.standard_normal(n) * 0.01
+            ctx.h2d(dev["ys"], np.ascontiguousarray(y))
+            ctx.set_resident(1)
+            sm_r, ll_r = run()
+            if it % 8 == 0:
+                ctx.set_resident(0)
+                sm_3, ll_3 = run()
+                ctx.set_resident(1)
+                assert relerr(sm_r, sm_3) < 1e-11 and abs(ll_r - ll_3) < 1e-11 * abs(ll_3), it
+            else:
+                assert np.isfinite(ll_r) and np.all(np.isfinite(sm_r[::4097]))
+    finally:
+        for p in list(dev.values()) + list(outs.values()) + [ll_d]:
+            ctx.free(p)
+
+
+def test_statespacegp_predict_takes_the_resident_pass_unchanged(ctx):
+    """The model-level API on top (pssgp/model.py:92-117): same posterior whichever road the filter + smoother take."""
+    from pssgp.model import StateSpaceGP
+    rng = np.random.default_rng(5)
+    n, k = 3000, 200
+    t = np.cumsum(0.05 * rng.uniform(0.5, 1.5, n))
+    y = np.sin(t) + 0.3 * rng.standard_normal(n)
+    tq = np.sort(rng.uniform(t[0], t[-1], k))
+    kern = _m32()
+    model = StateSpaceGP((t[:, None], y[:, None]), kern, noise_variance=0.1, parallel=True)
+    mean, var = model.predict_f(tq[:, None])
+    mean_o, var_o = O.ssgp_predict_f(kern.get_sde(), t, y, 0.1, tq, parallel=False)
+    assert np.max(np.abs(mean[:, 0] - mean_o)) < 1e-8 and np.max(np.abs(var[:, 0] - var_o)) < 1e-8
