@@ -605,8 +605,13 @@ def main():
     dominant = max(per_pass, key=per_pass.get) if per_pass else "k_smoother_apply"
     empty_pair_ms = ctx.profile_calibrate()
     ctx.profile_read(reset=True)
-    # a short timed region (the driver's --steps 20) samples EVERY launch of the dominant kernel
-    ctx.profile_sample(1 if args.steps <= 32 else max(1, args.event_every))
+    # A timed launch goes out through hipExtLaunchKernelGGL with a start / stop event pair, which costs the stream ~5 us
+    # (measured in round 5: a 20-pass region with every launch stamped 61.7 us per pass, GPU-event time, against 56.8 us in a
+    # 200-pass region stamping every 8th -- the whole "driver protocol is 8 % slower" gap of rounds 2-4; a 55 ms re-warm
+    # changed nothing).  A short region therefore stamps every 5th launch (4 of the driver's 20), a long one every
+    # --event-every-th: <= 2 % of the region either way.
+    sample_every = max(1, args.event_every) if args.steps > 32 else max(1, min(5, args.steps // 4 if args.steps >= 8 else 1))
+    ctx.profile_sample(sample_every)
     dom_slot = SLOT_INDEX[dominant]
     # let the host's CPU-quota window refill after the data generation (a throttled host thread shows up as tens of
     # milliseconds of wall time with an idle GPU) -- and then bring the GPU back to its clocks under load: after half a
@@ -736,7 +741,7 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src, "traffic_stale": traffic_stale, "slots": slots,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_avg_s * 1e3,
-                     "launches_timed": dom_n, "empty_event_pair_ms": empty_pair_ms,
+                     "launches_timed": dom_n, "launch_sampled_every": sample_every, "empty_event_pair_ms": empty_pair_ms,
                      "dominant_by": {k: round(v, 6) for k, v in per_pass.items()},
                      # the whole pass against its algorithmic bytes B_alg = (7d^2+3d+1)w per step, per GPU,
                      # from the GPU-event time of the timed region

@@ -18,7 +18,7 @@ import glob
 import json
 import sys
 
-SLOT_OF = [("k_filter_reduce", "k_filter_reduce"), ("k_filter_apply", "k_filter_apply"), ("k_filter_single", "k_filter_apply"),
+SLOT_OF = [("k_pkfs_resident", "k_pkfs_resident"), ("k_filter_reduce", "k_filter_reduce"), ("k_filter_apply", "k_filter_apply"), ("k_filter_single", "k_filter_apply"),
            ("k_smoother_apply", "k_smoother_apply"), ("k_smoother_reduce", "k_smoother_reduce"),
            ("rc_reduce1", "k_filter_reduce"), ("rc_ks_filter", "k_filter_reduce"), ("rc_apply1", "k_filter_apply"),
            ("rc_ks_smoother", "k_smoother_reduce"), ("rc_selem1", "k_smoother_reduce"), ("rc_smooth1", "k_smoother_apply"),
@@ -30,6 +30,8 @@ def main():
     root, key = sys.argv[1], sys.argv[2]
     out_path = sys.argv[3] if len(sys.argv) > 3 else None
     factor = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
+    # optional slot renames "from=to,..." (the fused road's resident launch is filed as the bench line's fused_path leg)
+    rename = dict(kv.split("=") for kv in sys.argv[5].split(",")) if len(sys.argv) > 5 else {}
     per = collections.defaultdict(lambda: collections.defaultdict(list))    # kernel -> counter -> values per dispatch
     for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -38,6 +40,7 @@ def main():
     passes = None
     for kname, ctr in per.items():
         slot = next((s for pat, s in SLOT_OF if pat in kname), None)
+        slot = rename.get(slot, slot)
         if slot is None or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
             continue
         short = kname.split("(")[0].replace("void pgps::", "")
@@ -46,7 +49,7 @@ def main():
                                        "WRITE_SIZE_KiB_mean": sum(ctr["WRITE_SIZE"]) / len(ctr["WRITE_SIZE"])})
         # single-launch kernels fix the number of passes that were profiled
         # (the most frequent one: warm-up / fused-path variants of the same kernel run fewer times)
-        if any(p in kname for p in ("rc_apply1", "k_filter_apply", "k_filter_single")):
+        if any(p in kname for p in ("rc_apply1", "k_filter_apply", "k_filter_single", "k_pkfs_resident")):
             passes = max(passes or 0, n)
         slots[slot]["FETCH_SIZE_KiB"] += sum(ctr["FETCH_SIZE"])
         slots[slot]["WRITE_SIZE_KiB"] += sum(ctr["WRITE_SIZE"])
@@ -75,6 +78,10 @@ def main():
         entry["_kernel_source_sha"] = kernel_source_sha()
     except Exception:                   # noqa: BLE001
         pass
+    if rename and key in doc:           # a renamed slot is ADDED to the workload's entry (measured in a run of its own)
+        merged = dict(doc[key])
+        merged.update({k: v for k, v in entry.items() if k in rename.values()})
+        entry = merged
     doc[key] = entry
     text = json.dumps(doc, indent=1)
     if out_path:
