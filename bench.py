@@ -258,6 +258,30 @@ SLOT_INDEX = {"k_filter_reduce": 0, "k_filter_apply": 1, "k_smoother_reduce": 2,
 SLOT_MASK = sum(1 << i for i in SLOT_INDEX.values())
 
 
+def slot_bytes(slot, d, w, fam):
+    """Bytes of the contract per time step that the kernels of a launch slot touch themselves, for the family the call
+    runs on -- or None where a slot holds no per-step traffic at all.  The cooperative families (row / quad: 3, 4; wave /
+    two-rows: 2, 5) keep only the scans of their chain totals in the smoother's reduce slot: a few records per chain, not
+    bytes per step -- priced with the lane-chunk model that slot read frac 6.27 in round 4."""
+    if fam in (2, 3, 4, 5) and slot == "k_smoother_reduce":
+        return None
+    return SLOT_BYTES[slot](d, w)
+
+
+def slot_moved_bytes(slot, d, w, fam):
+    """What the slot's kernels really move per step where that differs from the contract: the cooperative families hand the
+    smoothing elements (E, g, packed L) from the Kalman pass to the backward pass instead of re-reading Fs, Qs, fms, fPs."""
+    if fam in (3, 4):
+        elem = d * d + d + d * (d + 1) // 2
+        if slot == "k_filter_apply":
+            return (3 * d * d + d + 1 + elem) * w
+        if slot == "k_smoother_apply":
+            return (elem + d * d + d) * w
+    if slot == "k_pkfs_resident":
+        return (5 * d * d + 2 * d + 1) * w
+    return slot_bytes(slot, d, w, fam)
+
+
 def vector_fp(d, suf, n_local, ms_per_pass, alg_bytes_step):
     flops_step = 64 * d ** 3 + 40 * d ** 2
     peak = VECTOR_PEAK_TFLOPS[suf]
@@ -601,7 +625,9 @@ def main():
         step()
     probe = ctx.profile_read(reset=True)
     ctx.profile_enable(0)
-    per_pass = {k: v[0] / n_probe for k, v in probe.items() if v[1] and k in SLOT_BYTES}
+    # (only slots whose kernels touch bytes of the contract can be priced against it: the cooperative families' scan slots cannot)
+    fam_probe = ctx.get_family(n_local, d, f32=(suf == "f32"), what=3 if (world > 1 or args.force_segments) else 2)
+    per_pass = {k: v[0] / n_probe for k, v in probe.items() if v[1] and k in SLOT_BYTES and slot_bytes(k, d, w, fam_probe) is not None}
     dominant = max(per_pass, key=per_pass.get) if per_pass else "k_smoother_apply"
     empty_pair_ms = ctx.profile_calibrate()
     ctx.profile_read(reset=True)
@@ -688,7 +714,7 @@ def main():
     # the two slots that can dominate there, k_filter_apply and k_smoother_apply, are one launch per pass
     dom_raw_ms = dom_ms / max(dom_n, 1)
     dom_avg_s = max(dom_raw_ms, 1e-9) * 1e-3
-    dom_bytes = SLOT_BYTES[dominant](d, w) * n_local
+    dom_bytes = (slot_bytes(dominant, d, w, fam) or 0) * n_local
     achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     alg_bytes_step = (7 * d * d + 3 * d + 1) * w
     # HBM-side bytes per launch of the dominant kernel from the committed PMC profile of this workload
@@ -701,15 +727,18 @@ def main():
     # every launch slot of the pass against the bytes of the contract it touches itself (two slots within a few per cent of
     # each other swap the `dominant` role from box to box: read them side by side)
     slots = {}
-    for sname, fn in SLOT_BYTES.items():
+    for sname in SLOT_BYTES:
         ms_tot, n_l = breakdown.get(sname, (0.0, 0))
         if not n_l:
             continue
         ms_pass = ms_tot / n_break
-        ab = fn(d, w) * n_local
+        bs = slot_bytes(sname, d, w, fam)
+        ab = bs * n_local if bs is not None else None      # None: the slot's kernels touch no per-step bytes (scans of chain totals)
+        mb = slot_moved_bytes(sname, d, w, fam)
         tb = committed_traffic(tkey, sname) if default_cfg else (None, None, None)
         slots[sname] = {"ms_per_pass": ms_pass, "launches_per_pass": n_l / n_break, "alg_bytes": ab,
-                        "frac": ab / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_pass > 0 else 0.0,
+                        "moved_bytes_model": mb * n_local if mb is not None else None,
+                        "frac": (ab / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_pass > 0 else 0.0) if ab is not None else None,
                         "traffic": tb[0], "traffic_stale": tb[2]}
     whole_gbps = alg_bytes_step * n_total * args.steps / (gpu_ms * 1e-3) / 1e9 / world     # per GPU
 

@@ -879,6 +879,7 @@ struct SmallStage {
     pgps_ctx* ctx;
     size_t in_bytes = 0, out_bytes = 0, in_cap, out_off;
     bool ok = false;
+    bool in_flight = false;         // send() has queued a copy out of the pinned arena and finish() has not synchronised yet
     struct Out { void* host; size_t off, bytes; } outs[4];
     int nout = 0;
     // in_total / out_total: bytes of all inputs / outputs (each rounded up to 16)
@@ -888,6 +889,13 @@ struct SmallStage {
         if (ensure(ctx, ctx->pin_d, kPinArena) != PGPS_OK) return;
         ok = true;
     }
+    // an error return between send() and finish() (TRY leaves the function) must not leave the arena's host-to-device copy
+    // in flight: the next small call would memcpy its inputs into the same pinned bytes underneath it
+    ~SmallStage() {
+        if (in_flight) (void)hipStreamSynchronize(ctx->stream);
+    }
+    SmallStage(const SmallStage&) = delete;
+    SmallStage& operator=(const SmallStage&) = delete;
     static size_t up(size_t b) { return (b + 15) / 16 * 16; }
     template <typename T> T* in(const T* host, size_t n) {          // -> device pointer of the staged copy
         T* dev = (T*)((char*)ctx->pin_d.p + in_bytes);
@@ -902,12 +910,14 @@ struct SmallStage {
         return dev;
     }
     int send() {
+        in_flight = true;
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_d.p, ctx->pin_h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
         return PGPS_OK;
     }
     int finish() {                                                  // one copy back, the synchronisation, the scatter
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_h + out_off, (char*)ctx->pin_d.p + out_off, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        in_flight = false;
         for (int i = 0; i < nout; ++i)
             if (outs[i].host) memcpy(outs[i].host, ctx->pin_h + outs[i].off, outs[i].bytes);
         return PGPS_OK;

@@ -28,6 +28,7 @@ several contexts on one GPU or by CPU stand-ins under gloo in the tests.
 """
 import ctypes
 import os
+import threading
 import time
 
 import numpy as np
@@ -79,56 +80,122 @@ def _unique_launch(run_id):
     return bool(os.environ.get("SLURM_JOB_ID")) or (rid not in ("", "none"))
 
 
-def share_unique_id(rank, path=None, broadcast=None, timeout=120.0, run_id=None):
+def _read_small(path, want=None):
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+        return blob if (want is None or len(blob) == want) else None
+    except (FileNotFoundError, PermissionError):
+        return None
+
+
+def _write_atomic(path, blob):
+    tmp = f"{path}.tmp.{os.getpid()}.{threading.get_ident()}"
+    with open(tmp, "wb") as fh:
+        fh.write(blob)
+    os.replace(tmp, path)
+
+
+def _handshake_files(path, world):
+    return [f"{path}.hello.{r}" for r in range(1, world)] + [f"{path}.ack.{r}" for r in range(1, world)]
+
+
+def share_unique_id(rank, path=None, broadcast=None, timeout=120.0, run_id=None, world=None, make_id=None):
     """The communicator id of rank 0 on every rank.  Either `broadcast(bytes_or_None) -> bytes` (whatever the launcher
-    offers: MPI bcast, a torch.distributed / TCP store, ...) or a file all ranks can see (`path`, written atomically
-    by rank 0, polled by the others).  The file carries a tag of `run_id` (default: the launcher's rendezvous variables
-    MASTER_ADDR / MASTER_PORT / TORCHELASTIC_RUN_ID / SLURM_JOB_ID), and the other ranks accept only a file with THIS
-    run's tag: an id left at the same path by an earlier run is ignored, not joined.  Rank 0 removes the file with
-    `remove_unique_id_file(path)` once every rank has called pgps_comm_init.  No GPU work."""
+    offers: MPI bcast, a torch.distributed / TCP store, ...) or a file all ranks can see (`path`).  Joining an id that is
+    not this run's makes ncclCommInitRank hang, so a file is accepted only when it PROVABLY belongs to this launch -- never
+    because it looks recent (file ages compare a shared file system's clock with the local one, and a relaunch right after a
+    crash finds the dead run's file seconds old):
+
+    * `run_id` given, or the launcher provides one that differs from run to run (SLURM_JOB_ID, a real TORCHELASTIC_RUN_ID):
+      rank 0 writes the file atomically with a tag of that id, the others accept only a file carrying THIS run's tag;
+    * otherwise (plain `torchrun`: TORCHELASTIC_RUN_ID = 'none', the same address and port every time) `world` must be
+      given and the ranks shake hands through files next to `path`: every other rank draws a random token and leaves it in
+      `<path>.hello.<rank>`; rank 0 -- which first removes whatever an earlier run left there -- publishes the id together
+      with the tokens it has seen, a rank accepts the file only if it carries ITS token and acknowledges with
+      `<path>.ack.<rank>`; rank 0 returns once every acknowledgement matches (re-publishing if a rank re-drew its token).
+      A file of a dead run cannot carry a token drawn after it died.
+    * neither: ValueError -- fail rather than join an id that cannot be verified.
+
+    Rank 0 removes the files with `remove_unique_id_file(path)` once every rank has called pgps_comm_init.  `make_id`
+    (tests) replaces pgps_comm_get_unique_id.  No GPU work."""
     from . import _backend
-    uid = _backend.Context.comm_unique_id() if rank == 0 else None
+    uid = None
+    if rank == 0:
+        uid = make_id() if make_id is not None else _backend.Context.comm_unique_id()
+    nid = _backend.COMM_ID_BYTES
     if broadcast is not None:
         uid = broadcast(uid)
     elif path is not None:
-        tag = _run_tag(run_id)
-        want = len(_UID_MAGIC) + len(tag) + _backend.COMM_ID_BYTES
-        # Without a launch id that differs from run to run the tag cannot tell this run's file from one a crashed run left
-        # behind: readers then also require the file to be YOUNGER than their own start (rank 0 writes after it started,
-        # the ranks start within minutes of each other: 300 s of slack), so an id left long ago is never joined -- ncclCommInitRank on a dead id would hang.
-        started = time.time() - 1.0
-        fresh_only = not _unique_launch(run_id)
-        if rank == 0:
-            tmp = f"{path}.tmp.{os.getpid()}"
-            with open(tmp, "wb") as fh:
-                fh.write(_UID_MAGIC + tag + uid)
-            os.replace(tmp, path)
-        else:
-            deadline = time.monotonic() + timeout
-            while True:
-                try:
-                    with open(path, "rb") as fh:
-                        blob = fh.read()
-                    if len(blob) == want and blob.startswith(_UID_MAGIC + tag) and \
-                            (not fresh_only or os.path.getmtime(path) >= started - 300.0):
+        deadline = time.monotonic() + timeout
+        if _unique_launch(run_id):
+            tag = _run_tag(run_id)
+            want = len(_UID_MAGIC) + len(tag) + nid
+            if rank == 0:
+                _write_atomic(path, _UID_MAGIC + tag + uid)
+            else:
+                while True:
+                    blob = _read_small(path, want)
+                    if blob is not None and blob.startswith(_UID_MAGIC + tag):
                         uid = blob[len(_UID_MAGIC) + len(tag):]
                         break
-                except FileNotFoundError:
-                    pass
-                if time.monotonic() > deadline:
-                    raise TimeoutError(f"no communicator id of this run at {path} after {timeout} s")
-                time.sleep(0.01)
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"no communicator id of this run at {path} after {timeout} s")
+                    time.sleep(0.01)
+        elif world is not None and int(world) >= 1:
+            world = int(world)
+            magic = _UID_MAGIC + b"HANDSHAK"
+            want = len(magic) + nid + 16 * (world - 1)
+            if rank == 0:
+                for f in [path] + _handshake_files(path, world):
+                    try:
+                        os.unlink(f)
+                    except FileNotFoundError:
+                        pass
+                published = None
+                while True:
+                    toks = [_read_small(f"{path}.hello.{r}", 16) for r in range(1, world)]
+                    if all(t is not None for t in toks) and toks != published:
+                        _write_atomic(path, magic + uid + b"".join(toks))
+                        published = toks
+                    if published is not None and all(_read_small(f"{path}.ack.{r}", 16) == published[r - 1] for r in range(1, world)):
+                        break
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"ranks missing from the id handshake at {path} after {timeout} s")
+                    time.sleep(0.01)
+            else:
+                token = os.urandom(16)
+                hello, ack = f"{path}.hello.{rank}", f"{path}.ack.{rank}"
+                while True:
+                    if _read_small(hello, 16) != token:         # (rank 0 clears what it finds when it starts: say it again)
+                        _write_atomic(hello, token)
+                    blob = _read_small(path, want)
+                    if blob is not None and blob.startswith(magic):
+                        off = len(magic) + nid + 16 * (rank - 1)
+                        if blob[off:off + 16] == token:
+                            uid = blob[len(magic):len(magic) + nid]
+                            _write_atomic(ack, token)
+                            break
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"no communicator id carrying this rank's token at {path} after {timeout} s")
+                    time.sleep(0.01)
+        else:
+            raise ValueError("share_unique_id(path=...): this launch has no id that differs from run to run (plain torchrun) -- "
+                             "pass run_id=<unique per launch>, or world=<ranks> for the token handshake, or broadcast=")
     elif rank != 0:
         raise ValueError("share_unique_id needs `path` or `broadcast` when there is more than one rank")
     return bytes(uid)
 
 
-def remove_unique_id_file(path):
-    """Rank 0, after every rank has joined the communicator: the id file has served its purpose."""
-    try:
-        os.unlink(path)
-    except FileNotFoundError:
-        pass
+def remove_unique_id_file(path, world=None):
+    """Rank 0, after every rank has joined the communicator: the id file (and the handshake's files) have served."""
+    import glob as _glob
+    files = [path] + (_handshake_files(path, int(world)) if world else _glob.glob(path + ".hello.*") + _glob.glob(path + ".ack.*"))
+    for f in files:
+        try:
+            os.unlink(f)
+        except FileNotFoundError:
+            pass
 
 
 class ShardedScan:

@@ -52,6 +52,27 @@ class _StructureChanged(Exception):
     """_grad_rows_composite: the block partition of the drift is not the same at the perturbed parameters."""
 
 
+def _public_evaluation(fn):
+    """Marks the model's public evaluations (predict_f, maximum_log_likelihood_objective, log_likelihood_and_grad,
+    log_likelihood_batch).  `_device_series()` counts THESE -- the outermost one of a call chain -- not its own calls: one
+    evaluation may ask for the series several times on its way through the gradient methods and must get the same answer
+    each time (round 4 counted calls: the first gradient of a Matern model got None for its fused adjoint, a series on
+    the next internal call, and went down the dual-number road it had not chosen)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        depth = getattr(self, "_eval_depth", 0)
+        if depth == 0:
+            self._n_eval = getattr(self, "_n_eval", 0) + 1
+        self._eval_depth = depth + 1
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            self._eval_depth = depth
+    return wrapper
+
+
 class StateSpaceGP:
     def __init__(self, data, kernel, noise_variance=1.0, parallel=False, max_parallel=10000):
         self.noise_variance = float(noise_variance)
@@ -144,9 +165,8 @@ class StateSpaceGP:
         if ser is not None and getattr(self, "_series_stamp", None) != self._data_stamp(ts, ys):
             self.invalidate_device_series()         # the arrays were replaced or edited since the copy was made
             ser = None
-        if ser is None and not force and not getattr(self, "_series_wanted", False):
-            self._series_wanted = True
-            return None
+        if ser is None and not force and getattr(self, "_n_eval", 0) <= 1:
+            return None                             # still inside the model's first evaluation (however many internal calls it makes)
         if ser is None:
             from . import _backend
             t = ts.reshape(-1)
@@ -169,7 +189,6 @@ class StateSpaceGP:
             ser.close()
         self._series = None
         self._series_stamp = None
-        self._series_wanted = False
         self._ll_memo = None
 
     def _device_forms(self):
@@ -331,6 +350,7 @@ class StateSpaceGP:
         R = np.reshape(np.asarray(self.noise_variance, dtype=config.default_float()), (1, 1))
         return self.kernel.get_ssm(ts, R)
 
+    @_public_evaluation
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
         """Posterior mean (K, 1) and variance (K, 1) at `Xnew` (pssgp/model.py:92-111):
         merge train and query times, mark queries as missing, smooth, keep the query rows,
@@ -396,6 +416,7 @@ class StateSpaceGP:
         var = np.einsum("ai,nij,aj->na", H, sP, H)
         return mean, var
 
+    @_public_evaluation
     def maximum_log_likelihood_objective(self):
         ts, Y = self.data
         fused, lti = self._device_forms()
@@ -710,6 +731,7 @@ class StateSpaceGP:
             g = np.where(keep, g, 0.0)
         return config.default_float()(stats[0]), g
 
+    @_public_evaluation
     def log_likelihood_and_grad(self, wrt=None, method=None):
         """(ll, grad): the marginal log-likelihood and its gradient with respect to
         `trainable_parameters()` -- what the reference obtains from tf.GradientTape over
@@ -722,9 +744,15 @@ class StateSpaceGP:
         the cross-checks of the tests); `wrt`: only these parameter indices, the others get 0."""
         if not self.parallel:
             raise NotImplementedError("gradients run on the parallel (HIP) path: construct with parallel=True")
+        if method not in (None, "adjoint", "dual", "differences"):
+            raise ValueError(f"method = {method!r}: None (automatic), 'adjoint', 'dual' or 'differences'")
         from . import _backend
         ts, Y = self.data
         fused, lti = self._device_forms()
+        if method == "differences":
+            # asked for by name: Richardson differences of batched likelihoods whatever the kernel (one evaluation at a
+            # time where no batched entry point covers the state dimension)
+            return self._lti_ll_and_grad(batched=(fused is not None or lti is not None), wrt=wrt)
         if fused is None and lti is not None and method in (None, "adjoint"):
             # every kernel without the closed-form discretisation: the adjoint pass (two passes whatever the number of
             # parameters); None when the kernel has no derivative rule or the library no such entry point
@@ -746,6 +774,11 @@ class StateSpaceGP:
                     keep[[int(i) for i in wrt]] = True
                     g = np.where(keep, g, 0.0)
                 return ll, g
+            if method == "dual":
+                raise NotImplementedError("method = 'dual': this kernel is no sum / product of Matern kernels of d <= "
+                                          f"{_backend.GRAD_BLOCKS_DIM_MAX} (use 'adjoint' or 'differences')")
+            if method == "adjoint":
+                raise NotImplementedError("no adjoint gradient for this kernel / library")
             # no dual-number path: batched differences on the general-LTI kernels (d <= 16), one evaluation at a
             # time above that (e.g. the CO2 kernel at its reference order, d = 18)
             return self._lti_ll_and_grad(batched=lti is not None, wrt=wrt)
@@ -759,6 +792,13 @@ class StateSpaceGP:
             out = self._adjoint_ll_and_grad(wrt, prepared=self._matern_prepared(fused))
             if out is not None:
                 return out
+        if method == "adjoint":
+            # asked for by name and not available on the fused path (float32 data, a library without the entry point, a series
+            # that cannot be made resident): the general adjoint pass on the same model, or an error -- never silently duals
+            out = self._adjoint_ll_and_grad(wrt, prepared=self._matern_prepared(fused))
+            if out is not None:
+                return out
+            raise NotImplementedError("method = 'adjoint' is not available for this model / library")
         ser = self._device_series() if ts.dtype == np.float64 else None
         if ser is not None:
             model, d, npar = _backend.pack_grad_model(self._grad_blocks())
@@ -808,6 +848,7 @@ class StateSpaceGP:
             grad[i] = (4.0 * d2 - d1) / 3.0
         return float(lls[0]), grad
 
+    @_public_evaluation
     def log_likelihood_batch(self, thetas):
         """Marginal log-likelihoods at B hyper-parameter settings in one call: `thetas` is (B, P) in the
         order of `trainable_parameters()`.  The B filters share the series and run side by side on

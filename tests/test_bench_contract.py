@@ -92,6 +92,7 @@ def test_one_gpu_line_has_the_contract_fields():
     assert {"k_filter_reduce", "k_filter_apply", "k_smoother_apply"} <= set(r["slots"])
     for v in r["slots"].values():
         assert v["ms_per_pass"] > 0 and abs(v["frac"] - v["alg_bytes"] / (v["ms_per_pass"] * 1e-3) / 1e9 / r["peak"]) < 1e-9
+        assert v["frac"] <= 1.0
     assert "traffic_stale" in r
     assert j["f32_promoted"] is None and j["grid"] == "baseline"
     for leg in ("filter+smooth+log-lik", "log-lik only"):
@@ -102,6 +103,25 @@ def test_one_gpu_line_has_the_contract_fields():
     c = j["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["cores"] == 1
     assert c["value"] > 0 and c["unit"] == j["unit"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["--kernel", "c5", "--log2n", "16"], ["--kernel", "rbf8", "--dtype", "f32", "--log2n", "16"],
+                                  ["--kernel", "co2", "--log2n", "14"], ["--log2n", "19"]])
+def test_no_launch_slot_is_priced_above_the_roofline(args):
+    """Every slot of every kernel family is priced against the bytes of the contract its own kernels touch: the cooperative
+    families' scan slots (chain totals only) carry no per-step bytes and report frac = None, never a fraction above 1
+    (round 4's c5 line read 6.27 there); the resident launch (2^19 steps of d = 2) is priced against the whole contract."""
+    j = _run(args + ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--main-only"])
+    r = j["roofline"]
+    assert r["slots"], r
+    for name, v in r["slots"].items():
+        assert v["frac"] is None or 0.0 < v["frac"] <= 1.0, (name, v)
+        if v["frac"] is None:
+            assert v["alg_bytes"] is None and name == "k_smoother_reduce"
+    assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["whole_path_frac"] <= 1.0
+    if args == ["--log2n", "19"]:
+        assert r["kernel"] == "k_pkfs_resident" and r["kernel_family"] == 12 and set(r["slots"]) == {"k_pkfs_resident"}
 
 
 @pytest.mark.gpu

@@ -426,8 +426,8 @@ def test_rccl_communicator_in_library_world_1(dtype, kname, tmp_path):
     os_, osP = O.kfs(ssm, y)
     ctx = B.Context(0)
     assert ctx.comm_info() == (0, 0)
-    uid = share_unique_id(0, path=str(tmp_path / "uid"))
-    assert share_unique_id(1, path=str(tmp_path / "uid")) == uid        # what another rank would read
+    uid = share_unique_id(0, path=str(tmp_path / "uid"), run_id="world-1-test")
+    assert share_unique_id(1, path=str(tmp_path / "uid"), run_id="world-1-test") == uid        # what another rank would read
     seg = ShardedScan(ctx, uid, 0, 1, d, dtype)
     assert ctx.comm_info() == (0, 1)
     n = y.size
@@ -508,3 +508,73 @@ def test_segment_phases_out_of_order_are_refused(kname):
     for v in (P0, Fs, Qs, H, ys, fms, fPs, sms, sPs, rec_f, rec_s, ll):
         v.free()
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU: the communicator id reaches every rank of THIS launch only (no clocks, no file ages)
+# ------------------------------------------------------------------------------------------------
+def _fake_id(byte):
+    from pssgp import _backend as B
+    return lambda: bytes([byte]) * B.COMM_ID_BYTES
+
+
+def test_unique_id_by_run_tag_ignores_another_runs_file(tmp_path):
+    from pssgp.distributed import share_unique_id
+    path = str(tmp_path / "uid")
+    old = share_unique_id(0, path=path, run_id="run-A", make_id=_fake_id(1))
+    with pytest.raises(TimeoutError):                     # run B's rank 1 does not join run A's id, however fresh the file is
+        share_unique_id(1, path=path, run_id="run-B", timeout=0.3)
+    new = share_unique_id(0, path=path, run_id="run-B", make_id=_fake_id(2))
+    assert share_unique_id(1, path=path, run_id="run-B", timeout=5.0) == new != old
+
+
+def test_unique_id_without_a_launch_id_needs_the_handshake(tmp_path, monkeypatch):
+    from pssgp.distributed import share_unique_id
+    for k in ("TORCHELASTIC_RUN_ID", "SLURM_JOB_ID"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(ValueError):
+        share_unique_id(1, path=str(tmp_path / "uid"), timeout=0.2)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")     # plain torchrun
+    with pytest.raises(ValueError):
+        share_unique_id(1, path=str(tmp_path / "uid"), timeout=0.2)
+
+
+@pytest.mark.parametrize("rank0_late", [False, True])
+def test_unique_id_handshake_survives_a_dead_runs_files(tmp_path, monkeypatch, rank0_late):
+    """A relaunch at the same path right after a crash (plain torchrun: no launch id): the dead run's id file -- seconds old --
+    and its hello / ack files are all there.  Every rank must end up with the NEW id, whichever side starts first."""
+    import threading
+    import time as _time
+    from pssgp import _backend as B
+    from pssgp.distributed import share_unique_id, remove_unique_id_file
+    for k in ("TORCHELASTIC_RUN_ID", "SLURM_JOB_ID"):
+        monkeypatch.delenv(k, raising=False)
+    path = str(tmp_path / "uid")
+    world = 4
+    # what the dead run left: a well-formed id file with ITS tokens, and the matching hello / ack files
+    dead_tokens = [bytes([0x40 + r]) * 16 for r in range(1, world)]
+    with open(path, "wb") as fh:
+        fh.write(b"PGPSUID2HANDSHAK" + b"\x07" * B.COMM_ID_BYTES + b"".join(dead_tokens))
+    for r in range(1, world):
+        for kind in ("hello", "ack"):
+            with open(f"{path}.{kind}.{r}", "wb") as fh:
+                fh.write(dead_tokens[r - 1])
+    got, errs = {}, []
+
+    def run(rank, delay):
+        try:
+            _time.sleep(delay)
+            got[rank] = share_unique_id(rank, path=path, world=world, timeout=20.0, make_id=_fake_id(9))
+        except Exception as e:              # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(r, (0.3 if rank0_late else 0.0) if r == 0 else (0.0 if rank0_late else 0.3) + 0.05 * r))
+           for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(30.0)
+    assert not errs, errs
+    assert len(got) == world and all(v == bytes([9]) * B.COMM_ID_BYTES for v in got.values())
+    remove_unique_id_file(path, world)
+    assert not list(tmp_path.iterdir())

@@ -10,7 +10,7 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
             "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/$out/p$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --main-only --event-every 0 "$@" > $R/gpurun_out/$out/p$i.log 2>&1
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/$out/p$i -- python3 $R/bench.py --steps 5 --warmup 2 --rewarm-ms 0 --no-cpu-baseline --main-only --event-every 0 "$@" > $R/gpurun_out/$out/p$i.log 2>&1
   echo "pass $i rc=$?"
 done
 python3 - "$R/gpurun_out/$out" <<'PY'

@@ -37,7 +37,9 @@ def main():
         for r in csv.DictReader(open(f)):
             per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     slots = collections.defaultdict(lambda: {"FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0, "kernels": []})
-    passes = None
+    # passes PER COUNTER RUN: FETCH_SIZE and WRITE_SIZE come from separate runs of the bench, and since its re-warm is time
+    # based the two runs do not make the same number of passes
+    passes = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
     for kname, ctr in per.items():
         slot = next((s for pat, s in SLOT_OF if pat in kname), None)
         slot = rename.get(slot, slot)
@@ -50,13 +52,14 @@ def main():
         # single-launch kernels fix the number of passes that were profiled
         # (the most frequent one: warm-up / fused-path variants of the same kernel run fewer times)
         if any(p in kname for p in ("rc_apply1", "k_filter_apply", "k_filter_single", "k_pkfs_resident")):
-            passes = max(passes or 0, n)
+            for c in passes:
+                passes[c] = max(passes[c], len(ctr[c]))
         slots[slot]["FETCH_SIZE_KiB"] += sum(ctr["FETCH_SIZE"])
         slots[slot]["WRITE_SIZE_KiB"] += sum(ctr["WRITE_SIZE"])
-    assert passes, "no filter-apply dispatches found"
+    assert passes["FETCH_SIZE"] and passes["WRITE_SIZE"], "no filter-apply dispatches found"
     entry = {}
     for slot, v in slots.items():
-        f, w = v["FETCH_SIZE_KiB"] / passes, v["WRITE_SIZE_KiB"] / passes
+        f, w = v["FETCH_SIZE_KiB"] / passes["FETCH_SIZE"], v["WRITE_SIZE_KiB"] / passes["WRITE_SIZE"]
         entry[slot] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "fetch_factor": factor,
                        "traffic_bytes": int((factor * f + w) * 1024), "kernels": v["kernels"]}
     doc = {}
