@@ -1,3 +1,4 @@
+#include <chrono>
 // pgps_core.hip -- the C ABI of libpgps.so (include/pgps.h): context, scratch, staging and
 // dimension dispatch.  The kernels live in pgps_inst.hip (one unit per dtype x state dim).
 // No PyTorch, no TensorFlow: HIP runtime only.
@@ -106,9 +107,6 @@ extern "C" int pgps_destroy(pgps_ctx* ctx) {
     for (auto& b : ctx->wide)
         if (b.p) (void)hipFree(b.p);
     if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
-    if (ctx->probe_ev) (void)hipEventDestroy(ctx->probe_ev);
-    if (ctx->probe_in) (void)hipEventDestroy(ctx->probe_in);
-    if (ctx->probe_stream) (void)hipStreamDestroy(ctx->probe_stream);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -606,33 +604,35 @@ extern "C" int pgps_get_family(pgps_ctx* ctx, long N, int d, int f32, int what, 
 // grid, 2 always widens.  Filter-only calls (pkf) hold 1e-3 natively on every grid measured and are never probed.
 // ---------------------------------------------------------------------------------------------
 namespace pgps {
-// work[0] = dense samples so far, work[1] = workgroups done (both device memory, zero between calls: the last workgroup
-// publishes the count to the pinned word and clears them -- no memset launch in front of the probe)
-static __global__ void k_f32_probe(long N, int d, const float* __restrict__ Fs, float tau, long stride, int nsamp, int* work,
-                                   int* result) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+// ONE workgroup of 1024 lanes: sixteen lanes share a sampled transition matrix (consecutive lanes read consecutive entries:
+// whole 64-byte segments -- one lane per matrix made every load instruction touch 64 cache lines, 17 us of one CU's address
+// unit for 1024 samples), kProbeRounds samples per group; the count of dense samples comes out of a workgroup reduction -- no
+// inter-workgroup atomics, no counters to reset.  result[1] = the count, then result[0] = the call's sequence number
+// (system-scope release): the host spins on that word, no event involved.
+constexpr int kProbeGroup = 16, kProbeRounds = 4, kProbeSamples = 1024 / kProbeGroup * kProbeRounds;
+static __global__ __launch_bounds__(1024) void k_f32_probe(long N, int d, const float* __restrict__ Fs, float tau, long stride,
+                                                             int nsamp, int* result, int seq) {
+    const int g = threadIdx.x / kProbeGroup, j = threadIdx.x % kProbeGroup;
+    const int dd = d * d;
     int dense = 0;
-    if (s < nsamp) {
-        long k = 1 + (long)s * stride;              // (step 0 spans t0 .. t_0: whatever the grid, it may be long)
-        if (k >= N) k = N - 1;
-        const float* F = Fs + k * (long)d * d;
-        float r = 0.f;
-        for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) r = fmaxf(r, fabsf(F[i * d + j] - (i == j ? 1.f : 0.f)));
-        dense = r < tau;
-    }
-    const int cnt = __syncthreads_count(dense);
-    if (threadIdx.x == 0) {
-        if (cnt) atomicAdd(&work[0], cnt);
-        __threadfence();
-        if (atomicAdd(&work[1], 1) == (int)gridDim.x - 1) {
-            __threadfence();
-            const int total = atomicAdd(&work[0], 0);
-            __hip_atomic_store(result, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            work[0] = 0;
-            work[1] = 0;
-            __threadfence();
+    for (int r = 0; r < kProbeRounds; ++r) {
+        const int s = r * (1024 / kProbeGroup) + g;
+        float m = 0.f;
+        if (s < nsamp) {
+            long k = 1 + (long)s * stride;          // (step 0 spans t0 .. t_0: whatever the grid, it may be long)
+            if (k >= N) k = N - 1;
+            const float* F = Fs + k * (long)dd;
+            for (int e = j; e < dd; e += kProbeGroup) m = fmaxf(m, fabsf(F[e] - ((e / d == e % d) ? 1.f : 0.f)));
         }
+        for (int o = kProbeGroup / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kProbeGroup));
+        dense += (j == 0 && s < nsamp && m < tau) ? 1 : 0;
+    }
+    // (a lane's count is 0..kProbeRounds: sum them over the workgroup)
+    int total = 0;
+    for (int c = 1; c <= kProbeRounds; ++c) total += __syncthreads_count(dense >= c);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(result + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(result, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 }  // namespace pgps
@@ -649,39 +649,60 @@ static float f32_dense_threshold(int d) {
     return 3.0e38f;
 }
 
-// The probe of a float32 smoother call, enqueued on the context's stream with an event behind it.  *fixed: the policy
-// already decides (no probe): 0 / 1 = float32 / fp64 arithmetic.
+// The probe of a float32 smoother call: ONE small launch on the context's stream, in front of the call's own kernels, whose
+// last workgroup writes its verdict and the call's sequence number to pinned host memory.  *fixed: the policy already decides
+// (no probe): 0 / 1 = float32 / fp64 arithmetic.
+// (Round 4 ran the probe on a stream of its own between two events -- hipEventRecord on the context's stream, a
+// hipStreamWaitEvent, a second event the host synchronised on: beside the call's first kernel instead of in front of it, but
+// each event record is a barrier packet on the stream that costs the pass ~5 us (the same effect bench.py's per-launch stamps
+// showed in round 5), which is where the probe's +3 .. 4.6 % on c3 came from.  One 4 us kernel costs less than its plumbing.)
 static int f32_probe_launch(pgps_ctx* ctx, long N, int d, const float* Fs, int* fixed, int* nsamp_out) {
     *fixed = -1;
     if (ctx->f32_policy == 1) { *fixed = 0; return PGPS_OK; }
     if (ctx->f32_policy == 2 || d > 16) { *fixed = 1; return PGPS_OK; }
     if (N < 3) { *fixed = 0; return PGPS_OK; }
     if (!ctx->probe_host) {
-        HIPCHK(ctx, hipHostMalloc((void**)&ctx->probe_host, 64, hipHostMallocDefault));
-        HIPCHK(ctx, hipHostGetDevicePointer((void**)&ctx->probe_dev, ctx->probe_host, 0));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->probe_ev, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->probe_in, hipEventDisableTiming));
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->probe_stream, hipStreamNonBlocking));
-        HIPCHK(ctx, hipMemset(ctx->status_word + 16, 0, 2 * sizeof(int)));     // the probe's two work counters
+        // all or nothing: the context keeps the pinned words only once every step of the setup has succeeded
+        int* host = nullptr;
+        int* dev = nullptr;
+        HIPCHK(ctx, hipHostMalloc((void**)&host, 64, hipHostMallocDefault));
+        if (hipHostGetDevicePointer((void**)&dev, host, 0) != hipSuccess) {
+            (void)hipHostFree(host);
+            ctx->hip_err = "float32 probe: pinned result words could not be set up";
+            return PGPS_E_HIP;
+        }
+        host[0] = 0;
+        host[1] = 0;
+        ctx->probe_host = host;
+        ctx->probe_dev = dev;
+        ctx->probe_seq = 0;
     }
-    const int nsamp = (int)std::min<long>(4096, N - 1);
+    const int nsamp = (int)std::min<long>(pgps::kProbeSamples, N - 1);
     const long stride = std::max<long>(1, (N - 1) / nsamp);
-    // The probe runs on a stream of its own, behind everything the context's stream holds at this point (the arrays it reads
-    // may have been produced there) and BESIDE what the call enqueues next: in front of the call's first kernel it cost the
-    // pass its launch gap.
-    HIPCHK(ctx, hipEventRecord(ctx->probe_in, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->probe_stream, ctx->probe_in, 0));
-    hipLaunchKernelGGL(pgps::k_f32_probe, dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, ctx->probe_stream, N, d, Fs,
-                       f32_dense_threshold(d), stride, nsamp, ctx->status_word + 16, ctx->probe_dev);
+    ctx->probe_seq = (ctx->probe_seq % 0x3fffffff) + 1;         // never 0: the words start at 0
+    hipLaunchKernelGGL(pgps::k_f32_probe, dim3(1), dim3(1024), 0, ctx->stream, N, d, Fs, f32_dense_threshold(d), stride, nsamp,
+                       ctx->probe_dev, ctx->probe_seq);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->probe_ev, ctx->probe_stream));
     *nsamp_out = nsamp;
     return PGPS_OK;
 }
-// ... and its answer: waits for the probe alone (whatever the call has enqueued behind it keeps the GPU busy meanwhile)
+// ... and its answer: the host spins on the pinned sequence word (no HIP call, no event: the probe is the first thing this
+// call put on the stream, whatever the call enqueues behind it keeps the GPU busy meanwhile).  Bounded: a stream that never
+// reaches the probe (a hung predecessor) ends the call with PGPS_E_HIP after ~20 s instead of hanging the host.
 static int f32_probe_result(pgps_ctx* ctx, int nsamp, int* dense) {
-    HIPCHK(ctx, hipEventSynchronize(ctx->probe_ev));
-    *dense = (long)ctx->probe_host[0] * 8 >= nsamp;
+    volatile int* w = ctx->probe_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(&w[0], __ATOMIC_ACQUIRE) != ctx->probe_seq) {
+        if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            ctx->hip_err = "float32 probe: no verdict from the device within 20 s";
+            return PGPS_E_HIP;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    *dense = (long)w[1] * 8 >= nsamp;
     return PGPS_OK;
 }
 
@@ -704,7 +725,10 @@ static int f32_smoother_call(pgps_ctx* ctx, int d, const ScanArgs<float>& a, Mod
         ctx->f32_last_promoted = dense;
         return dense ? f32_run_wide(ctx, d, a, mode) : dispatch_scan<float>(ctx, d, a, mode);
     }
-    if ((rc_ = dispatch_scan<float>(ctx, d, a, mode))) return rc_;
+    if ((rc_ = dispatch_scan<float>(ctx, d, a, mode))) {
+        (void)f32_probe_result(ctx, nsamp, &dense);      // (the probe reads the caller's Fs: it has run before the error is returned)
+        return rc_;
+    }
     if ((rc_ = f32_probe_result(ctx, nsamp, &dense))) return rc_;
     ctx->f32_last_promoted = dense;
     return dense ? f32_run_wide(ctx, d, a, mode) : PGPS_OK;

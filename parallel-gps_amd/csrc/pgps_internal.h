@@ -48,9 +48,7 @@ struct pgps_ctx {
     int f32_policy = 0;                 // float32 series with a smoother: 0 = automatic promotion on dense grids, 1 = always native, 2 = always fp64 arithmetic (pgps_set_f32_policy)
     int* probe_host = nullptr;          // pinned word pair the dense-grid probe of a float32 call writes (and its device alias)
     int* probe_dev = nullptr;
-    hipEvent_t probe_ev = nullptr;      // recorded behind the probe: the host waits for the probe alone, not for the stream
-    hipEvent_t probe_in = nullptr;      // recorded on the context's stream at the call's entry: the probe's stream waits for it
-    hipStream_t probe_stream = nullptr; // the probe runs beside the call's first kernel, not in front of it
+    int probe_seq = 0;                  // sequence number of the last probe: its last workgroup writes it to probe_host[0] behind the verdict
     int f32_last_promoted = 0;          // which way the last probed call went: decides the ORDER of the next one (see pgps_core.hip)
     // small host-array calls (pgps_gp_predict_*, pgps_lti_predict_f64, ...): one pinned arena, ONE copy in and ONE copy out
     char* pin_h = nullptr;              // hipHostMalloc, kPinArena bytes, made at the first small call

@@ -262,6 +262,47 @@ __device__ __forceinline__ E res_readlane_elem(const E& e, int l) {
 }
 // inclusive scan of the values lanes 0..3 hold (identity elsewhere), in place: lanes 0..3 end with the prefixes (FORWARD)
 // or the suffixes of the four
+// wave_scan_inclusive of pgps_kernels.hip.h with the per-level `if (lane takes part)` turned into a select: six levels in one
+// basic block instead of six divergent regions (PGPS_RES_SCAN_SELECT=0: the shared branching version)
+#ifndef PGPS_RES_SCAN_SELECT
+#define PGPS_RES_SCAN_SELECT 1
+#endif
+template <typename E, bool FORWARD>
+__device__ __forceinline__ void res_wave_scan_inclusive(E& incl, int lane) {
+#if PGPS_RES_SCAN_SELECT
+    using TR = ElemTraits<E>;
+    const int r = lane & 15;
+    auto step = [&](const E& other, bool act) {
+        E t;
+        if (FORWARD) TR::combine(other, incl, t); else TR::combine(incl, other, t);
+        typename TR::Scalar a[TR::N], b[TR::N];
+        pack(t, a);
+        pack(incl, b);
+#pragma unroll
+        for (int i = 0; i < TR::N; ++i) b[i] = act ? a[i] : b[i];
+        unpack(b, incl);
+    };
+    if constexpr (FORWARD) {
+        step(dpp_elem<kDppRowShr + 1, 0xf>(incl), r >= 1);
+        step(dpp_elem<kDppRowShr + 2, 0xf>(incl), r >= 2);
+        step(dpp_elem<kDppRowShr + 4, 0xf>(incl), r >= 4);
+        step(dpp_elem<kDppRowShr + 8, 0xf>(incl), r >= 8);
+        step(dpp_elem<kDppBcast15, 0xa>(incl), (lane & 16) != 0);
+        step(dpp_elem<kDppBcast31, 0xc>(incl), lane >= 32);
+    } else {
+        step(dpp_elem<kDppRowShl + 1, 0xf>(incl), r + 1 < 16);
+        step(dpp_elem<kDppRowShl + 2, 0xf>(incl), r + 2 < 16);
+        step(dpp_elem<kDppRowShl + 4, 0xf>(incl), r + 4 < 16);
+        step(dpp_elem<kDppRowShl + 8, 0xf>(incl), r + 8 < 16);
+        const int row = lane >> 4;
+        step(shfl_idx_elem(incl, ((row + 1) & 3) * 16), row < 3);
+        step(shfl_idx_elem(incl, ((row + 2) & 3) * 16), row < 2);
+    }
+#else
+    wave_scan_inclusive<E, FORWARD>(incl, lane);
+#endif
+}
+
 template <typename E, bool FORWARD>
 __device__ __forceinline__ void res_scan4(E& x, int lane) {
     using TR = ElemTraits<E>;
@@ -287,7 +328,7 @@ __device__ __forceinline__ void res_block_scan_exclusive(const E& mine, E& excl,
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     E incl = mine;
-    wave_scan_inclusive<E, FORWARD>(incl, lane);
+    res_wave_scan_inclusive<E, FORWARD>(incl, lane);
     E wex = wave_shift1<E, FORWARD>(incl);
     if (FORWARD ? (lane == 0) : (lane == kWave - 1)) TR::identity(wex);
     if (FORWARD ? (lane == kWave - 1) : (lane == 0)) rec_store(lds + wave * TR::N, incl);
@@ -323,7 +364,7 @@ __device__ __forceinline__ void res_block_reduce_ordered(const E& mine, E& total
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     E acc = mine;
-    wave_scan_inclusive<E, true>(acc, lane);
+    res_wave_scan_inclusive<E, true>(acc, lane);
     if (lane == kWave - 1) rec_store(lds + wave * TR::N, acc);
     __syncthreads();
     E t;

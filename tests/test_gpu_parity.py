@@ -18,6 +18,10 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 TOL64 = 1e-9
 TOL32 = 1e-3
+# How the tolerances are applied (tests/conftest.py `relerr`): max |got - want| / max |want| over the whole array -- a
+# MAX-NORM relative error, as the reference's own comparisons are (np.testing.assert_allclose with atol = rtol on arrays of
+# O(1) entries, tests/test_gp_vs_kfs.py:60-99).  Entries much smaller than the array's largest one (far off-diagonal terms of
+# a smoothed covariance) are therefore not each held to 1e-3 of their own size in float32.
 
 
 def _gpu():
