@@ -529,10 +529,21 @@ struct StageGeom {
     static constexpr int BYTES = kWave * STRIDE;
 };
 
+// Ordering of a wave's OWN LDS accesses (the staging buffers are wave-private: one lane writes what another lane of the same
+// wave reads next).  The LDS executes a wave's instructions in issue order, so only the compiler has to be held to program
+// order: fences at WAVEFRONT scope.  Until round 5 these were workgroup-scope fences, which on gfx950 also drain every
+// vector-memory operation of the wave (s_waitcnt vmcnt(0) in front of each): every sub-tile waited for its own prefetch and
+// for the previous sub-tile's output stores.  -DPGPS_LDS_SYNC_WORKGROUP restores that (A/B: profiles/r05_experiments.txt).
 __device__ __forceinline__ void wave_lds_sync() {
+#ifdef PGPS_LDS_SYNC_WORKGROUP
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 template <typename GEO>

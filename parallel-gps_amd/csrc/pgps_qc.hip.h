@@ -287,10 +287,21 @@ __device__ __forceinline__ void ident2(const Lane<D>& ln, float dg, V2 (&z)[D]) 
 #define PGPS_QC_WIDE 1
 #endif
 constexpr unsigned kOob = 0x7ffff000u;
+// (every kernel that calls this is ONE wave per workgroup and its LDS is that wave's own: the LDS executes a wave's
+// instructions in issue order, so only the compiler has to be held to program order -- wavefront scope.  Until round 5 these
+// were workgroup-scope fences, which on gfx950 also drain the wave's vector-memory operations (s_waitcnt vmcnt(0)): the
+// prefetched next step and the previous step's stores were waited for at every LDS hand-over.  -DPGPS_LDS_SYNC_WORKGROUP
+// restores that for A/B runs.  LDS-DMA fetches are waited for explicitly where they are consumed: dma_wait_all.)
 __device__ __forceinline__ void wsync() {
+#ifdef PGPS_LDS_SYNC_WORKGROUP
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 template <int D>
 struct Wide {

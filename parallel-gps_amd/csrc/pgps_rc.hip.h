@@ -49,10 +49,21 @@ template <typename T> using Id = typename Ident<T>::type;      // a parameter th
 constexpr int kLdT = 17;                    // leading dimension of a transpose patch (16 lanes + 1)
 constexpr int kPatch = 16 * kLdT;           // doubles per row patch
 
+// (every kernel that calls this is ONE wave per workgroup and its LDS is that wave's own: the LDS executes a wave's
+// instructions in issue order, so only the compiler has to be held to program order -- wavefront scope.  Until round 5 these
+// were workgroup-scope fences, which on gfx950 also drain the wave's vector-memory operations (s_waitcnt vmcnt(0)): the
+// prefetched next step and the previous step's stores were waited for at every LDS hand-over.  -DPGPS_LDS_SYNC_WORKGROUP
+// restores that for A/B runs.  LDS-DMA fetches are waited for explicitly where they are consumed: dma_wait_all.)
 __device__ __forceinline__ void sync() {
+#ifdef PGPS_LDS_SYNC_WORKGROUP
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 __host__ __device__ inline int nfilt(int d) { return 3 * d * d + 2 * d; }      // [A | C | J | b | eta], as pgps_wc.hip
 __host__ __device__ inline int nsmth(int d) { return 2 * d * d + d; }          // [E | L | g]
