@@ -108,8 +108,22 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
     if constexpr (sizeof(T) == 8 && D == 2 && G == 4)
         dma = ctx->dma > 0 && (a.Lc == 16 || a.Lc == 32);
 #endif
+    // whole-series filter + smoother: the smoothing totals in innovation form (pgps_math.h smth_extend_u) -- the fold of a step into
+    // the lane's total is one matrix product and a rank-one update instead of three matrix products, and no L = P - E F P
+    // (-DPGPS_DFORM=0: the reference's (E, g, L) elements everywhere, as the segment protocol keeps them)
+#ifndef PGPS_DFORM
+#define PGPS_DFORM 1
+#endif
+    const bool dform = PGPS_DFORM != 0 && mode == MODE_PKFS && !dma;
+    a.dform = dform ? 1 : 0;
     auto launch_apply = [&](auto smooth_tag) {
         constexpr bool SMOOTH = decltype(smooth_tag)::value;
+        if constexpr (SMOOTH) {
+            if (dform) {
+                timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_apply<T, D, true, G, NT, false, true>, grid, block, 0, a);
+                return;
+            }
+        }
 #ifdef PGPS_NARROW
         if constexpr (sizeof(T) == 8 && D == 2 && G == 4) {
             if (dma) {
@@ -150,6 +164,7 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
         const bool want = ctx->single_pass < 0 ? PGPS_SINGLE_PASS_AUTO : ctx->single_pass != 0;
         if (want && fits && (mode == MODE_PKF || mode == MODE_PKFS)) {
             a.win = 0;
+            a.dform = 0;                    // (k_filter_single builds the reference's elements)
             HIPCHK(ctx, hipMemsetAsync(a.flags, 0, 8 * 32 * sizeof(int), s));        // the barrier's 8 counter shards
             if (mode == MODE_PKFS) {
                 timed_launch(ctx, PGPS_K_FILTER_APPLY, k_filter_single<T, D, true, 16, NT>, grid, block, 0, a);

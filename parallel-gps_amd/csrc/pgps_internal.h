@@ -160,6 +160,8 @@ struct ScanArgs {
     T* incl;                // (nblocks, d + d(d+1)/2) inclusive (m, P) of the window-closing tiles
     int win;                // look-back window (tiles); <= kBlock
     long long* stamps;      // diagnostic build only (-DPGPS_STAMPS): (3 kernels, nblocks, 8) s_memtime stamps
+    int dform;              // lsuf / sspine hold smoothing totals in innovation form (pgps_math.h smth_extend_u): the smoother adds the
+                            // filtered moments of the step a total was applied at.  Whole-series pkfs of the lane-chunk kernels only
 };
 
 // record lengths (in elements of T) of the segment exchange
@@ -313,6 +315,7 @@ struct RcArgsT {
     int store_f;                // write fms / fPs (0: log-likelihood-only and projected-posterior calls)
     const int* qslot;           // projected-posterior mode: (N,) slot of step k in pmean / pvar, or -1
     Real *pmean, *pvar;       // (K,) H sm and H sP H^T at the query steps
+    int dform;                  // the chains' smoothing totals are in innovation form (rc_apply1 DFORM): rc_smooth1 adds the filtered moments
     int quad;                   // level-1 kernels of the quad-cooperative family (pgps_qc.hip.h: fp32, 5 <= d <= 8, 16 chains per wave)
 };
 using RcArgs = RcArgsT<double>;

@@ -783,20 +783,33 @@ __global__ __launch_bounds__(kBlock) void k_filter_reduce(const ScanArgs<T> a) {
 // K-F3: filter apply (+ log-likelihood, + fused smoothing-aggregate build when SMOOTH)
 // ---------------------------------------------------------------------------------------------
 // one step of the lane-serial Kalman pass; `prev` = filtered state of step k-1 (or the carry-in)
-template <typename T, int D, bool SMOOTH, typename LL = LogLik>
+// DFORM: the smoothing total is kept in innovation form (pgps_math.h smth_extend_u): no L = P - E (F P) product and a rank-one
+// fold instead of two matrix products; the smoother then adds the filtered moments of the step a total is applied at
+// (ScanArgs::dform).  Whole-series pkfs only: the segment protocol exchanges totals in the reference's (E, g, L) form.
+template <typename T, int D, bool SMOOTH, typename LL = LogLik, bool DFORM = false>
 __device__ __forceinline__ void filter_apply_step(const ScanArgs<T>& a, long k, long k0, const T* F, const T* Qf, T y,
                                                   const T* h, MeanCov<T, D>& s, LL& ll, SmthElem<T, D>& sagg) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM;
     T Q[SYM];
     sym_from_full<T, D>(Qf, Q);
-    MeanCov<T, D> prev = s;
     T mp[D], Pp[SYM], FP[MAT];
-    kf_step(s, F, Q, y, h, a.R, (k == 0) && a.seg_first, ll, mp, Pp, FP);
-    if (SMOOTH && k > k0) {                 // element of step k-1 from this step's predict
-        SmthElem<T, D> e, r;
-        smth_element(prev, mp, Pp, FP, e);
-        smth_combine(sagg, e, r);
-        sagg = r;
+    if constexpr (DFORM && SMOOTH) {
+        T u[D], inv, res;
+        kf_step_u(s, F, Q, y, h, a.R, (k == 0) && a.seg_first, ll, mp, Pp, FP, u, inv, res);
+        if (k > k0) {                       // element of step k-1: its gain, and THIS step's update
+            T E[MAT];
+            smth_gain<T, D>(FP, Pp, E);
+            smth_extend_u(sagg, E, u, inv, res);
+        }
+    } else {
+        MeanCov<T, D> prev = s;
+        kf_step(s, F, Q, y, h, a.R, (k == 0) && a.seg_first, ll, mp, Pp, FP);
+        if (SMOOTH && k > k0) {                 // element of step k-1 from this step's predict
+            SmthElem<T, D> e, r;
+            smth_element(prev, mp, Pp, FP, e);
+            smth_combine(sagg, e, r);
+            sagg = r;
+        }
     }
 }
 
@@ -840,6 +853,28 @@ __device__ __forceinline__ void filter_tail_apply(bool have_next, const T* F, co
     sagg = r;
 }
 
+// the same in innovation form: the step after the chunk contributes its predict AND its update (y of that step)
+template <typename T, int D>
+__device__ __forceinline__ void filter_tail_apply_u(bool have_next, const T* F, const T* Qf, T yn, const T* h, T R,
+                                                    const MeanCov<T, D>& s, SmthElem<T, D>& sagg) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM;
+    if (!have_next) { smth_extend_last_u(sagg); return; }
+    T Q[SYM];
+    sym_from_full<T, D>(Qf, Q);
+    T mp[D], Pp[SYM], FP[MAT], u[D], E[MAT];
+    mat_vec<T, D>(F, s.m, mp);
+    predict_cov<T, D>(F, s.P, Q, FP, Pp);
+    sym_vec<T, D>(Pp, h, u);
+    T S = R, mu = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; mu += h[i] * mp[i]; }
+    const bool obs = !is_nan(yn);
+    const T inv = obs ? recip(S) : T(0);
+    const T res = obs ? yn - mu : T(0);
+    smth_gain<T, D>(FP, Pp, E);
+    smth_extend_u(sagg, E, u, inv, res);
+}
+
 template <typename T, int D>
 __device__ __forceinline__ void filter_apply_tail(const ScanArgs<T>& a, long k1, const MeanCov<T, D>& s,
                                                   SmthElem<T, D>& sagg) {
@@ -848,7 +883,7 @@ __device__ __forceinline__ void filter_apply_tail(const ScanArgs<T>& a, long k1,
     filter_tail_apply<T, D>(have_next, F, Qf, s, sagg);
 }
 
-template <typename T, int D, bool SMOOTH>
+template <typename T, int D, bool SMOOTH, bool DFORM = false>
 __device__ __forceinline__ void lane_filter_apply_direct(const ScanArgs<T>& a, long k0, long k1, const T* h,
                                                          MeanCov<T, D>& s, LogLik& ll, SmthElem<T, D>& sagg) {
     constexpr int MAT = D * D;
@@ -868,19 +903,26 @@ __device__ __forceinline__ void lane_filter_apply_direct(const ScanArgs<T>& a, l
             load_rec<T, MAT>(a.Qs + (k + 1) * MAT, Qn);
             yn = a.ys[k + 1];
         }
-        filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, y, h, s, ll, sagg);
+        filter_apply_step<T, D, SMOOTH, LogLik, DFORM>(a, k, k0, F, Qf, y, h, s, ll, sagg);
         store_rec<T, D>(a.fms + k * D, s.m);
         T Pf[MAT];
         full_from_sym<T, D>(s.P, Pf);
         store_rec<T, MAT>(a.fPs + k * MAT, Pf);
     }
-    if (SMOOTH) filter_apply_tail<T, D>(a, k1, s, sagg);
+    if constexpr (SMOOTH && DFORM) {
+        T Fh[MAT], Qh[MAT];
+        const bool have_next = filter_tail_load<T, D>(a, k1, Fh, Qh);
+        const T yh = (k1 < a.N) ? a.ys[k1] : T(0);
+        filter_tail_apply_u<T, D>(have_next, Fh, Qh, yh, h, a.R, s, sagg);
+    } else if (SMOOTH) {
+        filter_apply_tail<T, D>(a, k1, s, sagg);
+    }
 }
 
 // Staged lane-serial Kalman pass.  prefetch() issues the first sub-tile's global loads (and the
 // halo step's) into registers; it is called BEFORE the workgroup folds the spine so that the
 // memory latency hides behind the fold's arithmetic.  run() streams the wave's span.
-template <typename T, int D, bool SMOOTH, int G, bool NT>
+template <typename T, int D, bool SMOOTH, int G, bool NT, bool DFORM = false>
 struct FilterApplyStaged {
     using CFG = StageCfg<T, D, G>;
     using GF = typename CFG::GF;
@@ -889,6 +931,7 @@ struct FilterApplyStaged {
     V4 rF[GF::NV], rQ[GF::NV];
     T yn[G];
     T Fh[MAT], Qh[MAT];
+    T yh;                               // DFORM: the observation of the step after the chunk
     bool have_next;
 
     __device__ __forceinline__ void prefetch(const ScanArgs<T>& a, long wbase) {
@@ -900,7 +943,12 @@ struct FilterApplyStaged {
         // the halo step of lane l is the first step of lane l+1: after the first sub-tile is in LDS
         // it is fetched from there (run()); only the wave's last lane reads global memory
         have_next = false;
-        if (SMOOTH && lane == kWave - 1) have_next = filter_tail_load<T, D>(a, wbase + (long)kWave * a.Lc, Fh, Qh);
+        yh = T(0);
+        if (SMOOTH && lane == kWave - 1) {
+            const long kn = wbase + (long)kWave * a.Lc;
+            have_next = filter_tail_load<T, D>(a, kn, Fh, Qh);
+            if (DFORM && kn < a.N) yh = a.ys[kn];
+        }
     }
 
     __device__ __forceinline__ void run(const ScanArgs<T>& a, long wbase, char* lds, const T* h, MeanCov<T, D>& s,
@@ -940,6 +988,10 @@ struct FilterApplyStaged {
             for (int i = 0; i < G; ++i) yv[i] = yn[i];
             if (kPrefetch && sb + 1 < S) issue(sb + 1);
             wave_lds_sync();
+            if (SMOOTH && DFORM && sb == 0) {       // (every lane takes part in the shuffle; the last lane keeps what it loaded)
+                const T yq = wshfl_down(yv[0], 1);
+                if (lane < kWave - 1) yh = yq;
+            }
             if (SMOOTH && sb == 0 && lane < kWave - 1) {
                 // record 0 of the next lane = this lane's halo step
                 load_rec<T, MAT>(reinterpret_cast<const T*>(lF + (lane + 1) * GF::STRIDE), Fh);
@@ -952,7 +1004,7 @@ struct FilterApplyStaged {
                 T F[MAT], Qf[MAT];
                 stage_get<GF, T, MAT>(lF, i, F);
                 stage_get<GF, T, MAT>(lQ, i, Qf);
-                filter_apply_step<T, D, SMOOTH>(a, k, k0, F, Qf, yv[i], h, s, ll, sagg);
+                filter_apply_step<T, D, SMOOTH, LogLik, DFORM>(a, k, k0, F, Qf, yv[i], h, s, ll, sagg);
                 T Pf[MAT];
                 full_from_sym<T, D>(s.P, Pf);
                 if constexpr (CFG::stage_m) stage_put<GM, T, D, GF::STRIDE>(lQ, i, s.m);    // Q_k is dead too: m_k goes where Q_0..Q_k were
@@ -963,7 +1015,8 @@ struct FilterApplyStaged {
             if constexpr (CFG::stage_m) stage_drain<GM, NT, GF::STRIDE>(gM + (long)sb * GM::SEG, pitchM, lQ);
             stage_drain<GF, NT>(gP + (long)sb * GF::SEG, pitchF, lF);
         }
-        if (SMOOTH) filter_tail_apply<T, D>(have_next, Fh, Qh, s, sagg);
+        if constexpr (SMOOTH && DFORM) filter_tail_apply_u<T, D>(have_next, Fh, Qh, yh, h, a.R, s, sagg);
+        else if (SMOOTH) filter_tail_apply<T, D>(have_next, Fh, Qh, s, sagg);
     }
 };
 
@@ -1185,8 +1238,9 @@ struct FilterApplyDma {
 };
 #endif      // PGPS_NARROW
 
-template <typename T, int D, bool SMOOTH, int G, bool NT, bool DMA = false>
+template <typename T, int D, bool SMOOTH, int G, bool NT, bool DMA = false, bool DFORM = false>
 __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
+    static_assert(!(DMA && DFORM), "the LDS-DMA variant keeps the reference's element form");
     constexpr int MAT = D * D, NF = Dim<D>::NFILT;
     using FE = FiltElem<T, D>;
     using SE = SmthElem<T, D>;
@@ -1220,7 +1274,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     if (blockIdx.x > 0) fold_spine_partial<FE>(a.spine, 0, (int)blockIdx.x, left_part);
     ws_load(a.lpre, a.nlanes, gt, lp);
     bool staged = false;
-    FilterApplyStaged<T, D, SMOOTH, CFG::GG, NT> st;
+    FilterApplyStaged<T, D, SMOOTH, CFG::GG, NT, DFORM> st;
 #if defined(PGPS_NARROW)
     DM dm;
 #endif
@@ -1302,7 +1356,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     if constexpr (CFG::on && !DMA) {
         if (staged) st.run(a, wbase, stage[wave], h, s, ll, sagg);
     }
-    if (!staged) lane_filter_apply_direct<T, D, SMOOTH>(a, k0, k1, h, s, ll, sagg);
+    if (!staged) lane_filter_apply_direct<T, D, SMOOTH, DFORM>(a, k0, k1, h, s, ll, sagg);
     PGPS_STAMP(1, 3);
 
     // log-likelihood partial of this workgroup
@@ -1836,6 +1890,17 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
     }
     PGPS_STAMP(2, 1);
     smth_apply(ls, s);
+    if (a.dform && k0 < a.N && k1 < a.N) {
+        // totals in innovation form: s is (sm - m, sP - P) of the step after the chunk -- add that step's filtered moments
+        T mh[D], Ph[MAT], Ps[SYM];
+        load_rec<T, D>(a.fms + k1 * D, mh);
+        load_rec<T, MAT>(a.fPs + k1 * MAT, Ph);
+        sym_from_full<T, D>(Ph, Ps);
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] += mh[i];
+#pragma unroll
+        for (int i = 0; i < SYM; ++i) s.P[i] += Ps[i];
+    }
     PGPS_STAMP(2, 2);
 
     if constexpr (CFG::on) {

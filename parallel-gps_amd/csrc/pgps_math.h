@@ -640,4 +640,93 @@ PGPS_HD void rts_step(const MeanCov<T, D>& f, const T* mp, const T* Pp, const T*
     mat_mul_t_sym<T, D>(X, E, f.P, s.P);
 }
 
+// ------------------------------------------------------------------------------------
+// The smoothing element in INNOVATION FORM.  With one scalar observation per step the filter's update is rank one:
+// m_{k+1} - mp = u res / S,  P_{k+1} - Pp = -u u^T / S  (u = Pp H^T).  Write the smoothed moments relative to the filtered
+// ones, d_k = sm_k - m_k,  D_k = sP_k - P_k; the RTS recursion (parallel.py:159-166 + 176-184) becomes
+//     d_k = E_k d_{k+1} + (E_k u) res / S,      D_k = E_k D_{k+1} E_k^T - (E_k u)(E_k u)^T / S
+// i.e. in these coordinates step k's element is (E_k, v res / S, -v v^T / S) with v = E_k u: its L is RANK ONE.  The
+// composition law is the smoothing operator's own (it is the same affine map, read in shifted coordinates), so scans and
+// trees do not change; what changes is the lane-serial fold: extending a total by a raw element costs one matrix product
+// (E_a E), two matrix-vector products and a rank-one update instead of three matrix products, and the element needs no
+// L = P - E (F P) product at all -- the smoother's counterpart of filt_extend's Sherman-Morrison step.  Per step at d = 6:
+// 1080 -> ~530 multiply-adds on the smoothing side.  The series' last element maps everything to (0, 0): E = 0, g = 0, L = 0.
+// Whoever applies a total in this form gets (d, D) and adds the filtered moments of that step (k_smoother_apply, `dform`).
+// ------------------------------------------------------------------------------------
+// kf_step that also hands out the update it made: u = Pp H^T, inv = 1 / S (0 for a missing observation), res = y - H mp
+template <typename T, int D, typename LL>
+PGPS_HD void kf_step_u(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, const T* h, T R, bool first, LL& ll, T* mp,
+                       T* Pp, T* FP, T* u, T& inv_o, T& res_o) {
+    mat_vec<T, D>(F, s.m, mp);
+    predict_cov<T, D>(F, s.P, Q, FP, Pp);
+    const bool obs = !is_nan(y);
+    sym_vec<T, D>(Pp, h, u);
+    T S = R, mu = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; mu += h[i] * mp[i]; }
+    if (obs) ll.add(ll_diff(y, mu), ll_wide(S));
+    inv_o = T(0);
+    res_o = T(0);
+    if (first) {
+        // update straight from the prior (s holds m0 = 0, P0); no element is built from this step's predict
+        T u0[D];
+        sym_vec<T, D>(s.P, h, u0);
+        T S0 = R, mu0 = T(0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { S0 += h[i] * u0[i]; mu0 += h[i] * s.m[i]; }
+        if (obs) {
+            const T inv = recip(S0);
+            const T res = y - mu0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) s.m[i] += u0[i] * (res * inv);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] -= u0[i] * u0[j] * inv;
+        }
+        return;
+    }
+    if (obs) {
+        const T inv = recip(S);
+        const T res = y - mu;
+        inv_o = inv;
+        res_o = res;
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] = mp[i] + u[i] * (res * inv);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] = Pp[symi<D>(i, j)] - u[i] * u[j] * inv;
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; ++i) s.m[i] = mp[i];
+#pragma unroll
+        for (int i = 0; i < Dim<D>::SYM; ++i) s.P[i] = Pp[i];
+    }
+}
+
+// a <- a (x) element, the element of a step in innovation form: gain E, and the NEXT step's update (u, inv = 1/S or 0, res)
+template <typename T, int D>
+PGPS_HD void smth_extend_u(SmthElem<T, D>& a, const T* E, const T* u, T inv, T res) {
+    T v[D], w[D], EE[D * D];
+    mat_vec<T, D>(E, u, v);
+    mat_vec<T, D>(a.E, v, w);               // (with the total's gain BEFORE this step)
+    const T c = res * inv;
+#pragma unroll
+    for (int i = 0; i < D; ++i) a.g[i] += w[i] * c;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) a.L[symi<D>(i, j)] -= w[i] * w[j] * inv;
+    mat_mul<T, D>(a.E, E, EE);
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) a.E[i] = EE[i];
+}
+// ... and the series' last element: everything after it is forgotten, nothing is added
+template <typename T, int D>
+PGPS_HD void smth_extend_last_u(SmthElem<T, D>& a) {
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) a.E[i] = T(0);
+}
+
 }  // namespace pgps

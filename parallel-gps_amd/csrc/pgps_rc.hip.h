@@ -820,9 +820,16 @@ __global__ __launch_bounds__(64, PGPS_RC_WAVES_R) void rc_reduce1(const RcArgsT<
 // ====================================================================================================
 // (FAST / EDGE as in reduce1_body; EDGE here also runs the series' first update from the prior itself and, in the step
 // after the last chain of the series, takes Q = I for the F = 0 the cut descriptor delivers)
-template <typename Real, int D, bool SMOOTH, bool FAST, bool IMPQS, bool STORE, bool EDGE = false>
+// DFORM (whole-series filter + smoother with every moment stored): the chain's smoothing TOTAL is accumulated in innovation form
+// (pgps_math.h, smth_extend_u): folding step k-1's element into it takes E u (u = Pp H^T, the direction of step k's rank-one
+// update), its image under the total's gain, and a rank-one update of L -- two matrix-vector products instead of the two
+// matrix products E_a L and (E_a L) E_a^T and the symmetrisation behind them.  The per-step elements (E, g, L) are stored as
+// before (rc_smooth1 applies them unchanged); rc_smooth1 enters a chain with the total's (g, L) PLUS the filtered moments of
+// the chain's successor step (RcArgs::dform).  Segments keep the reference's form: their totals travel between ranks.
+template <typename Real, int D, bool SMOOTH, bool FAST, bool IMPQS, bool STORE, bool EDGE = false, bool DFORM = false>
 __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch, char* wslots, int lane, int row) {
     static_assert(FAST || !EDGE, "EDGE is a flavour of the FAST body");
+    static_assert(!DFORM || (SMOOTH && STORE), "innovation-form totals: filter + smoother with the filtered moments stored");
     constexpr int dd = D * D;
     const long kw = (long)blockIdx.x * 4 * a.Lw;
     const long c = (long)blockIdx.x * 4 + row;
@@ -875,6 +882,7 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
             if (!impq) io.template mat_slow<false>(reinterpret_cast<const Real*>(bQ), real, Real(1.0), Q);
             y = __builtin_nan("");
             if (s < a.Lw && k < k1) y = a.ys[k];
+            if (DFORM && s == a.Lw && k < a.N) y = a.ys[k];     // the step after the chunk lends its update to the last element
         }
     };
     // FAST: whole records as 16-byte pieces through LDS (Io, WIDE path), requested a whole step ahead; the results
@@ -967,6 +975,14 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
         const Real yk = y;
         if constexpr (!FAST && !LAST && EARLY) load(s + 1);
         symmetrise<D>(Pp, patch, lane);
+        // this step's rank-one update (direction, 1 / S, residual): the filter below and, DFORM, the element of step k-1
+        const bool obs = !(yk != yk);
+        Real u = Real(0.0), S = Real(1.0), mu = Real(0.0);
+        if constexpr (!LAST || DFORM) {
+            u = dot_h<D>(Pp, h);
+            S = rowsum<D>(hl * u, a.R);
+            mu = rowsum<D>(hl * mp, Real(0.0));
+        }
         if constexpr (SMOOTH && !FIRST) {
             // element of step k-1: W = Pp^-1 F P = E^T (i.e. E in row layout), g = m - E mp, L = P - E F P
             Real M[D], W[D];
@@ -989,10 +1005,18 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
             // total <- total (x) element:  E = Ea En, g = Ea gn + ga, L = Ea Ln Ea^T + La
             Real E2[D];
             zero<D>(E2); mm<D>(E2, Ec, En);
-            zero<D>(T); mm<D>(T, Ec, Ln);
+            if constexpr (!DFORM) { zero<D>(T); mm<D>(T, Ec, Ln); }
             Real Er[D];                       // the total's E in row layout, made where it is used
             transpose<D>(Ec, Er, patch, lane);
-            if (FAST) {
+            if constexpr (DFORM) {
+                const Real dinv = obs ? Real(1.0) / S : Real(0.0);
+                const Real dres = obs ? yk - mu : Real(0.0);
+                const Real v = mvr<D>(W, u, Real(0.0));         // (E u)_lane: W is E in row layout
+                const Real w = mvr<D>(Er, v, Real(0.0));        // its image under the total's gain
+                g = g + w * (dres * dinv);
+                rank1<D>(L, w, -w * dinv);
+                copy<D>(Ec, E2);
+            } else if (FAST) {
                 g = mvr<D>(Er, gn, g);
                 mm<D>(L, T, Er);
                 symmetrise<D>(L, patch, lane);
@@ -1012,9 +1036,6 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
         }
         if constexpr (!LAST) {
             const bool upd = FAST || k < k1;
-            const bool obs = !(yk != yk);
-            Real u = dot_h<D>(Pp, h);
-            Real S = rowsum<D>(hl * u, a.R), mu = rowsum<D>(hl * mp, Real(0.0));
             if (obs) ll.add((double)yk - (double)mu, (double)S);
             Real mb = mp;
             if ((!FAST || EDGE) && blockIdx.x == 0 && s == 0) {
@@ -1068,7 +1089,7 @@ __device__ __forceinline__ void apply1_body(const RcArgsT<Real>& a, Real* patch,
 }
 
 // STORE: the filtered moments are written (pkf / pkfs); not for the log-likelihood-only and projected-posterior calls
-template <typename Real, int D, bool SMOOTH, bool IMPQS, bool STORE>
+template <typename Real, int D, bool SMOOTH, bool IMPQS, bool STORE, bool DFORM = false>
 __global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_apply1(const RcArgsT<Real> a0) {
     static_assert(SMOOTH || !IMPQS, "the implicit-noise instantiation is the smoothing one");
     __shared__ Real tl[4 * kPatch];
@@ -1078,7 +1099,7 @@ __global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_apply1(const RcArgsT<Rea
     Real* patch = patch_init(tl, row);
     const RcArgsT<Real> a = model_view(a0);
 #ifdef PGPS_RC_FAST_ONLY
-    apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, wslots, lane, row);
+    apply1_body<Real, D, SMOOTH, true, IMPQS, STORE, false, DFORM>(a, patch, wslots, lane, row);
 #else
     // EDGE: whole chains; the workgroup that ends the series only when nothing follows it (a segment that is not the last of
     // its series takes the first step of the next rank from the halo record: general body)
@@ -1086,12 +1107,12 @@ __global__ __launch_bounds__(64, PGPS_RC_WAVES) void rc_apply1(const RcArgsT<Rea
     // (the filter + smoothing-element kernels only: the filter-only ones fit two waves per SIMD and a third body would cost
     // them that)
     const bool edge_ok = SMOOTH && PGPS_RC_EDGE_FAST != 0 && end4 <= a.N && !(end4 == a.N && (a.halo_F != nullptr || !a.seg_last));
-    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE>(a, patch, wslots, lane, row);
+    if (blockIdx.x >= 1 && blockIdx.x < a.wfast) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE, false, DFORM>(a, patch, wslots, lane, row);
 #ifdef PGPS_RC_SKIP_EDGE               // (timing experiment: what the kernel costs without its edge waves; results are wrong)
     else return;
 #else
-    else if (edge_ok) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE, SMOOTH>(a, patch, wslots, lane, row);
-    else apply1_body<Real, D, SMOOTH, false, IMPQS, STORE>(a, patch, wslots, lane, row);
+    else if (edge_ok) apply1_body<Real, D, SMOOTH, true, IMPQS, STORE, SMOOTH, DFORM>(a, patch, wslots, lane, row);
+    else apply1_body<Real, D, SMOOTH, false, IMPQS, STORE, false, DFORM>(a, patch, wslots, lane, row);
 #endif
 #endif
 }
@@ -1215,6 +1236,14 @@ __device__ __forceinline__ void smooth1_body(const RcArgsT<Real>& a, Real* patch
         sm = (nx && lv) ? rec[2 * dd + lane] : Real(0.0);
 #pragma unroll
         for (int i = 0; i < D; ++i) sP[i] = (nx && lv) ? rec[dd + i * D + lane] : Real(0.0);
+        if (a.dform && inner && lv) {
+            // totals in innovation form (rc_apply1, DFORM): (g, L) of the suffix are sm - m, sP - P at the next chain's first
+            // step -- add that step's filtered moments
+            const long kn = (c + 1) * a.Lw;
+            sm += a.fms[kn * D + lane];
+#pragma unroll
+            for (int i = 0; i < D; ++i) sP[i] += Real(0.5) * (a.fPs[kn * dd + i * D + lane] + a.fPs[kn * dd + lane * D + i]);
+        }
     }
     Real Ec[D], Er[D], L[D], g = Real(0.0);
     zero<D>(Ec); zero<D>(Er); zero<D>(L);
@@ -1840,7 +1869,8 @@ int launch_rc_level1(pgps_ctx* ctx, const RcArgsT<Real>& a, int phase) {
                 if (st) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, true, true>, g1, blk, 0u, a);
                 else timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, true, false>, g1, blk, 0u, a);
             } else {
-                if (st) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, false, true>, g1, blk, 0u, a);
+                if (st && a.dform) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, false, true, true>, g1, blk, 0u, a);
+                else if (st) timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, false, true>, g1, blk, 0u, a);
                 else timed_launch(ctx, PGPS_K_FILTER_APPLY, rc_apply1<Real, D, true, false, false>, g1, blk, 0u, a);
             }
             break;

@@ -2522,6 +2522,12 @@ static int scan_rc_entry(pgps_ctx* ctx, ScanArgs<Real> sa, int d, Mode mode, int
     a.P0 = sa.P0; a.H = sa.H; a.R = sa.R; a.Fs = sa.Fs; a.Qs = sa.Qs; a.ys = sa.ys;
     a.fms = sa.fms; a.fPs = sa.fPs; a.sms = sa.sms; a.sPs = sa.sPs;
     a.store_f = store_f; a.qslot = qslot; a.pmean = pmean; a.pvar = pvar;
+    // whole-series filter + smoother with every moment stored: the chains' smoothing totals in innovation form (pgps_rc.hip.h,
+    // apply1_body DFORM); -DPGPS_RC_DFORM=0 keeps the reference's form everywhere (A/B)
+#ifndef PGPS_RC_DFORM
+#define PGPS_RC_DFORM 1
+#endif
+    a.dform = (PGPS_RC_DFORM != 0 && mode == MODE_PKFS && !seg && store_f && !quad && !qslot && batch <= 1 && sa.Qs != nullptr) ? 1 : 0;
     a.seg_first = 1; a.seg_last = 1;
     a.implicit_q = (sa.Qs == nullptr) ? 1 : 0;
     // (Qs may be absent where nothing per step is written: the log-likelihood call and the projected smoother)
