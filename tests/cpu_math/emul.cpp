@@ -24,7 +24,9 @@ static void store_sym(const T* sym, T* full) {
         for (int j = 0; j < D; ++j) full[i * D + j] = sym[symi<D>(i, j)];
 }
 
-template <typename T, int D>
+// DFORM: the smoothing totals in innovation form (pgps_math.h kf_step_u / smth_extend_u), as the whole-series pkfs kernels of
+// the lane-chunk family keep them: the carry of a chunk is (sm - m, sP - P) and the filtered moments are added back
+template <typename T, int D, bool DFORM = false>
 static int run(long N, int Lc, int W, const T* P0f, const T* Fs, const T* Qs, const T* h, T R,
                const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll_out) {
     constexpr int MAT = D * D, SYM = Dim<D>::SYM;
@@ -78,6 +80,7 @@ static int run(long N, int Lc, int W, const T* P0f, const T* Fs, const T* Qs, co
         const long k0 = t * Lc, k1 = std::min<long>(N, (t + 1) * Lc);
         for (long k = k0; k <= k1; ++k) {
             if (k == N) {               // element of the last step of the series
+                if (DFORM) { smth_extend_last_u(sagg[t]); break; }
                 SmthElem<T, D> e, tmp;
                 smth_last(prev, e);
                 smth_combine(sagg[t], e, tmp);
@@ -88,12 +91,23 @@ static int run(long N, int Lc, int W, const T* P0f, const T* Fs, const T* Qs, co
             load_sym<T, D>(Qs + k * MAT, Q);
             LogLik dummy;
             MeanCov<T, D> cur = prev;
+            if (DFORM) {
+                // (the halo step k == k1 lends its TRUE observation to the last element of the chunk)
+                T u[D], inv, res;
+                kf_step_u(cur, Fs + k * MAT, Q, ys[k], h, R, k == 0, k < k1 ? ll : dummy, mp, Pp, FP, u, inv, res);
+                if (k > k0) {
+                    T E[MAT];
+                    smth_gain<T, D>(FP, Pp, E);
+                    smth_extend_u(sagg[t], E, u, inv, res);
+                }
+            } else {
             kf_step(cur, Fs + k * MAT, Q, k < k1 ? ys[k] : T(0), h, R, k == 0, k < k1 ? ll : dummy, mp, Pp, FP);
             if (k > k0) {               // element of step k-1 from this step's predict
                 SmthElem<T, D> e, tmp;
                 smth_element(prev, mp, Pp, FP, e);
                 smth_combine(sagg[t], e, tmp);
                 sagg[t] = tmp;
+            }
             }
             if (k == k1) break;         // halo step: only its predict was needed
             for (int i = 0; i < D; ++i) fms[k * D + i] = cur.m[i];
@@ -133,6 +147,12 @@ static int run(long N, int Lc, int W, const T* P0f, const T* Fs, const T* Qs, co
         for (int i = 0; i < SYM; ++i) s.P[i] = T(0);
         smth_apply(sexcl[t], s);        // state at the first step after this chunk
         const long k0 = t * Lc, k1 = std::min<long>(N, (t + 1) * Lc);
+        if (DFORM && k1 < N) {          // innovation form: (sm - m, sP - P) of step k1 -- add its filtered moments
+            T Pn[SYM];
+            load_sym<T, D>(fPs + k1 * MAT, Pn);
+            for (int i = 0; i < D; ++i) s.m[i] += fms[k1 * D + i];
+            for (int i = 0; i < SYM; ++i) s.P[i] += Pn[i];
+        }
         for (long k = k1 - 1; k >= k0; --k) {
             MeanCov<T, D> f;
             for (int i = 0; i < D; ++i) f.m[i] = fms[k * D + i];
@@ -172,6 +192,27 @@ extern "C" int emul_pkfs_f32(int d, long N, int Lc, int W, const float* P0, cons
                              const float* h, float R, const float* ys, float* fms, float* fPs,
                              float* sms, float* sPs, double* ll) {
     return dispatch<float>(d, N, Lc, W, P0, Fs, Qs, h, R, ys, fms, fPs, sms, sPs, ll);
+}
+// the same scan with the smoothing totals in innovation form
+#undef CASE
+#define CASE(D_) case D_: return run<T, D_, true>(N, Lc, W, P0, Fs, Qs, h, R, ys, fms, fPs, sms, sPs, ll);
+template <typename T>
+static int dispatch_dform(int d, long N, int Lc, int W, const T* P0, const T* Fs, const T* Qs, const T* h, T R,
+                          const T* ys, T* fms, T* fPs, T* sms, T* sPs, double* ll) {
+    switch (d) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
+        default: return -1;
+    }
+}
+extern "C" int emul_pkfs_dform_f64(int d, long N, int Lc, int W, const double* P0, const double* Fs, const double* Qs,
+                                   const double* h, double R, const double* ys, double* fms, double* fPs,
+                                   double* sms, double* sPs, double* ll) {
+    return dispatch_dform<double>(d, N, Lc, W, P0, Fs, Qs, h, R, ys, fms, fPs, sms, sPs, ll);
+}
+extern "C" int emul_pkfs_dform_f32(int d, long N, int Lc, int W, const float* P0, const float* Fs, const float* Qs,
+                                   const float* h, float R, const float* ys, float* fms, float* fPs,
+                                   float* sms, float* sPs, double* ll) {
+    return dispatch_dform<float>(d, N, Lc, W, P0, Fs, Qs, h, R, ys, fms, fPs, sms, sPs, ll);
 }
 
 // ---------------------------------------------------------------------------------------------
