@@ -77,6 +77,12 @@ int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
  * pgps_status set and undefined outputs.  mode -1 = automatic (from 2^18 steps), 0 = never (three launches),
  * 1 = wherever the series fits, 2 = as 1 with in-kernel phase stamps kept for pgps_resident_stamps (diagnostics). */
 int pgps_set_resident(pgps_ctx* ctx, int mode);
+/* The forgetting shortcut of the lane-chunk and resident kernels (csrc/pgps_kernels.hip.h): a workgroup whose neighbour's total
+ * has |A| (smoother: |E|) <= 2^-120 (fp64) / 2^-60 (fp32) -- a filter that has forgotten what came before those thousands of
+ * steps -- takes the neighbour's (b, C) ((g, L)) as its carry instead of folding every total on that side: same bits, ten
+ * combine levels less.  Decided from the data per workgroup; 1 (default) = where a workgroup spans >= 2048 steps, 0 = never
+ * (every carry by the general fold: what the tests compare it with). */
+int pgps_set_shortcut(pgps_ctx* ctx, int on);
 /* Diagnostics: cycle stamps of the last resident launch made under mode 2: out = (n_blocks, 16) long long (host), at most
  * max_blocks rows copied; out may be NULL to ask for n_blocks only. */
 int pgps_resident_stamps(pgps_ctx* ctx, long long* out, int max_blocks, int* n_blocks);

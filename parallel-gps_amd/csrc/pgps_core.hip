@@ -173,6 +173,12 @@ extern "C" int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window) {
     return PGPS_OK;
 }
 
+extern "C" int pgps_set_shortcut(pgps_ctx* ctx, int on) {
+    if (!ctx || on < 0 || on > 1) return PGPS_E_INVALID;
+    ctx->shortcut = on;
+    return PGPS_OK;
+}
+
 extern "C" int pgps_set_resident(pgps_ctx* ctx, int mode) {
     if (!ctx || mode < -1 || mode > 2) return PGPS_E_INVALID;
     ctx->resident = mode;

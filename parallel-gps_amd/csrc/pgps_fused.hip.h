@@ -150,7 +150,9 @@ __device__ __forceinline__ void gp_apply_body(const GpArgs<T>& g, GpLds<T, D>& s
     const bool staged = store && (wbase + (long)kWave * a.Lc <= a.N) && (a.Lc % G == 0);
 
     FE left_part, lp;
-    if (blockIdx.x > 0) fold_spine_partial<FE>(a.spine, 0, (int)blockIdx.x, left_part);
+    MC s_short;
+    const bool shortcut = a.shortcut != 0 && blockIdx.x > 0 && carry_shortcut_filter<T, D>(a.spine, (int)blockIdx.x - 1, s_short);
+    if (blockIdx.x > 0 && !shortcut) fold_spine_partial<FE>(a.spine, 0, (int)blockIdx.x, left_part);
     ws_load(a.lpre, a.nlanes, gt, lp);
     T tprev = T(0), tn = T(0), yn = T(0);
     if (k0 < k1) {
@@ -158,7 +160,9 @@ __device__ __forceinline__ void gp_apply_body(const GpArgs<T>& g, GpLds<T, D>& s
         tn = g.m.ts[k0];
         yn = a.ys[k0];
     }
-    if (blockIdx.x > 0) {
+    if (shortcut) {
+        s = s_short;
+    } else if (blockIdx.x > 0) {
         FE left;
         block_reduce_ordered(left_part, left, lds);
         filt_apply(s, left);
@@ -312,7 +316,10 @@ __device__ __forceinline__ void gp_smooth_body(const GpArgs<T>& g, GpLds<T, D>& 
     const int S = a.Lc / G;
 
     SE right_part, ls;
-    if ((int)blockIdx.x + 1 < a.nblocks) fold_spine_partial<SE>(a.sspine, (int)blockIdx.x + 1, a.nblocks, right_part);
+    MC s_short;
+    const bool has_right = (int)blockIdx.x + 1 < a.nblocks;
+    const bool shortcut = a.shortcut != 0 && has_right && carry_shortcut_smoother<T, D>(a.sspine, (int)blockIdx.x + 1, s_short);
+    if (has_right && !shortcut) fold_spine_partial<SE>(a.sspine, (int)blockIdx.x + 1, a.nblocks, right_part);
     ws_load(a.lsuf, a.nlanes, gt, ls);
     V4 rP[GF::NV], rM[GM::NV];
     const char* gP = reinterpret_cast<const char*>(a.fPs + wbase * MAT);
@@ -331,7 +338,9 @@ __device__ __forceinline__ void gp_smooth_body(const GpArgs<T>& g, GpLds<T, D>& 
     for (int i = 0; i < D; ++i) s.m[i] = T(0);
 #pragma unroll
     for (int i = 0; i < SYM; ++i) s.P[i] = T(0);
-    if ((int)blockIdx.x + 1 < a.nblocks) {
+    if (shortcut) {
+        s = s_short;
+    } else if ((int)blockIdx.x + 1 < a.nblocks) {
         SE right;
         block_reduce_ordered(right_part, right, lds);
         smth_apply(right, s);

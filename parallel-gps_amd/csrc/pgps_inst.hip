@@ -89,6 +89,7 @@ static int launch_scan_g(pgps_ctx* ctx, ScanArgs<T> a, Mode mode) {
 #endif
     a.nlanes = (long)a.nblocks * kBlock;
     a.nt = NT ? 1 : 0;
+    a.shortcut = (ctx->shortcut != 0 && (long)kBlock * a.Lc >= 2048) ? 1 : 0;
     int rc = carve_workspace<T, D>(ctx, a);
     if (rc) return rc;
     const dim3 grid(a.nblocks), block(kBlock);
@@ -295,6 +296,7 @@ int launch_gp(pgps_ctx* ctx, GpArgs<T> g, int want_filtered, int want_smoothed) 
         a.nlanes = (long)a.nblocks * kBlock;
         a.seg_first = 1;
         a.seg_last = 1;
+        a.shortcut = (ctx->shortcut != 0 && (long)kBlock * a.Lc >= 2048) ? 1 : 0;
         int rc = carve_workspace<T, D>(ctx, a);
         if (rc) return rc;
         if (one) {

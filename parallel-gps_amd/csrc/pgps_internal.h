@@ -30,6 +30,7 @@ struct pgps_ctx {
     long grad_pack = -1;                // gradient at d <= 2: one direction per model up to this many steps (-1 = automatic, 0 = never)
     int rc_scan = -1;                   // scans of the chain totals (row- / quad-cooperative families): -1 = auto, 0 = one launch per Kogge-Stone level, 1 = blocked (pgps_set_rc_scan)
     int dma = -1;                       // LDS-DMA ring in the Kalman pass (d = 2 fp64, 128-lane build): -1 = auto, 0 = off, 1 = on
+    int shortcut = 1;                   // forgetting shortcut for the carry across workgroups (pgps_set_shortcut): 1 = where it applies, 0 = never
     int resident = -1;                  // one resident launch for filter + smoother (pgps_resident.hip.h): -1 = auto, 0 = off, 1 = on where it fits, 2 = on + phase stamps
     unsigned res_epoch = 0;             // launches of the resident kernel so far: picks the barrier's counter set
     DevBuf res_stamps;                  // diagnostics: (workgroups, 16) cycle stamps of the last resident launch
@@ -160,6 +161,8 @@ struct ScanArgs {
     T* incl;                // (nblocks, d + d(d+1)/2) inclusive (m, P) of the window-closing tiles
     int win;                // look-back window (tiles); <= kBlock
     long long* stamps;      // diagnostic build only (-DPGPS_STAMPS): (3 kernels, nblocks, 8) s_memtime stamps
+    int shortcut;           // try the forgetting shortcut for the carry across workgroups (pgps_kernels.hip.h): set by the launch code where a
+                            // workgroup spans >= 2048 steps and pgps_set_shortcut has not turned it off
     int dform;              // lsuf / sspine hold smoothing totals in innovation form (pgps_math.h smth_extend_u): the smoother adds the
                             // filtered moments of the step a total was applied at.  Whole-series pkfs of the lane-chunk kernels only
 };

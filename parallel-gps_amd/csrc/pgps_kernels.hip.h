@@ -657,6 +657,60 @@ __device__ __forceinline__ void fold_spine(const typename ElemTraits<E>::Scalar*
 }
 
 // ---------------------------------------------------------------------------------------------
+// The forgetting shortcut for the carry across workgroups.
+//
+// A workgroup's carry-in is the prefix T_0 (x) ... (x) T_{b-1} of the workgroup totals applied to the prior.  In ANY bracketing
+// the prefix's (b, C) are those of the LAST total whenever that total's A vanishes: out.b = A_2 w + b_2, out.C = A_2 N A_2^T
+// + C_2 (filtering operator, parallel.py:100-118).  A total over a few thousand steps of a filter that forgets has |A| far
+// below anything a sum with b or C can see (config c2: 0.917^4096 = 1e-154 from F alone), so the left neighbour's record IS
+// the carry and the fold of every total to the left -- ten combine levels: 10 % of a c2 pass, two thirds of the instructions of
+// a c3 Kalman-pass launch -- is skipped.  The smoother has the mirror image: a total whose E vanishes (a product of
+// thousands of smoother gains) hands the workgroup before it its own (g, L) (parallel.py:176-184).
+// Decided per workgroup FROM THE DATA: max |A| (|E|) <= 2^-120 in fp64, 2^-60 in fp32 -- thirty orders of magnitude below the
+// unit round-off, NaN fails the test -- the same in every lane (they read the same words); otherwise the general fold runs.
+// Where the shortcut applies both roads give the same bits.  Tried only where a workgroup spans >= 2048 steps
+// (ScanArgs::shortcut, set by the launch code; pgps_set_shortcut(ctx, 0) turns it off: the tests run both roads).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Forget;
+template <> struct Forget<double> { static constexpr double kA = 0x1p-120; };
+template <> struct Forget<float> { static constexpr float kA = 0x1p-60f; };
+
+template <typename T, int N>
+__device__ __forceinline__ bool forget_test(const T* __restrict__ rec) {
+    T x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = rec[i];
+    T amax = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) amax = fmax(amax, fabs(x[i]));
+    return __builtin_amdgcn_readfirstlane((int)(amax <= Forget<T>::kA)) != 0;
+}
+// filter: true and s = (b, C) of workgroup `nb`'s total when that total has forgotten what came before it
+template <typename T, int D>
+__device__ __forceinline__ bool carry_shortcut_filter(const T* __restrict__ spine, int nb, MeanCov<T, D>& s) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM, NF = Dim<D>::NFILT;
+    const T* rec = spine + (long)nb * NF;
+    if (!forget_test<T, MAT>(rec)) return false;
+#pragma unroll
+    for (int i = 0; i < D; ++i) s.m[i] = rec[MAT + i];
+#pragma unroll
+    for (int i = 0; i < SYM; ++i) s.P[i] = rec[MAT + D + i];
+    return true;
+}
+// smoother: true and s = (g, L) of workgroup `nb`'s total
+template <typename T, int D>
+__device__ __forceinline__ bool carry_shortcut_smoother(const T* __restrict__ sspine, int nb, MeanCov<T, D>& s) {
+    constexpr int MAT = D * D, SYM = Dim<D>::SYM, NS = Dim<D>::NSMTH;
+    const T* rec = sspine + (long)nb * NS;
+    if (!forget_test<T, MAT>(rec)) return false;
+#pragma unroll
+    for (int i = 0; i < D; ++i) s.m[i] = rec[MAT + i];
+#pragma unroll
+    for (int i = 0; i < SYM; ++i) s.P[i] = rec[MAT + D + i];
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // K-F1: filter reduce
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
@@ -1271,7 +1325,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     // small loads first (spine entries, this lane's local prefix), then the first sub-tile's
     // prefetch: loads retire in order, so the fold below only waits for what it needs
     FE left_part, lp;
-    if (blockIdx.x > 0) fold_spine_partial<FE>(a.spine, 0, (int)blockIdx.x, left_part);
+    MC s_short;
+    // (the shortcut's test waits for one record: tried only where the launch code expects it to hold, never with the LDS-DMA ring)
+    const bool shortcut = !DMA && a.shortcut != 0 && blockIdx.x > 0 && carry_shortcut_filter<T, D>(a.spine, (int)blockIdx.x - 1, s_short);
+    if (blockIdx.x > 0 && !shortcut) fold_spine_partial<FE>(a.spine, 0, (int)blockIdx.x, left_part);
     ws_load(a.lpre, a.nlanes, gt, lp);
     bool staged = false;
     FilterApplyStaged<T, D, SMOOTH, CFG::GG, NT, DFORM> st;
@@ -1336,7 +1393,9 @@ __global__ __launch_bounds__(kBlock) void k_filter_apply(const ScanArgs<T> a) {
     PGPS_STAMP(1, 6);
 #endif
     // ... pushed through the workgroups to the left, then through this lane's local prefix
-    if (blockIdx.x > 0) {
+    if (shortcut) {
+        s = s_short;
+    } else if (blockIdx.x > 0) {
         FE left;
         block_reduce_ordered(left_part, left, lds);
         filt_apply(s, left);
@@ -1847,7 +1906,10 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
 
     PGPS_STAMP(2, 0);
     SE right_part, ls;
-    if ((int)blockIdx.x + 1 < a.nblocks) fold_spine_partial<SE>(a.sspine, (int)blockIdx.x + 1, a.nblocks, right_part);
+    MC s_short;
+    const bool has_right = (int)blockIdx.x + 1 < a.nblocks;
+    const bool shortcut = a.shortcut != 0 && has_right && carry_shortcut_smoother<T, D>(a.sspine, (int)blockIdx.x + 1, s_short);
+    if (has_right && !shortcut) fold_spine_partial<SE>(a.sspine, (int)blockIdx.x + 1, a.nblocks, right_part);
     ws_load(a.lsuf, a.nlanes, gt, ls);
     bool staged = false;
     SmootherApplyStaged<T, D, CFG::GG, NT> st;
@@ -1883,7 +1945,9 @@ __global__ __launch_bounds__(kBlock) void k_smoother_apply(const ScanArgs<T> a) 
     if ((int)blockIdx.x + 1 < a.nblocks) pin_elem(right_part);
     PGPS_STAMP(2, 4);
 #endif
-    if ((int)blockIdx.x + 1 < a.nblocks) {
+    if (shortcut) {
+        s = s_short;
+    } else if ((int)blockIdx.x + 1 < a.nblocks) {
         SE right;
         block_reduce_ordered(right_part, right, lds);
         smth_apply(right, s);

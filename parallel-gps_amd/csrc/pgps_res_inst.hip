@@ -18,6 +18,7 @@ int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused) {
     a.nlanes = (long)a.nblocks * kBlock;
     a.seg_first = 1;
     a.seg_last = 1;
+    a.shortcut = ctx->shortcut != 0 ? 1 : 0;        // (a workgroup spans 4096 steps)
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t nb = (size_t)a.nblocks;
     size_t off = 0;

@@ -70,6 +70,11 @@ __device__ __forceinline__ void res_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// max |A| (|E|) of a neighbouring tile's total below which its own (b, C) ((g, L)) ARE the carry: see the forgetting shortcut
+template <typename T> struct ResForget;
+template <> struct ResForget<double> { static constexpr double kA = 0x1p-120; };
+template <> struct ResForget<float> { static constexpr float kA = 0x1p-60f; };
+
 #define PGPS_RSTAMP(IDX)                                                                              \
     do {                                                                                              \
         if (ra.stamps && threadIdx.x == 0) ra.stamps[(long)blockIdx.x * 16 + (IDX)] = __builtin_readcyclecounter(); \
@@ -587,17 +592,43 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
 #pragma unroll
     for (int i = 0; i < SYM; ++i) s.P[i] = P0[i];
     if (tile > 0) {
-        FE mine, left;
-        filt_identity(mine);
-        if ((int)threadIdx.x < tile) {
+        // The forgetting shortcut.  The carry into this tile is the prefix T_0 (x) ... (x) T_{tile-1} applied to the prior; in
+        // ANY bracketing its (b, C) are those of the last total whenever that total's A vanishes: out.b = A_2 w + b_2,
+        // out.C = A_2 N A_2^T + C_2 (parallel.py:100-118).  A total over 4096 steps of a filter that forgets (|A| shrinks by a
+        // factor per step: 0.917^4096 = 1e-154 for config c2 before the update's own contraction) has |A| far below anything a
+        // sum with b or C can see, so the left neighbour's record alone is the carry and the fold of up to 255 records -- eight
+        // combine levels, 10 % of the launch -- is skipped.  Decided per launch FROM THE DATA (max |A| <= 2^-120 in fp64, 2^-60 in
+        // fp32: thirty orders below the unit round-off; a NaN fails the test), identical in every lane (they read the same
+        // words); otherwise the general fold below runs.  Both roads give the same bits whenever the shortcut applies.
+        FE nb;
+        {
             T v[NF];
-            const T* rec = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.spine) + threadIdx.x * (unsigned)(NF * sizeof(T)));
 #pragma unroll
-            for (int i = 0; i < NF; ++i) v[i] = pub_load(rec + i);
-            unpack(v, mine);
+            for (int i = 0; i < NF; ++i) v[i] = pub_load(a.spine + (long)(tile - 1) * NF + i);
+            unpack(v, nb);
         }
-        res_block_reduce_ordered(mine, left, lds);
-        filt_apply(s, left);
+        T amax = T(0);
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) amax = fmax(amax, fabs(nb.A[i]));
+        const bool forget = a.shortcut != 0 && amax <= ResForget<T>::kA;
+        if (__builtin_amdgcn_readfirstlane((int)forget)) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) s.m[i] = nb.b[i];
+#pragma unroll
+            for (int i = 0; i < SYM; ++i) s.P[i] = nb.C[i];
+        } else {
+            FE mine, left;
+            filt_identity(mine);
+            if ((int)threadIdx.x < tile) {
+                T v[NF];
+                const T* rec = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.spine) + threadIdx.x * (unsigned)(NF * sizeof(T)));
+#pragma unroll
+                for (int i = 0; i < NF; ++i) v[i] = pub_load(rec + i);
+                unpack(v, mine);
+            }
+            res_block_reduce_ordered(mine, left, lds);
+            filt_apply(s, left);
+        }
     }
     filt_apply(s, excl);
     PGPS_RSTAMP(4);
@@ -751,19 +782,39 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
 #pragma unroll
     for (int i = 0; i < SYM; ++i) s.P[i] = T(0);
     if (tile + 1 < a.nblocks) {
-        SE mine, right;
-        smth_identity(mine);
-        const int b = tile + 1 + (int)threadIdx.x;
-        if (b < a.nblocks) {
+        // the same shortcut backwards: a smoothing total whose E vanishes (the product of 4096 smoother gains) hands the tile
+        // before it its own (g, L), whatever follows (parallel.py:176-184: E = E_a E_b, g = E_a g_b + g_a, L = E_a L_b E_a^T + L_a)
+        SE nb;
+        {
             T v[NS];
-            const T* rec = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.sspine + (long)(tile + 1) * NS) +
-                                                      threadIdx.x * (unsigned)(NS * sizeof(T)));
 #pragma unroll
-            for (int i = 0; i < NS; ++i) v[i] = pub_load(rec + i);
-            unpack(v, mine);
+            for (int i = 0; i < NS; ++i) v[i] = pub_load(a.sspine + (long)(tile + 1) * NS + i);
+            unpack(v, nb);
         }
-        res_block_reduce_ordered(mine, right, lds);
-        smth_apply(right, s);
+        T emax = T(0);
+#pragma unroll
+        for (int i = 0; i < MAT; ++i) emax = fmax(emax, fabs(nb.E[i]));
+        const bool forget = a.shortcut != 0 && emax <= ResForget<T>::kA;
+        if (__builtin_amdgcn_readfirstlane((int)forget)) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) s.m[i] = nb.g[i];
+#pragma unroll
+            for (int i = 0; i < SYM; ++i) s.P[i] = nb.L[i];
+        } else {
+            SE mine, right;
+            smth_identity(mine);
+            const int b = tile + 1 + (int)threadIdx.x;
+            if (b < a.nblocks) {
+                T v[NS];
+                const T* rec = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.sspine + (long)(tile + 1) * NS) +
+                                                          threadIdx.x * (unsigned)(NS * sizeof(T)));
+#pragma unroll
+                for (int i = 0; i < NS; ++i) v[i] = pub_load(rec + i);
+                unpack(v, mine);
+            }
+            res_block_reduce_ordered(mine, right, lds);
+            smth_apply(right, s);
+        }
     }
     smth_apply(sexcl, s);
     PGPS_RSTAMP(8);

@@ -55,6 +55,8 @@ def _declare(lib):
     if hasattr(lib, "pgps_set_resident"):       # (absent from libraries built before round 5: A/B runs load those)
         lib.pgps_set_resident.argtypes = [P, c_int]
         lib.pgps_resident_stamps.argtypes = [P, P, c_int, ctypes.POINTER(c_int)]
+    if hasattr(lib, "pgps_set_shortcut"):
+        lib.pgps_set_shortcut.argtypes = [P, c_int]
     if hasattr(lib, "pgps_set_rc_scan"):
         lib.pgps_set_rc_scan.argtypes = [P, c_int]
     if hasattr(lib, "pgps_set_one_launch"):
@@ -206,6 +208,11 @@ class Context:
         0 never, 1 wherever the series fits, 2 = 1 + in-kernel phase stamps (pgps_set_resident)."""
         if hasattr(self.lib, "pgps_set_resident"):
             check(self, self.lib.pgps_set_resident(self.handle, int(mode)), "pgps_set_resident")
+
+    def set_shortcut(self, on):
+        """Forgetting shortcut for the carry across workgroups (lane-chunk and resident kernels): 1 where it applies (default), 0 never."""
+        if hasattr(self.lib, "pgps_set_shortcut"):
+            check(self, self.lib.pgps_set_shortcut(self.handle, int(on)), "pgps_set_shortcut")
 
     def resident_stamps(self):
         """(workgroups, 16) cycle stamps of the last resident launch made under set_resident(2) (diagnostics)."""

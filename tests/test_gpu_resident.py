@@ -262,3 +262,86 @@ def test_statespacegp_predict_takes_the_resident_pass_unchanged(ctx):
     mean, var = model.predict_f(tq[:, None])
     mean_o, var_o = O.ssgp_predict_f(kern.get_sde(), t, y, 0.1, tq, parallel=False)
     assert np.max(np.abs(mean[:, 0] - mean_o)) < 1e-8 and np.max(np.abs(var[:, 0] - var_o)) < 1e-8
+
+
+# ------------------------------------------------------------------------------------------------
+# the forgetting shortcut for the carry across workgroups (csrc/pgps_kernels.hip.h, pgps_set_shortcut)
+# ------------------------------------------------------------------------------------------------
+def _both_roads(ctx, ssm, y, resident):
+    ctx.set_resident(1 if resident else 0)
+    out = {}
+    for on in (1, 0):
+        ctx.set_shortcut(on)
+        out[on] = _array_all(ssm, y)
+    ctx.set_shortcut(1)
+    return out[1], out[0]
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_forgetting_shortcut_gives_the_same_bits_where_it_applies(ctx, resident):
+    """An ordinary model (Matern-3/2, observations at every step): every workgroup total has |A| ~ 1e-150 and below, the
+    shortcut is taken -- and the result is bit for bit the general fold's (0 * w + b = b in any bracketing)."""
+    n = (1 << 19) + 77              # (the three-launch kernels try the shortcut from 2048 steps per workgroup: 2^19 steps here)
+    sde = _m32().get_sde()
+    t = make_times(n, seed=31)
+    ssm = tuple(np.asarray(a, np.float64) for a in O.get_ssm(sde, t, 0.1))
+    y = sample_series_fast(ssm, seed=31, nan_frac=0.1)
+    fast, slow = _both_roads(ctx, ssm, y, resident)
+    for k in fast:
+        assert np.array_equal(fast[k], slow[k]), k
+    fms, fPs, sms, sPs, ll = C.kfs(ssm, y)
+    _check(fast, dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([ll])))
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_forgetting_shortcut_steps_aside_where_the_filter_remembers(ctx, resident):
+    """A model that does NOT forget within a workgroup's span: lengthscale 2e4 (F within 1e-5 of the identity per step) and
+    long stretches without observations, some of them covering whole workgroups -- there the totals' A is O(1), the test
+    fails and the general fold runs; where observations return the shortcut applies again.  Both settings against the C
+    oracle, and against each other to round-off."""
+    n = 1 << 19
+    sde = _m32(ls=2.0e4).get_sde()
+    t = make_times(n, seed=32)
+    ssm = tuple(np.asarray(a, np.float64) for a in O.get_ssm(sde, t, 0.1))
+    y = sample_series_fast(ssm, seed=32)
+    y[3000:180000] = np.nan
+    y[280000:280010] = np.nan
+    y[360000:] = np.nan
+    fast, slow = _both_roads(ctx, ssm, y, resident)
+    fms, fPs, sms, sPs, ll = C.kfs(ssm, y)
+    want = dict(fms=fms, fPs=fPs, sms=sms, sPs=sPs, ll=np.array([ll]))
+    _check(fast, want, 1e-8)
+    _check(slow, want, 1e-8)
+    _check(fast, slow, 1e-12)
+
+
+def test_forgetting_shortcut_on_the_fused_road_and_in_float32(ctx):
+    """pgps_gp_* (three launches, 2^21 steps: beyond the resident launch) and a float32 series on the lane-chunk kernels."""
+    B = _B()
+    n = 1 << 21
+    sde = _m32().get_sde()
+    t = make_times(n, seed=33)
+    y = np.sin(0.3 * t) + 0.3 * np.random.default_rng(33).standard_normal(n)
+    form = B.nilpotent_form(sde.F)
+    res = {}
+    for on in (1, 0):
+        ctx.set_shortcut(on)
+        res[on] = B.gp(form, sde.P0, np.asarray(sde.H).reshape(-1), 0.1, t, y, want_filtered=True, want_smoothed=True)
+    ctx.set_shortcut(1)
+    for k in ("fms", "fPs", "sms", "sPs"):
+        assert np.array_equal(res[1][k], res[0][k]), k
+    assert float(res[1]["ll"]) == float(res[0]["ll"])
+    n = 1 << 17
+    ssm = tuple(np.asarray(a, np.float32) for a in O.get_ssm(sde, t[:n], 0.1))
+    y32 = y[:n].astype(np.float32)
+    ctx.set_f32_policy(1)
+    try:
+        out = {}
+        for on in (1, 0):
+            ctx.set_shortcut(on)
+            out[on] = B.pkfs(ssm, y32, return_filtered=True, return_loglikelihood=True)
+        ctx.set_shortcut(1)
+    finally:
+        ctx.set_f32_policy(0)
+    for a_, b_ in zip(out[1][:4], out[0][:4]):
+        assert np.array_equal(a_, b_)
