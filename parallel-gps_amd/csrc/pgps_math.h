@@ -92,12 +92,353 @@ PGPS_HD float recip<float>(float x) {
 }
 #endif
 
+
+// ------------------------------------------------------------------------------------
+// Packed float32.  The float32 d >= 3 kernels keep whole operands in registers and run ONE wave per SIMD (512 registers);
+// from one wave a v_fma_f32 issues every ~5.8 cycles and a v_pk_fma_f32 -- two multiply-adds -- every ~4.2
+// (tools/micro/pk_f32.hip, profiles/r05_experiments.txt item 8): 2.8 x the multiply-adds per issue slot.  hipcc's SLP pass
+// does not get there on the fully unrolled units (> 10 min per unit, Makefile), so the products are written on two-element
+// vectors here, device float only; everything else (double, dual numbers, the host build of tests/cpu_math) takes the scalar
+// loops.  Conventions: a pair is (column j, column j + 1) with j EVEN of a row -- rows of general matrices and of the packed
+// triangles alike, so that a value belongs to one pair for its whole life and the register allocator can keep it there;
+// products of a row with a column broadcast the row's entry (op_sel, free) against a pair of the other operand; products of
+// two rows (X Y^T, matrix-vector) pair along the summation index and add the two halves at the end.  A product that is
+// symmetric in exact arithmetic (F P F^T, A N A^T, G^T J A, E (F P)) is evaluated on its upper triangle only -- the scalar
+// path averages it with its transpose, twice the multiply-adds for a rounding-level difference; the packed triangle it is
+// stored in stays symmetric by construction either way.  -DPGPS_PK_F32=0 restores the scalar path (A/B).
+// ------------------------------------------------------------------------------------
+#ifndef PGPS_PK_F32
+#define PGPS_PK_F32 14
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && PGPS_PK_F32
+#define PGPS_PK_ON 1
+#else
+#define PGPS_PK_ON 0
+#endif
+// which callers take the packed path is a bit mask (PGPS_PK_F32): registers decide -- a pair lives in an aligned 64-bit
+// register, and the d = 6 kernels already keep half of their values in the accumulation registers
+enum PkSel { kPkTree = 0, kPkSolve = 1, kPkExtend = 2, kPkStep = 3, kPkOther = 4, kPkTreeS = 5 };
+template <typename T, int D, int SEL>
+struct UsePk { static constexpr bool on = false; };
+#if PGPS_PK_ON
+template <int D, int SEL>
+struct UsePk<float, D, SEL> { static constexpr bool on = (D >= 2) && (((PGPS_PK_F32) >> SEL) & 1); };
+
+namespace pk {
+typedef float f2 __attribute__((ext_vector_type(2)));
+PGPS_HD f2 mk(float a, float b) { return f2{a, b}; }
+PGPS_HD f2 sp(float a) { return f2{a, a}; }
+PGPS_HD f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// pair (j, j + 1) of row i of a general / packed-symmetric matrix
+template <int D> PGPS_HD f2 gen2(const float* X, int i, int j) { return mk(X[i * D + j], X[i * D + j + 1]); }
+template <int D> PGPS_HD f2 sym2(const float* S, int i, int j) { return mk(S[symi<D>(i, j)], S[symi<D>(i, j + 1)]); }
+
+// sum_k a[k] b[k] over contiguous runs (rows): pairs along k, halves added at the end
+template <int N>
+PGPS_HD float dot(const float* a, const float* b) {
+    if constexpr (N == 1) {
+        return a[0] * b[0];
+    } else {
+        f2 acc = mk(a[0], a[1]) * mk(b[0], b[1]);
+#pragma unroll
+        for (int k = 2; k + 1 < N; k += 2) acc = fma2(mk(a[k], a[k + 1]), mk(b[k], b[k + 1]), acc);
+        float r = acc.x + acc.y;
+        if constexpr (N & 1) r = __builtin_fmaf(a[N - 1], b[N - 1], r);
+        return r;
+    }
+}
+
+// out = X Y, both general: out(i, j..j+1) = sum_k X(i, k) * Y(k, j..j+1)
+template <int D>
+PGPS_HD void mat_mul(const float* X, const float* Y, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j + 1 < D; j += 2) {
+            f2 acc = sp(X[i * D]) * gen2<D>(Y, 0, j);
+#pragma unroll
+            for (int k = 1; k < D; ++k) acc = fma2(sp(X[i * D + k]), gen2<D>(Y, k, j), acc);
+            out[i * D + j] = acc.x;
+            out[i * D + j + 1] = acc.y;
+        }
+        if constexpr (D & 1) {
+            float acc = X[i * D] * Y[D - 1];
+#pragma unroll
+            for (int k = 1; k < D; ++k) acc = __builtin_fmaf(X[i * D + k], Y[k * D + D - 1], acc);
+            out[i * D + D - 1] = acc;
+        }
+    }
+}
+
+// out = X S, S packed symmetric
+template <int D>
+PGPS_HD void mat_mul_sym(const float* X, const float* S, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j + 1 < D; j += 2) {
+            f2 acc = sp(X[i * D]) * sym2<D>(S, 0, j);
+#pragma unroll
+            for (int k = 1; k < D; ++k) acc = fma2(sp(X[i * D + k]), sym2<D>(S, k, j), acc);
+            out[i * D + j] = acc.x;
+            out[i * D + j + 1] = acc.y;
+        }
+        if constexpr (D & 1) {
+            float acc = X[i * D] * S[symi<D>(0, D - 1)];
+#pragma unroll
+            for (int k = 1; k < D; ++k) acc = __builtin_fmaf(X[i * D + k], S[symi<D>(k, D - 1)], acc);
+            out[i * D + D - 1] = acc;
+        }
+    }
+}
+
+// out = S X, S packed symmetric
+template <int D>
+PGPS_HD void sym_mul_mat(const float* S, const float* X, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j + 1 < D; j += 2) {
+            f2 acc = sp(S[symi<D>(i, 0)]) * gen2<D>(X, 0, j);
+#pragma unroll
+            for (int k = 1; k < D; ++k) acc = fma2(sp(S[symi<D>(i, k)]), gen2<D>(X, k, j), acc);
+            out[i * D + j] = acc.x;
+            out[i * D + j + 1] = acc.y;
+        }
+        if constexpr (D & 1) {
+            float acc = S[symi<D>(i, 0)] * X[D - 1];
+#pragma unroll
+            for (int k = 1; k < D; ++k) acc = __builtin_fmaf(S[symi<D>(i, k)], X[k * D + D - 1], acc);
+            out[i * D + D - 1] = acc;
+        }
+    }
+}
+
+// out(sym) = upper(X Y^T) + add(sym): rows against rows
+template <int D>
+PGPS_HD void mat_mul_t_sym(const float* X, const float* Y, const float* add, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            const float acc = dot<D>(X + i * D, Y + j * D);
+            out[symi<D>(i, j)] = add ? acc + add[symi<D>(i, j)] : acc;
+        }
+}
+
+// out(sym) = upper(X^T Y) + add(sym): out(i, j..j+1) = sum_k X(k, i) * Y(k, j..j+1), the pairs that reach the triangle
+template <int D>
+PGPS_HD void mat_t_mul_sym(const float* X, const float* Y, const float* add, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = (i & ~1); j + 1 < D; j += 2) {
+            f2 acc = sp(X[i]) * gen2<D>(Y, 0, j);
+#pragma unroll
+            for (int k = 1; k < D; ++k) acc = fma2(sp(X[k * D + i]), gen2<D>(Y, k, j), acc);
+            if (j >= i) out[symi<D>(i, j)] = add ? acc.x + add[symi<D>(i, j)] : acc.x;
+            out[symi<D>(i, j + 1)] = add ? acc.y + add[symi<D>(i, j + 1)] : acc.y;
+        }
+        if constexpr (D & 1) {
+            float acc = X[i] * Y[D - 1];
+#pragma unroll
+            for (int k = 1; k < D; ++k) acc = __builtin_fmaf(X[k * D + i], Y[k * D + D - 1], acc);
+            out[symi<D>(i, D - 1)] = add ? acc + add[symi<D>(i, D - 1)] : acc;
+        }
+    }
+}
+
+template <int D>
+PGPS_HD void mat_vec(const float* X, const float* v, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) out[i] = dot<D>(X + i * D, v);
+}
+
+// out = X^T v: out(j..j+1) = sum_k v(k) * X(k, j..j+1)
+template <int D>
+PGPS_HD void mat_t_vec(const float* X, const float* v, float* out) {
+#pragma unroll
+    for (int j = 0; j + 1 < D; j += 2) {
+        f2 acc = sp(v[0]) * gen2<D>(X, 0, j);
+#pragma unroll
+        for (int k = 1; k < D; ++k) acc = fma2(sp(v[k]), gen2<D>(X, k, j), acc);
+        out[j] = acc.x;
+        out[j + 1] = acc.y;
+    }
+    if constexpr (D & 1) {
+        float acc = v[0] * X[D - 1];
+#pragma unroll
+        for (int k = 1; k < D; ++k) acc = __builtin_fmaf(v[k], X[k * D + D - 1], acc);
+        out[D - 1] = acc;
+    }
+}
+
+template <int D>
+PGPS_HD void sym_vec(const float* S, const float* v, float* out) {
+#pragma unroll
+    for (int j = 0; j + 1 < D; j += 2) {
+        f2 acc = sp(v[0]) * sym2<D>(S, 0, j);
+#pragma unroll
+        for (int k = 1; k < D; ++k) acc = fma2(sp(v[k]), sym2<D>(S, k, j), acc);
+        out[j] = acc.x;
+        out[j + 1] = acc.y;
+    }
+    if constexpr (D & 1) {
+        float acc = v[0] * S[symi<D>(0, D - 1)];
+#pragma unroll
+        for (int k = 1; k < D; ++k) acc = __builtin_fmaf(v[k], S[symi<D>(k, D - 1)], acc);
+        out[D - 1] = acc;
+    }
+}
+
+// dst(j) += f * src(j) for FROM <= j < N of two rows: the even-aligned pairs packed, the ragged ends scalar
+template <int N, int FROM>
+PGPS_HD void row_axpy(float* dst, const float* src, float f) {
+    constexpr int A0 = (FROM + 1) & ~1;             // first even column >= FROM
+    if constexpr (FROM < A0 && FROM < N) dst[FROM] = __builtin_fmaf(f, src[FROM], dst[FROM]);
+#pragma unroll
+    for (int j = A0; j + 1 < N; j += 2) {
+        const f2 r = fma2(sp(f), mk(src[j], src[j + 1]), mk(dst[j], dst[j + 1]));
+        dst[j] = r.x;
+        dst[j + 1] = r.y;
+    }
+    if constexpr (A0 < N && ((N - A0) & 1)) dst[N - 1] = __builtin_fmaf(f, src[N - 1], dst[N - 1]);
+}
+template <int N, int FROM>
+PGPS_HD void row_scale(float* dst, float f) {
+    constexpr int A0 = (FROM + 1) & ~1;
+    if constexpr (FROM < A0 && FROM < N) dst[FROM] *= f;
+#pragma unroll
+    for (int j = A0; j + 1 < N; j += 2) {
+        const f2 r = sp(f) * mk(dst[j], dst[j + 1]);
+        dst[j] = r.x;
+        dst[j + 1] = r.y;
+    }
+    if constexpr (A0 < N && ((N - A0) & 1)) dst[N - 1] *= f;
+}
+
+// out(sym) = in(sym) + alpha u u^T: row i from its diagonal on, the even-aligned pairs packed
+template <int D>
+PGPS_HD void sym_rank1(const float* in, const float* u, float alpha, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float t = alpha * u[i];
+        if (i & 1) out[symi<D>(i, i)] = __builtin_fmaf(t, u[i], in[symi<D>(i, i)]);
+#pragma unroll
+        for (int j = (i + 1) & ~1; j + 1 < D; j += 2) {
+            const f2 r = fma2(sp(t), mk(u[j], u[j + 1]), sym2<D>(in, i, j));
+            out[symi<D>(i, j)] = r.x;
+            out[symi<D>(i, j + 1)] = r.y;
+        }
+        if constexpr (D & 1) out[symi<D>(i, D - 1)] = __builtin_fmaf(t, u[D - 1], in[symi<D>(i, D - 1)]);
+    }
+}
+
+// out = in + alpha a b^T (general D x D)
+template <int D>
+PGPS_HD void rank1(const float* in, const float* a, const float* b, float alpha, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float t = alpha * a[i];
+#pragma unroll
+        for (int j = 0; j + 1 < D; j += 2) {
+            const f2 r = fma2(sp(t), mk(b[j], b[j + 1]), gen2<D>(in, i, j));
+            out[i * D + j] = r.x;
+            out[i * D + j + 1] = r.y;
+        }
+        if constexpr (D & 1) out[i * D + D - 1] = __builtin_fmaf(t, b[D - 1], in[i * D + D - 1]);
+    }
+}
+// out(sym) = add(sym) + upper(X Y), both general
+template <int D>
+PGPS_HD void mat_mul_upper(const float* X, const float* Y, const float* add, float* out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = (i & ~1); j + 1 < D; j += 2) {
+            f2 acc = mk(j >= i ? add[symi<D>(i, j)] : 0.0f, add[symi<D>(i, j + 1)]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = fma2(sp(X[i * D + k]), gen2<D>(Y, k, j), acc);
+            if (j >= i) out[symi<D>(i, j)] = acc.x;
+            out[symi<D>(i, j + 1)] = acc.y;
+        }
+        if constexpr (D & 1) {
+            float acc = add[symi<D>(i, D - 1)];
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = __builtin_fmaf(X[i * D + k], Y[k * D + D - 1], acc);
+            out[symi<D>(i, D - 1)] = acc;
+        }
+    }
+}
+
+// M = I + C J, both packed symmetric (the system of the filtering operator)
+template <int D>
+PGPS_HD void eye_plus_sym_sym(const float* C, const float* J, float* M) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j + 1 < D; j += 2) {
+            f2 acc = mk(i == j ? 1.0f : 0.0f, i == j + 1 ? 1.0f : 0.0f);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = fma2(sp(C[symi<D>(i, k)]), sym2<D>(J, k, j), acc);
+            M[i * D + j] = acc.x;
+            M[i * D + j + 1] = acc.y;
+        }
+        if constexpr (D & 1) {
+            float acc = (i == D - 1) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = __builtin_fmaf(C[symi<D>(i, k)], J[symi<D>(k, D - 1)], acc);
+            M[i * D + D - 1] = acc;
+        }
+    }
+}
+
+// one column of the Gauss-Jordan elimination of gj_solve (below): pivot search by predicated row swaps as there, the row
+// operations packed
+template <int D, int NR, bool PIVOT, int C>
+PGPS_HD void gj_col(float* M, float* B) {
+    if constexpr (PIVOT) {
+#pragma unroll
+        for (int r = C + 1; r < D; ++r) {
+            const bool sw = __builtin_fabsf(M[r * D + C]) > __builtin_fabsf(M[C * D + C]);
+#pragma unroll
+            for (int j = C; j < D; ++j) {
+                const float u = M[C * D + j], v = M[r * D + j];
+                M[C * D + j] = sw ? v : u;
+                M[r * D + j] = sw ? u : v;
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const float u = B[C * NR + j], v = B[r * NR + j];
+                B[C * NR + j] = sw ? v : u;
+                B[r * NR + j] = sw ? u : v;
+            }
+        }
+    }
+    const float inv = recip(M[C * D + C]);
+    row_scale<D, C + 1>(M + C * D, inv);
+    row_scale<NR, 0>(B + C * NR, inv);
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        if (r == C) continue;
+        const float f = -M[r * D + C];
+        row_axpy<D, C + 1>(M + r * D, M + C * D, f);
+        row_axpy<NR, 0>(B + r * NR, B + C * NR, f);
+    }
+    if constexpr (C + 1 < D) gj_col<D, NR, PIVOT, C + 1>(M, B);
+}
+}  // namespace pk
+#endif      // PGPS_PK_ON
+
 // ------------------------------------------------------------------------------------
 // basic products
 // ------------------------------------------------------------------------------------
 // out = X * Y  (general D x D)
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void mat_mul(const T* X, const T* Y, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::mat_mul<D>(X, Y, out); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -110,8 +451,11 @@ PGPS_HD void mat_mul(const T* X, const T* Y, T* out) {
 }
 
 // out = X * S  with S symmetric-packed
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void mat_mul_sym(const T* X, const T* S, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::mat_mul_sym<D>(X, S, out); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -124,8 +468,11 @@ PGPS_HD void mat_mul_sym(const T* X, const T* S, T* out) {
 }
 
 // out = S * X  with S symmetric-packed
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void sym_mul_mat(const T* S, const T* X, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::sym_mul_mat<D>(S, X, out); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -138,8 +485,11 @@ PGPS_HD void sym_mul_mat(const T* S, const T* X, T* out) {
 }
 
 // out(sym) = sym_part(X * Y^T) + add(sym)      (add may be nullptr)
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void mat_mul_t_sym(const T* X, const T* Y, const T* add, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::mat_mul_t_sym<D>(X, Y, add, out); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -159,8 +509,11 @@ PGPS_HD void mat_mul_t_sym(const T* X, const T* Y, const T* add, T* out) {
 }
 
 // out(sym) = sym_part(X^T * Y) + add(sym)
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void mat_t_mul_sym(const T* X, const T* Y, const T* add, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::mat_t_mul_sym<D>(X, Y, add, out); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -179,8 +532,11 @@ PGPS_HD void mat_t_mul_sym(const T* X, const T* Y, const T* add, T* out) {
         }
 }
 
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void mat_vec(const T* X, const T* v, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::mat_vec<D>(X, v, out); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         T acc = T(0);
@@ -190,8 +546,11 @@ PGPS_HD void mat_vec(const T* X, const T* v, T* out) {
     }
 }
 
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void mat_t_vec(const T* X, const T* v, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::mat_t_vec<D>(X, v, out); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         T acc = T(0);
@@ -201,8 +560,11 @@ PGPS_HD void mat_t_vec(const T* X, const T* v, T* out) {
     }
 }
 
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void sym_vec(const T* S, const T* v, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::sym_vec<D>(S, v, out); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         T acc = T(0);
@@ -213,10 +575,37 @@ PGPS_HD void sym_vec(const T* S, const T* v, T* out) {
 }
 
 // out(sym) = F * P(sym) * F^T + Q(sym);  FP (general) is also returned (= F P)
-template <typename T, int D>
+template <typename T, int D, int SEL = kPkOther>
 PGPS_HD void predict_cov(const T* F, const T* P, const T* Q, T* FP, T* out) {
-    mat_mul_sym<T, D>(F, P, FP);
-    mat_mul_t_sym<T, D>(FP, F, Q, out);
+    mat_mul_sym<T, D, SEL>(F, P, FP);
+    mat_mul_t_sym<T, D, SEL>(FP, F, Q, out);
+}
+
+// sum_i a[i] b[i] + init
+template <typename T, int D, int SEL = kPkOther>
+PGPS_HD T dot_add(const T* a, const T* b, T init) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { return init + pk::dot<D>(a, b); }
+#endif
+    T acc = init;
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc += a[i] * b[i];
+    return acc;
+}
+
+// out(sym) = in(sym) -/+ u u^T inv   (the rank-one updates of the scalar-innovation steps; out may be in)
+template <typename T, int D, bool MINUS, int SEL = kPkOther>
+PGPS_HD void sym_outer(const T* in, const T* u, T inv, T* out) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::sym_rank1<D>(in, u, MINUS ? -inv : inv, out); return; }
+#endif
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            if (MINUS) out[symi<D>(i, j)] = in[symi<D>(i, j)] - u[i] * u[j] * inv;
+            else out[symi<D>(i, j)] = in[symi<D>(i, j)] + u[i] * u[j] * inv;
+        }
 }
 
 // ------------------------------------------------------------------------------------
@@ -224,7 +613,7 @@ PGPS_HD void predict_cov(const T* F, const T* P, const T* Q, T* FP, T* out) {
 // every index stays compile-time and operands stay in registers).  M and B are destroyed;
 // B holds X on return.  D = 1, 2 take closed forms.
 // ------------------------------------------------------------------------------------
-template <typename T, int D, int NR, bool PIVOT>
+template <typename T, int D, int NR, bool PIVOT, int SEL = kPkOther>
 PGPS_HD void gj_solve(T* M, T* B) {
     if constexpr (D == 1) {
         const T inv = recip(M[0]);
@@ -242,6 +631,9 @@ PGPS_HD void gj_solve(T* M, T* B) {
         }
         return;
     } else {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) { pk::gj_col<D, NR, PIVOT, 0>(M, B); return; }
+#endif
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         if (PIVOT) {
@@ -307,17 +699,12 @@ PGPS_HD void filt_first(FiltElem<T, D>& e, const T* P0 /*sym*/, T y, const T* h,
     for (int i = 0; i < Dim<D>::SYM; ++i) { e.C[i] = P0[i]; e.J[i] = T(0); }
     if (!is_nan(y)) {
         T u[D];
-        sym_vec<T, D>(P0, h, u);
-        T S = R;
-#pragma unroll
-        for (int i = 0; i < D; ++i) S += h[i] * u[i];
+        sym_vec<T, D, kPkExtend>(P0, h, u);
+        const T S = dot_add<T, D, kPkExtend>(h, u, R);
         const T inv = recip(S);
 #pragma unroll
         for (int i = 0; i < D; ++i) e.b[i] = u[i] * (y * inv);
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = i; j < D; ++j) e.C[symi<D>(i, j)] -= u[i] * u[j] * inv;
+        sym_outer<T, D, true, kPkExtend>(e.C, u, inv, e.C);
     }
 }
 
@@ -330,9 +717,9 @@ PGPS_HD void filt_first(FiltElem<T, D>& e, const T* P0 /*sym*/, T y, const T* h,
 template <typename T, int D>
 PGPS_HD void filt_extend(FiltElem<T, D>& e, const T* F, const T* Q /*sym*/, T y, const T* h, T R) {
     T Ap[D * D], bp[D], FC[D * D], Cp[Dim<D>::SYM];
-    mat_mul<T, D>(F, e.A, Ap);
-    mat_vec<T, D>(F, e.b, bp);
-    predict_cov<T, D>(F, e.C, Q, FC, Cp);
+    mat_mul<T, D, kPkExtend>(F, e.A, Ap);
+    mat_vec<T, D, kPkExtend>(F, e.b, bp);
+    predict_cov<T, D, kPkExtend>(F, e.C, Q, FC, Cp);
     if (is_nan(y)) {
 #pragma unroll
         for (int i = 0; i < D * D; ++i) e.A[i] = Ap[i];
@@ -343,13 +730,24 @@ PGPS_HD void filt_extend(FiltElem<T, D>& e, const T* F, const T* Q /*sym*/, T y,
         return;
     }
     T u[D], v[D];
-    sym_vec<T, D>(Cp, h, u);            // Cp H^T
-    mat_t_vec<T, D>(Ap, h, v);          // (H Ap)^T
-    T S = R, hb = T(0);
-#pragma unroll
-    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; hb += h[i] * bp[i]; }
+    sym_vec<T, D, kPkExtend>(Cp, h, u);            // Cp H^T
+    mat_t_vec<T, D, kPkExtend>(Ap, h, v);          // (H Ap)^T
+    const T S = dot_add<T, D, kPkExtend>(h, u, R), hb = dot_add<T, D, kPkExtend>(h, bp, T(0));
     const T inv = recip(S);
     const T res = y - hb;
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, kPkExtend>::on) {
+        pk::rank1<D>(Ap, u, v, -inv, e.A);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            e.b[i] = bp[i] + (u[i] * inv) * res;
+            e.eta[i] += v[i] * (res * inv);
+        }
+        sym_outer<T, D, true, kPkExtend>(Cp, u, inv, e.C);
+        sym_outer<T, D, false, kPkExtend>(e.J, v, inv, e.J);
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         const T Ki = u[i] * inv;
@@ -367,6 +765,34 @@ PGPS_HD void filt_extend(FiltElem<T, D>& e, const T* F, const T* Q /*sym*/, T y,
         }
 }
 
+// the system of the filtering operator: M = I + C1 J2 and w = b1 + C1 eta2
+template <typename T, int D, int SEL>
+PGPS_HD void filt_system(const T* C1, const T* J2, const T* b1, const T* eta2, T* M, T* w) {
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, SEL>::on) {
+        pk::eye_plus_sym_sym<D>(C1, J2, M);
+        T t[D];
+        pk::sym_vec<D>(C1, eta2, t);
+#pragma unroll
+        for (int i = 0; i < D; ++i) w[i] = b1[i] + t[i];
+        return;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T wi = b1[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            T acc = (i == j) ? T(1) : T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += C1[symi<D>(i, k)] * J2[symi<D>(k, j)];
+            M[i * D + j] = acc;
+            wi += C1[symi<D>(i, j)] * eta2[j];
+        }
+        w[i] = wi;
+    }
+}
+
 // out = e1 (x) e2, the general filtering operator (parallel.py:100-118).
 // One factorisation of M = I + C1 J2 serves both halves because (I + J2 C1) = M^T.
 //   G = M^-1 A1, N = M^-1 C1, w = M^-1 (b1 + C1 eta2)
@@ -375,24 +801,19 @@ PGPS_HD void filt_extend(FiltElem<T, D>& e, const T* F, const T* Q /*sym*/, T y,
 template <typename T, int D>
 PGPS_HD void filt_combine(const FiltElem<T, D>& e1, const FiltElem<T, D>& e2, FiltElem<T, D>& out) {
     constexpr int NR = 2 * D + 1;
-    T M[D * D], B[D * NR];
+    T M[D * D], B[D * NR], w[D];
+    filt_system<T, D, kPkTree>(e1.C, e2.J, e1.b, e2.eta, M, w);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        T wi = e1.b[i];
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            T acc = (i == j) ? T(1) : T(0);
-#pragma unroll
-            for (int k = 0; k < D; ++k) acc += e1.C[symi<D>(i, k)] * e2.J[symi<D>(k, j)];
-            M[i * D + j] = acc;
             B[i * NR + j] = e1.A[i * D + j];
             B[i * NR + D + j] = e1.C[symi<D>(i, j)];
-            wi += e1.C[symi<D>(i, j)] * e2.eta[j];
         }
-        B[i * NR + 2 * D] = wi;
+        B[i * NR + 2 * D] = w[i];
     }
-    gj_solve<T, D, NR, true>(M, B);
-    T G[D * D], Nm[D * D], w[D];
+    gj_solve<T, D, NR, true, kPkSolve>(M, B);
+    T G[D * D], Nm[D * D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
 #pragma unroll
@@ -400,21 +821,21 @@ PGPS_HD void filt_combine(const FiltElem<T, D>& e1, const FiltElem<T, D>& e2, Fi
         w[i] = B[i * NR + 2 * D];
     }
     T X[D * D];
-    mat_mul<T, D>(e2.A, G, out.A);
-    mat_vec<T, D>(e2.A, w, out.b);
+    mat_mul<T, D, kPkTree>(e2.A, G, out.A);
+    mat_vec<T, D, kPkTree>(e2.A, w, out.b);
 #pragma unroll
     for (int i = 0; i < D; ++i) out.b[i] += e2.b[i];
-    mat_mul<T, D>(e2.A, Nm, X);
-    mat_mul_t_sym<T, D>(X, e2.A, e2.C, out.C);
+    mat_mul<T, D, kPkTree>(e2.A, Nm, X);
+    mat_mul_t_sym<T, D, kPkTree>(X, e2.A, e2.C, out.C);
     T z[D], Jb[D];
-    sym_vec<T, D>(e2.J, e1.b, Jb);
+    sym_vec<T, D, kPkTree>(e2.J, e1.b, Jb);
 #pragma unroll
     for (int i = 0; i < D; ++i) z[i] = e2.eta[i] - Jb[i];
-    mat_t_vec<T, D>(G, z, out.eta);
+    mat_t_vec<T, D, kPkTree>(G, z, out.eta);
 #pragma unroll
     for (int i = 0; i < D; ++i) out.eta[i] += e1.eta[i];
-    sym_mul_mat<T, D>(e2.J, e1.A, X);
-    mat_t_mul_sym<T, D>(G, X, e1.J, out.J);
+    sym_mul_mat<T, D, kPkTree>(e2.J, e1.A, X);
+    mat_t_mul_sym<T, D, kPkTree>(G, X, e1.J, out.J);
 }
 
 // (m, P) <- (0, m, P, ., .) (x) e2: push a filtered state through an aggregate.  This is
@@ -422,34 +843,27 @@ PGPS_HD void filt_combine(const FiltElem<T, D>& e1, const FiltElem<T, D>& e2, Fi
 template <typename T, int D>
 PGPS_HD void filt_apply(MeanCov<T, D>& s, const FiltElem<T, D>& e2) {
     constexpr int NR = D + 1;
-    T M[D * D], B[D * NR];
+    T M[D * D], B[D * NR], w[D];
+    filt_system<T, D, kPkTree>(s.P, e2.J, s.m, e2.eta, M, w);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        T wi = s.m[i];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            T acc = (i == j) ? T(1) : T(0);
-#pragma unroll
-            for (int k = 0; k < D; ++k) acc += s.P[symi<D>(i, k)] * e2.J[symi<D>(k, j)];
-            M[i * D + j] = acc;
-            B[i * NR + j] = s.P[symi<D>(i, j)];
-            wi += s.P[symi<D>(i, j)] * e2.eta[j];
-        }
-        B[i * NR + D] = wi;
+        for (int j = 0; j < D; ++j) B[i * NR + j] = s.P[symi<D>(i, j)];
+        B[i * NR + D] = w[i];
     }
-    gj_solve<T, D, NR, true>(M, B);
-    T Nm[D * D], w[D], X[D * D];
+    gj_solve<T, D, NR, true, kPkSolve>(M, B);
+    T Nm[D * D], X[D * D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
 #pragma unroll
         for (int j = 0; j < D; ++j) Nm[i * D + j] = B[i * NR + j];
         w[i] = B[i * NR + D];
     }
-    mat_vec<T, D>(e2.A, w, s.m);
+    mat_vec<T, D, kPkTree>(e2.A, w, s.m);
 #pragma unroll
     for (int i = 0; i < D; ++i) s.m[i] += e2.b[i];
-    mat_mul<T, D>(e2.A, Nm, X);
-    mat_mul_t_sym<T, D>(X, e2.A, e2.C, s.P);
+    mat_mul<T, D, kPkTree>(e2.A, Nm, X);
+    mat_mul_t_sym<T, D, kPkTree>(X, e2.A, e2.C, s.P);
 }
 
 // ------------------------------------------------------------------------------------
@@ -487,33 +901,26 @@ struct LogLik {
 template <typename T, int D, typename LL>
 PGPS_HD void kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, const T* h, T R,
                      bool first, LL& ll, T* mp, T* Pp, T* FP) {
-    mat_vec<T, D>(F, s.m, mp);
-    predict_cov<T, D>(F, s.P, Q, FP, Pp);
+    mat_vec<T, D, kPkStep>(F, s.m, mp);
+    predict_cov<T, D, kPkStep>(F, s.P, Q, FP, Pp);
     const bool obs = !is_nan(y);
     T u[D];
-    sym_vec<T, D>(Pp, h, u);
-    T S = R, mu = T(0);
-#pragma unroll
-    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; mu += h[i] * mp[i]; }
+    sym_vec<T, D, kPkStep>(Pp, h, u);
+    const T S = dot_add<T, D, kPkStep>(h, u, R), mu = dot_add<T, D, kPkStep>(h, mp, T(0));
     if (obs) {
         ll.add(ll_diff(y, mu), ll_wide(S));
     }
     if (first) {
         // update straight from the prior (s holds m0 = 0, P0)
         T u0[D];
-        sym_vec<T, D>(s.P, h, u0);
-        T S0 = R, mu0 = T(0);
-#pragma unroll
-        for (int i = 0; i < D; ++i) { S0 += h[i] * u0[i]; mu0 += h[i] * s.m[i]; }
+        sym_vec<T, D, kPkStep>(s.P, h, u0);
+        const T S0 = dot_add<T, D, kPkStep>(h, u0, R), mu0 = dot_add<T, D, kPkStep>(h, s.m, T(0));
         if (obs) {
             const T inv = recip(S0);
             const T res = y - mu0;
 #pragma unroll
             for (int i = 0; i < D; ++i) s.m[i] += u0[i] * (res * inv);
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] -= u0[i] * u0[j] * inv;
+            sym_outer<T, D, true, kPkStep>(s.P, u0, inv, s.P);
         }
         return;
     }
@@ -522,10 +929,7 @@ PGPS_HD void kf_step(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, cons
         const T res = y - mu;
 #pragma unroll
         for (int i = 0; i < D; ++i) s.m[i] = mp[i] + u[i] * (res * inv);
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] = Pp[symi<D>(i, j)] - u[i] * u[j] * inv;
+        sym_outer<T, D, true, kPkStep>(Pp, u, inv, s.P);
     } else {
 #pragma unroll
         for (int i = 0; i < D; ++i) s.m[i] = mp[i];
@@ -555,7 +959,7 @@ PGPS_HD void smth_gain(const T* FP, const T* Pp, T* E) {
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j < D; ++j) { M[i * D + j] = Pp[symi<D>(i, j)]; B[i * D + j] = FP[i * D + j]; }
-    gj_solve<T, D, D, false>(M, B);     // B = Pp^-1 F P = E^T
+    gj_solve<T, D, D, false, kPkStep>(M, B);     // B = Pp^-1 F P = E^T
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -569,9 +973,18 @@ template <typename T, int D>
 PGPS_HD void smth_element(const MeanCov<T, D>& s, const T* mp, const T* Pp, const T* FP, SmthElem<T, D>& e) {
     smth_gain<T, D>(FP, Pp, e.E);
     T Em[D];
-    mat_vec<T, D>(e.E, mp, Em);
+    mat_vec<T, D, kPkStep>(e.E, mp, Em);
 #pragma unroll
     for (int i = 0; i < D; ++i) e.g[i] = s.m[i] - Em[i];
+#if PGPS_PK_ON
+    if constexpr (UsePk<T, D, kPkStep>::on) {
+        T nE[D * D];
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) nE[i] = -e.E[i];
+        pk::mat_mul_upper<D>(nE, FP, s.P, e.L);
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -601,23 +1014,23 @@ PGPS_HD void smth_last(const MeanCov<T, D>& s, SmthElem<T, D>& e) {
 template <typename T, int D>
 PGPS_HD void smth_combine(const SmthElem<T, D>& a, const SmthElem<T, D>& b, SmthElem<T, D>& out) {
     T X[D * D], gv[D];
-    mat_mul<T, D>(a.E, b.E, out.E);
-    mat_vec<T, D>(a.E, b.g, gv);
+    mat_mul<T, D, kPkTreeS>(a.E, b.E, out.E);
+    mat_vec<T, D, kPkTreeS>(a.E, b.g, gv);
 #pragma unroll
     for (int i = 0; i < D; ++i) out.g[i] = gv[i] + a.g[i];
-    mat_mul_sym<T, D>(a.E, b.L, X);
-    mat_mul_t_sym<T, D>(X, a.E, a.L, out.L);
+    mat_mul_sym<T, D, kPkTreeS>(a.E, b.L, X);
+    mat_mul_t_sym<T, D, kPkTreeS>(X, a.E, a.L, out.L);
 }
 
 // (sm, sP) at the step after an aggregate -> (sm, sP) at the aggregate's first step
 template <typename T, int D>
 PGPS_HD void smth_apply(const SmthElem<T, D>& a, MeanCov<T, D>& s) {
     T X[D * D], gv[D], Ls[Dim<D>::SYM];
-    mat_vec<T, D>(a.E, s.m, gv);
+    mat_vec<T, D, kPkTreeS>(a.E, s.m, gv);
 #pragma unroll
     for (int i = 0; i < D; ++i) s.m[i] = gv[i] + a.g[i];
-    mat_mul_sym<T, D>(a.E, s.P, X);
-    mat_mul_t_sym<T, D>(X, a.E, a.L, Ls);
+    mat_mul_sym<T, D, kPkTreeS>(a.E, s.P, X);
+    mat_mul_t_sym<T, D, kPkTreeS>(X, a.E, a.L, Ls);
 #pragma unroll
     for (int i = 0; i < Dim<D>::SYM; ++i) s.P[i] = Ls[i];
 }
@@ -633,11 +1046,11 @@ PGPS_HD void rts_step(const MeanCov<T, D>& f, const T* mp, const T* Pp, const T*
     for (int i = 0; i < D; ++i) dm[i] = s.m[i] - mp[i];
 #pragma unroll
     for (int i = 0; i < Dim<D>::SYM; ++i) dP[i] = s.P[i] - Pp[i];
-    mat_vec<T, D>(E, dm, Em);
+    mat_vec<T, D, kPkStep>(E, dm, Em);
 #pragma unroll
     for (int i = 0; i < D; ++i) s.m[i] = f.m[i] + Em[i];
-    mat_mul_sym<T, D>(E, dP, X);
-    mat_mul_t_sym<T, D>(X, E, f.P, s.P);
+    mat_mul_sym<T, D, kPkStep>(E, dP, X);
+    mat_mul_t_sym<T, D, kPkStep>(X, E, f.P, s.P);
 }
 
 // ------------------------------------------------------------------------------------
@@ -657,32 +1070,25 @@ PGPS_HD void rts_step(const MeanCov<T, D>& f, const T* mp, const T* Pp, const T*
 template <typename T, int D, typename LL>
 PGPS_HD void kf_step_u(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, const T* h, T R, bool first, LL& ll, T* mp,
                        T* Pp, T* FP, T* u, T& inv_o, T& res_o) {
-    mat_vec<T, D>(F, s.m, mp);
-    predict_cov<T, D>(F, s.P, Q, FP, Pp);
+    mat_vec<T, D, kPkStep>(F, s.m, mp);
+    predict_cov<T, D, kPkStep>(F, s.P, Q, FP, Pp);
     const bool obs = !is_nan(y);
-    sym_vec<T, D>(Pp, h, u);
-    T S = R, mu = T(0);
-#pragma unroll
-    for (int i = 0; i < D; ++i) { S += h[i] * u[i]; mu += h[i] * mp[i]; }
+    sym_vec<T, D, kPkStep>(Pp, h, u);
+    const T S = dot_add<T, D, kPkStep>(h, u, R), mu = dot_add<T, D, kPkStep>(h, mp, T(0));
     if (obs) ll.add(ll_diff(y, mu), ll_wide(S));
     inv_o = T(0);
     res_o = T(0);
     if (first) {
         // update straight from the prior (s holds m0 = 0, P0); no element is built from this step's predict
         T u0[D];
-        sym_vec<T, D>(s.P, h, u0);
-        T S0 = R, mu0 = T(0);
-#pragma unroll
-        for (int i = 0; i < D; ++i) { S0 += h[i] * u0[i]; mu0 += h[i] * s.m[i]; }
+        sym_vec<T, D, kPkStep>(s.P, h, u0);
+        const T S0 = dot_add<T, D, kPkStep>(h, u0, R), mu0 = dot_add<T, D, kPkStep>(h, s.m, T(0));
         if (obs) {
             const T inv = recip(S0);
             const T res = y - mu0;
 #pragma unroll
             for (int i = 0; i < D; ++i) s.m[i] += u0[i] * (res * inv);
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] -= u0[i] * u0[j] * inv;
+            sym_outer<T, D, true, kPkStep>(s.P, u0, inv, s.P);
         }
         return;
     }
@@ -693,10 +1099,7 @@ PGPS_HD void kf_step_u(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, co
         res_o = res;
 #pragma unroll
         for (int i = 0; i < D; ++i) s.m[i] = mp[i] + u[i] * (res * inv);
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = i; j < D; ++j) s.P[symi<D>(i, j)] = Pp[symi<D>(i, j)] - u[i] * u[j] * inv;
+        sym_outer<T, D, true, kPkStep>(Pp, u, inv, s.P);
     } else {
 #pragma unroll
         for (int i = 0; i < D; ++i) s.m[i] = mp[i];
@@ -709,16 +1112,13 @@ PGPS_HD void kf_step_u(MeanCov<T, D>& s, const T* F, const T* Q /*sym*/, T y, co
 template <typename T, int D>
 PGPS_HD void smth_extend_u(SmthElem<T, D>& a, const T* E, const T* u, T inv, T res) {
     T v[D], w[D], EE[D * D];
-    mat_vec<T, D>(E, u, v);
-    mat_vec<T, D>(a.E, v, w);               // (with the total's gain BEFORE this step)
+    mat_vec<T, D, kPkStep>(E, u, v);
+    mat_vec<T, D, kPkStep>(a.E, v, w);               // (with the total's gain BEFORE this step)
     const T c = res * inv;
 #pragma unroll
     for (int i = 0; i < D; ++i) a.g[i] += w[i] * c;
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = i; j < D; ++j) a.L[symi<D>(i, j)] -= w[i] * w[j] * inv;
-    mat_mul<T, D>(a.E, E, EE);
+    sym_outer<T, D, true, kPkStep>(a.L, w, inv, a.L);
+    mat_mul<T, D, kPkStep>(a.E, E, EE);
 #pragma unroll
     for (int i = 0; i < D * D; ++i) a.E[i] = EE[i];
 }

@@ -1,5 +1,7 @@
-"""Phase breakdown of the three scan kernels from the diagnostic build (make -C parallel-gps_amd/csrc stamps).
-Run on the GPU box:  PGPS_LIB=parallel-gps_amd/pssgp/libpgps_stamps.so python tools/stamps.py [chunk] [stage]"""
+"""Phase breakdown of the three scan kernels from the diagnostic build (make -C parallel-gps_amd/csrc stamps [ST=f32 SD=6]).
+Run on the GPU box:  PGPS_LIB=parallel-gps_amd/pssgp/libpgps_stamps.so python tools/stamps.py [chunk] [stage]
+STAMP_KERNEL / STAMP_DTYPE (bench.py's --kernel / --dtype names; default matern32 / f64) pick the model -- the library must have
+been built with the matching ST / SD."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("PGPS_LIB", os.path.join(ROOT, "parallel-gps_amd", "pssgp", "libpgps_stamps.so"))
@@ -13,24 +15,33 @@ stage = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 single = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 1: single-pass filter kernel (k_filter_single)
 block = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # lanes per workgroup: 0 auto, 128, 256
 dma = int(sys.argv[5]) if len(sys.argv) > 5 else -1        # LDS-DMA ring in the Kalman pass: -1 auto, 0 off, 1 on
-n, d = 1 << 20, 2
+sys.path.insert(0, ROOT)
+import bench as _bench
+kname, dt = os.environ.get("STAMP_KERNEL", "matern32"), os.environ.get("STAMP_DTYPE", "f64")
+npdt = np.float64 if dt == "f64" else np.float32
+n = 1 << 20
 ctx = B.Context(0)
+ctx.set_resident(0)
+if dt == "f32":
+    ctx.set_f32_policy(1)
 ctx.set_chunk(chunk); ctx.set_stage(stage); ctx.set_block(block); ctx.set_dma(dma)
 if single:
     ctx.set_single_pass(1, 256)
-sde = Matern32(1., 1.).get_sde()
+sde = _bench.make_kernel(kname).get_sde()
+d = sde.F.shape[0]
 rng = np.random.default_rng(0)
 ts = np.cumsum(0.05 * rng.uniform(0.5, 1.5, n))
 Fs, Qs = B.discretise(sde.F, sde.P0, ts, 0.0)
 ys = rng.standard_normal(n)
 def dev(a):
-    a = np.ascontiguousarray(a, dtype=np.float64); p = ctx.malloc(a.nbytes); ctx.h2d(p, a); return p
+    a = np.ascontiguousarray(a, dtype=npdt); p = ctx.malloc(a.nbytes); ctx.h2d(p, a); return p
 P0, F_, Q_, H, Y = dev(sde.P0), dev(Fs), dev(Qs), dev(sde.H.reshape(-1)), dev(ys)
-fms, fPs, sms, sPs, ll = (ctx.malloc(n * d * 8), ctx.malloc(n * d * d * 8), ctx.malloc(n * d * 8),
-                          ctx.malloc(n * d * d * 8), ctx.malloc(16))
+w = np.dtype(npdt).itemsize
+fms, fPs, sms, sPs, ll = (ctx.malloc(n * d * w), ctx.malloc(n * d * d * w), ctx.malloc(n * d * w),
+                          ctx.malloc(n * d * d * w), ctx.malloc(16))
 P = ctypes.c_void_p
 for it in range(5):
-    ctx.call("pgps_pkfs_dev_f64", ctypes.c_long(n), ctypes.c_int(d), P(P0), P(F_), P(Q_), P(H), ctypes.c_double(0.1),
+    ctx.call("pgps_pkfs_dev_" + dt, ctypes.c_long(n), ctypes.c_int(d), P(P0), P(F_), P(Q_), P(H), (ctypes.c_double if dt == "f64" else ctypes.c_float)(0.1),
              P(Y), P(fms), P(fPs), P(sms), P(sPs), P(ll))
 ctx.synchronize()
 lanes, lc, nb = ctx.get_geometry(n, d)
