@@ -212,11 +212,15 @@ struct ResArgs {
     GpModel<T> m;           // fused form: the Matern model (F = -lam I + N) and the time stamps
     int* bar;               // this launch's 8 counter shards (32 ints apart), zero on entry
     int* bar_next;          // the next launch's: zeroed by this one
+    int* flags1;            // per workgroup: `epoch` once its filtering total is published (the neighbour hand-off)
+    int* flags2;            // ... once its smoothing total and log-likelihood partial are
+    int epoch;              // this launch's (never 0)
     long long* stamps;      // diagnostics (pgps_set_resident(ctx, 2)): (nblocks, 16) cycle stamps, else null
 };
 constexpr int kResLc = 16;                  // steps per lane: the chunk lives in registers
 constexpr int kStatusBytes = 8192;          // the context's status buffer: word 0 flags, 16.. tickets, 512.. the resident kernel's barrier counters
 constexpr int kResBarWord = 512;            // two sets of 8 shards x 32 ints
+constexpr int kResFlagWord = 1024;          // two arrays of 256 per-workgroup hand-off flags (words 1024 .. 1535)
 // does a whole-series filter + smoother call of N steps at dimension d (fp64 when !f32) take the resident launch?
 bool resident_fits(const pgps_ctx* ctx, long N, int d, bool f32);
 template <typename T, int D>

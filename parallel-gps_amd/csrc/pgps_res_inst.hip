@@ -36,6 +36,10 @@ int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused) {
     const unsigned e = ctx->res_epoch++;
     ra.bar = ctx->status_word + kResBarWord + (e & 1u) * 256;
     ra.bar_next = ctx->status_word + kResBarWord + ((e + 1u) & 1u) * 256;
+    ra.flags1 = ctx->status_word + kResFlagWord;
+    ra.flags2 = ctx->status_word + kResFlagWord + 256;
+    ra.epoch = (int)(e % 0x7ffffffeu) + 1;           // compared for equality: a stale flag of any earlier launch never matches
+    static_assert(kResFlagWord * 4 + 2 * 256 * 4 <= kStatusBytes, "hand-off flags outside the status buffer");
     ra.stamps = nullptr;
     if (ctx->resident == 2) {
         rc = ensure(ctx, ctx->res_stamps, nb * 16 * sizeof(long long));

@@ -160,13 +160,37 @@ __device__ __forceinline__ void res_drain_m(char* __restrict__ g /*wave-uniform*
 
 // one arrival of this workgroup at a grid-wide barrier and the wait for `rounds` x (every workgroup's arrival).
 // The caller's lane 0 has drained the stores it publishes (s_waitcnt vmcnt(0)) before this is called.
-__device__ __forceinline__ void res_grid_barrier(int* bar, int tile, int nblocks, int rounds, int* status) {
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(bar + (tile & 7) * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void res_wait_all(int* bar, int nblocks, int rounds, int* status) {
     if (threadIdx.x < 8) {
         const int want = rounds * ((nblocks - (int)threadIdx.x + 7) / 8);       // tiles whose index is threadIdx.x mod 8
         if (want > 0) wait_flag(bar + threadIdx.x * 32, want, status);
     }
     __syncthreads();
+}
+__device__ __forceinline__ void res_arrive(int* bar, int tile) {
+    __hip_atomic_fetch_add(bar + (tile & 7) * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void res_grid_barrier(int* bar, int tile, int nblocks, int rounds, int* status) {
+    if (threadIdx.x == 0) res_arrive(bar, tile);
+    res_wait_all(bar, nblocks, rounds, status);
+}
+
+// The neighbour hand-off (round 5, with the forgetting shortcut): a workgroup that can take its carry from ONE neighbour's
+// total waits for that neighbour only -- a flag per workgroup, set to the launch's epoch by the lane that published the total
+// (after its stores have drained, like the arrival) -- and falls back to the grid-wide wait when the total has not forgotten
+// its past.  Every workgroup still ARRIVES at both barriers (the fallback and the log-likelihood sum count on it); nobody waits
+// for the slowest of 256 workgroups unless the data asks for it.  Waits go left in phase 2 and right in phase 3, each on a
+// flag set before its owner's own wait: no cycle.  Equality with the epoch: flags are never reset.
+__device__ __forceinline__ bool res_wait_epoch(const int* f, int want, int* status) {
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) {
+            atomicOr(status, 2);
+            return false;
+        }
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,10 +602,11 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) pub_store(a.spine + (long)tile * NF + i, v[i]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pub_store(ra.flags1 + tile, ra.epoch);
+            res_arrive(ra.bar, tile);
         }
     }
-    res_grid_barrier(ra.bar, tile, a.nblocks, 1, a.status);
-    PGPS_RSTAMP(3);
+    // (the wait: below, where the carry is taken -- for the left neighbour alone when its total has forgotten its past)
 
     // ---------------------------------------------------------------------------------------------
     // phase 2: carry in, Kalman pass, smoothing elements in place
@@ -591,7 +616,15 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
     for (int i = 0; i < D; ++i) s.m[i] = T(0);
 #pragma unroll
     for (int i = 0; i < SYM; ++i) s.P[i] = P0[i];
+    bool waited_all = false;
     if (tile > 0) {
+        if (a.shortcut != 0) {
+            if (threadIdx.x == 0) res_wait_epoch(ra.flags1 + tile - 1, ra.epoch, a.status);
+            __syncthreads();
+        } else {
+            res_wait_all(ra.bar, a.nblocks, 1, a.status);
+            waited_all = true;
+        }
         // The forgetting shortcut.  The carry into this tile is the prefix T_0 (x) ... (x) T_{tile-1} applied to the prior; in
         // ANY bracketing its (b, C) are those of the last total whenever that total's A vanishes: out.b = A_2 w + b_2,
         // out.C = A_2 N A_2^T + C_2 (parallel.py:100-118).  A total over 4096 steps of a filter that forgets (|A| shrinks by a
@@ -617,6 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
 #pragma unroll
             for (int i = 0; i < SYM; ++i) s.P[i] = nb.C[i];
         } else {
+            if (!waited_all) res_wait_all(ra.bar, a.nblocks, 1, a.status);     // every total to the left is needed
             FE mine, left;
             filt_identity(mine);
             if ((int)threadIdx.x < tile) {
@@ -630,6 +664,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
             filt_apply(s, left);
         }
     }
+    PGPS_RSTAMP(3);
     filt_apply(s, excl);
     PGPS_RSTAMP(4);
 
@@ -769,10 +804,10 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
             for (int i = 0; i < NS; ++i) pub_store(a.sspine + (long)tile * NS + i, vv[i]);
             pub_store(a.llpart + tile, t);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pub_store(ra.flags2 + tile, ra.epoch);
+            res_arrive(ra.bar, tile);
         }
     }
-    res_grid_barrier(ra.bar, tile, a.nblocks, 2, a.status);
-    PGPS_RSTAMP(7);
 
     // ---------------------------------------------------------------------------------------------
     // phase 3: carry back, smoothing pass over the kept elements
@@ -781,7 +816,15 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
     for (int i = 0; i < D; ++i) s.m[i] = T(0);
 #pragma unroll
     for (int i = 0; i < SYM; ++i) s.P[i] = T(0);
+    waited_all = false;
     if (tile + 1 < a.nblocks) {
+        if (a.shortcut != 0) {
+            if (threadIdx.x == 0) res_wait_epoch(ra.flags2 + tile + 1, ra.epoch, a.status);
+            __syncthreads();
+        } else {
+            res_wait_all(ra.bar, a.nblocks, 2, a.status);
+            waited_all = true;
+        }
         // the same shortcut backwards: a smoothing total whose E vanishes (the product of 4096 smoother gains) hands the tile
         // before it its own (g, L), whatever follows (parallel.py:176-184: E = E_a E_b, g = E_a g_b + g_a, L = E_a L_b E_a^T + L_a)
         SE nb;
@@ -801,6 +844,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
 #pragma unroll
             for (int i = 0; i < SYM; ++i) s.P[i] = nb.L[i];
         } else {
+            if (!waited_all) { res_wait_all(ra.bar, a.nblocks, 2, a.status); waited_all = true; }
             SE mine, right;
             smth_identity(mine);
             const int b = tile + 1 + (int)threadIdx.x;
@@ -816,9 +860,11 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
             smth_apply(right, s);
         }
     }
+    PGPS_RSTAMP(7);
     smth_apply(sexcl, s);
     PGPS_RSTAMP(8);
     if (tile == 0 && a.ll != nullptr) {
+        if (!waited_all) res_wait_all(ra.bar, a.nblocks, 2, a.status);         // every workgroup's partial is out
         double v = 0.0;
         for (int b = threadIdx.x; b < a.nblocks; b += kBlock) v += pub_load(a.llpart + b);
         const double t = block_sum_double(v, lds_ll);
