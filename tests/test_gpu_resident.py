@@ -191,7 +191,7 @@ def test_resident_automatic_choice_and_its_limits(ctx):
     ll = ctx.malloc(8)
     try:
         ctx.call("pgps_pkfs_dev_f64", ctypes.c_long(n), ctypes.c_int(2), bufs["P0"], bufs["Fs"], bufs["Qs"], bufs["H"],
-                 ctypes.c_double(float(R)), ctypes.c_void_p(bufs["ys"] + 8), outs["fms"], outs["fPs"], outs["sms"], outs["sPs"], ll)
+                 ctypes.c_double(float(np.asarray(R).reshape(-1)[0])), ctypes.c_void_p(bufs["ys"] + 8), outs["fms"], outs["fPs"], outs["sms"], outs["sPs"], ll)
         sms = np.empty((n, 2))
         ctx.d2h(sms, outs["sms"])
         sm_o, _ = O.kfs(ssm, y)
@@ -224,7 +224,7 @@ def test_resident_hand_offs_under_back_to_back_launches(ctx):
 
     def run():
         ctx.call("pgps_pkfs_dev_f64", ctypes.c_long(n), ctypes.c_int(2), dev["P0"], dev["Fs"], dev["Qs"], dev["H"],
-                 ctypes.c_double(float(R)), dev["ys"], outs["fms"], outs["fPs"], outs["sms"], outs["sPs"], ll_d)
+                 ctypes.c_double(float(np.asarray(R).reshape(-1)[0])), dev["ys"], outs["fms"], outs["fPs"], outs["sms"], outs["sPs"], ll_d)
         sms = np.empty((n, 2))
         llv = np.empty(1)
         ctx.d2h(sms, outs["sms"])

@@ -28,6 +28,7 @@ say stamps;              python tools/res_check.py --time > $O/resident_phase_st
 say small n latency;      python tools/small_n_latency.py > $O/small_n_latency.txt 2>&1
 say grad cost;            python tools/grad_cost.py > $O/grad_cost.txt 2>&1
 say probe ab;            bash tools/r05_probe_ab.sh > $O/probe_ab.txt 2>&1
+say d6 crossover;        bash tools/r05_d6_crossover.sh > $O/d6_crossover.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for cfg in "c2:" "c3:--kernel rbf6 --dtype f32" "c5:--kernel c5"; do
   name=${cfg%%:*}; args=${cfg#*:}

@@ -81,7 +81,7 @@ def timing(ctx, sde, form):
     from ctypes import c_long, c_int, c_double
 
     def run_array():
-        ctx.call("pgps_pkfs_dev_f64", c_long(n), c_int(2), dev["P0"], dev["Fs"], dev["Qs"], dev["H"], c_double(float(R)), dev["ys"],
+        ctx.call("pgps_pkfs_dev_f64", c_long(n), c_int(2), dev["P0"], dev["Fs"], dev["Qs"], dev["H"], c_double(float(np.asarray(R).reshape(-1)[0])), dev["ys"],
                  dev["fms"], dev["fPs"], dev["sms"], dev["sPs"], dev["ll"])
 
     def run_fused():
