@@ -501,12 +501,14 @@ static int choose_family(const pgps_ctx* ctx, int d, long N, Mode mode) {
         // row-cooperative family in fp32: its own instantiations (16-lane rows, v_fmac_f32_dpp), every mode; automatic
         // above the lane-chunk kernels' range (at d = 6 those still win in fp32: 0.71 against 0.85 ms at 2^20 steps)
         bool to_rc = rc_ok && (ctx->family == 3 || ((ctx->family == 0 || ctx->family == 4) && d > PGPS_MAX_DIM_LANE));
-        // d = 6, whole-series filter / filter + smoother: the quad-cooperative kernels are ahead of the lane-chunk ones
-        // except where the latter's geometry fits the chip exactly (same box, ms per pass, lane-chunk / quad:
-        // 2^14 0.212 / 0.171, 2^16 0.218 / 0.192, 2^17 0.230 / 0.218, 2^18 0.286 / 0.261, 2^19 0.395 / 0.398,
-        // 2^20 0.627 / 0.650, 2^21 1.266 / 1.217, 2^22 2.566 / 2.357)
+        // d = 6, whole-series filter / filter + smoother: the quad-cooperative kernels are ahead of the lane-chunk ones on
+        // short series; from 2^19 steps the lane-chunk kernels' workgroups span >= 2048 steps and take their carries by the
+        // forgetting shortcut (round 5), which put them ahead at every longer size (same box, ms per pass, lane-chunk / quad,
+        // profiles/r05_d6_crossover.txt: 2^14 0.177 / 0.128, 2^16 0.191 / 0.146, 2^17 0.202 / 0.182, 2^18 0.245 / 0.222,
+        // 2^19 0.258 / 0.354, 2^20 0.549 / 0.628, 2^21 1.042 / 1.163, 2^22 2.039 / 2.204; round 4, without the shortcut:
+        // 2^19 0.395 / 0.398, 2^20 0.627 / 0.650, 2^21 1.266 / 1.217, 2^22 2.566 / 2.357)
         if (ctx->family == 0 && d == 6 && (mode == MODE_PKF || mode == MODE_PKFS) && ctx->chunk == 0 && ctx->stage_g < 0 &&
-            (N <= (3L << 17) || N >= (3L << 19)) && N >= 64)
+            N <= (3L << 17) && N >= 64)
             to_rc = true;
         // quad-cooperative level-1 kernels under the row-cooperative driver: family 4 (fp32, 5 <= d <= 8)
         if (ctx->family == 4) {
