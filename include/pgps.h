@@ -74,7 +74,9 @@ int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
  * pgps_gp_dev_f64 / pgps_gp_f64 when smoothed moments are asked for.  Fs, Qs, ys are read once and every output is
  * written once (the reference's pkf + pks contract, pssgp/kalman/parallel.py:121-201); the launch needs every workgroup
  * resident, so another stream's kernel holding compute units makes it give up (bounded spins) with bit 1 of
- * pgps_status set and undefined outputs.  mode -1 = automatic (from 2^18 steps), 0 = never (three launches),
+ * pgps_status set and undefined outputs.  A call made while the stream is being captured into a hipGraph takes the three
+ * launches (the resident launch's barrier set and hand-off epoch are per-launch host state: a replay would reuse them).
+ * mode -1 = automatic (from 2^18 steps), 0 = never (three launches),
  * 1 = wherever the series fits, 2 = as 1 with in-kernel phase stamps kept for pgps_resident_stamps (diagnostics). */
 int pgps_set_resident(pgps_ctx* ctx, int mode);
 /* The forgetting shortcut of the lane-chunk and resident kernels (csrc/pgps_kernels.hip.h): a workgroup whose neighbour's total

@@ -445,6 +445,11 @@ bool resident_fits(const pgps_ctx* ctx, long N, int d, bool f32) {
     if (ctx->chunk > 0 || ctx->block != 0 || ctx->stage_g >= 0 || ctx->single_pass > 0 || ctx->dma > 0) return false;   // a pinned geometry or variant of the three-launch path was asked for
     if (ctx->family != 0 && ctx->family != 1) return false;
     if (N > (long)kBlock * kResLc * ctx->n_cu) return false;
+    // not while the stream is being captured: the launch's barrier set and hand-off epoch are chosen per launch on the host,
+    // and a replayed graph would present the same ones again (counters already at their targets, flags already equal)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (cs != hipStreamCaptureStatusNone) return false;
     return ctx->resident > 0 || N >= kResAutoMin;
 }
 }  // namespace pgps

@@ -345,3 +345,25 @@ def test_forgetting_shortcut_on_the_fused_road_and_in_float32(ctx):
         ctx.set_f32_policy(0)
     for a_, b_ in zip(out[1][:4], out[0][:4]):
         assert np.array_equal(a_, b_)
+
+
+def test_resident_launch_is_not_taken_under_stream_capture(ctx):
+    """The launch's barrier set and hand-off epoch are per-launch host state: a call made while its stream is captured into a
+    graph takes the three launches (a replay would present the same epoch again)."""
+    import torch
+    dev = torch.device("cuda:0")
+    s = torch.cuda.Stream(device=dev)
+    ctx.set_resident(1)
+    ctx.set_stream(s.cuda_stream)
+    try:
+        assert ctx.get_family(1 << 19, 2) == PGPS_FAMILY_RESIDENT
+        g = torch.cuda.CUDAGraph()
+        x = torch.zeros(16, device=dev)
+        with torch.cuda.graph(g, stream=s):
+            inside = ctx.get_family(1 << 19, 2)
+            x += 1.0
+        assert inside != PGPS_FAMILY_RESIDENT
+        assert ctx.get_family(1 << 19, 2) == PGPS_FAMILY_RESIDENT
+    finally:
+        torch.cuda.synchronize()
+        ctx.use_own_stream()
