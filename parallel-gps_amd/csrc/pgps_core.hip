@@ -442,9 +442,12 @@ namespace pgps {
 constexpr long kResAutoMin = 1L << 18;
 bool resident_fits(const pgps_ctx* ctx, long N, int d, bool f32) {
     if (f32 || d != 2 || ctx->resident == 0 || ctx->n_cu <= 0) return false;
-    if (ctx->chunk > 0 || ctx->block != 0 || ctx->stage_g >= 0 || ctx->single_pass > 0 || ctx->dma > 0) return false;   // a pinned geometry or variant of the three-launch path was asked for
+    // a pinned geometry or variant of the three-launch path was asked for (a chunk of 8 or 16 together with mode >= 1 pins the
+    // resident launch's own steps per lane instead: tests, A/B)
+    const bool own_chunk = ctx->resident > 0 && (ctx->chunk == 8 || ctx->chunk == 16);
+    if ((ctx->chunk > 0 && !own_chunk) || ctx->block != 0 || ctx->stage_g >= 0 || ctx->single_pass > 0 || ctx->dma > 0) return false;
     if (ctx->family != 0 && ctx->family != 1) return false;
-    if (N > (long)kBlock * kResLc * ctx->n_cu) return false;
+    if (N > (long)kBlock * (own_chunk ? ctx->chunk : kResLc) * ctx->n_cu) return false;
     // not while the stream is being captured: the launch's barrier set and hand-off epoch are chosen per launch on the host,
     // and a replayed graph would present the same ones again (counters already at their targets, flags already equal)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

@@ -12,13 +12,18 @@ template <typename T, int D>
 int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ScanArgs<T>& a = ra.s;
-    a.Lc = kResLc;
-    a.nblocks = (int)((a.N + (long)kBlock * kResLc - 1) / ((long)kBlock * kResLc));
+    // steps per lane: 16 (4096 per workgroup) -- or 8 where the whole series then still fits the chip: twice the workgroups
+    // for series of up to 2048 steps per CU, which at 16 would leave half of the CUs idle (2^19 steps: 39 -> 30 us)
+    int lc = kResLc;
+    if (ctx->resident > 0 && (ctx->chunk == 8 || ctx->chunk == 16)) lc = ctx->chunk;
+    else if (a.N <= (long)kBlock * 8 * ctx->n_cu) lc = 8;
+    a.Lc = lc;
+    a.nblocks = (int)((a.N + (long)kBlock * lc - 1) / ((long)kBlock * lc));
     if (a.nblocks < 1 || a.nblocks > ctx->n_cu) return PGPS_E_INVALID;      // every workgroup must be resident
     a.nlanes = (long)a.nblocks * kBlock;
     a.seg_first = 1;
     a.seg_last = 1;
-    a.shortcut = ctx->shortcut != 0 ? 1 : 0;        // (a workgroup spans 4096 steps)
+    a.shortcut = ctx->shortcut != 0 ? 1 : 0;        // (a workgroup spans 2048 or 4096 steps; the test is on the data either way)
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t nb = (size_t)a.nblocks;
     size_t off = 0;
@@ -48,8 +53,13 @@ int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused) {
         ctx->res_stamp_blocks = a.nblocks;
     }
     const dim3 grid(a.nblocks), block(kBlock);
-    if (fused) timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, kResLc, true>, grid, block, 0, ra);
-    else timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, kResLc, false>, grid, block, 0, ra);
+    if (lc == 8) {
+        if (fused) timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, 8, true>, grid, block, 0, ra);
+        else timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, 8, false>, grid, block, 0, ra);
+    } else {
+        if (fused) timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, kResLc, true>, grid, block, 0, ra);
+        else timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, kResLc, false>, grid, block, 0, ra);
+    }
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }

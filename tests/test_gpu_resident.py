@@ -367,3 +367,27 @@ def test_resident_launch_is_not_taken_under_stream_capture(ctx):
     finally:
         torch.cuda.synchronize()
         ctx.use_own_stream()
+
+
+@pytest.mark.parametrize("chunk,n", [(8, 4096 + 5), (16, 4096 + 5), (8, (1 << 17) + 123), (16, (1 << 17) + 123), (0, 1 << 18), (8, 1 << 19)])
+def test_resident_launch_with_eight_and_sixteen_steps_per_lane(ctx, chunk, n):
+    """The launch exists with 16 steps per lane and -- for series that then still fit the chip -- with 8 (twice the
+    workgroups); chunk 8 / 16 under mode 1 pins one of them, 0 lets the library choose.  Every output against the three
+    launches on the same inputs."""
+    B = _B()
+    sde = _m32(ls=0.7).get_sde()
+    t = make_times(n, seed=n % 1000)
+    Fs, Qs = B.discretise(sde.F, sde.P0, t, 0.0)
+    ssm = (sde.P0, Fs, Qs, sde.H, np.array([[0.1]]))
+    y = sample_series_fast(ssm, seed=3, nan_frac=0.1)
+    ctx.set_resident(1)
+    ctx.set_chunk(chunk)
+    try:
+        assert ctx.get_family(n, 2) == PGPS_FAMILY_RESIDENT
+        got = B.pkfs(ssm, y, return_filtered=True, return_loglikelihood=True)
+    finally:
+        ctx.set_chunk(0)
+    ctx.set_resident(0)
+    want = B.pkfs(ssm, y, return_filtered=True, return_loglikelihood=True)
+    for g, w in zip(got, want):
+        assert relerr(g, w) < 1e-11
