@@ -391,3 +391,40 @@ def test_resident_launch_with_eight_and_sixteen_steps_per_lane(ctx, chunk, n):
     want = B.pkfs(ssm, y, return_filtered=True, return_loglikelihood=True)
     for g, w in zip(got, want):
         assert relerr(g, w) < 1e-11
+
+
+@pytest.mark.parametrize("n,chunk,seed", [(1 << 18, 8, 1), ((1 << 19) - 7, 16, 2), ((1 << 19) + 4097, 0, 3), (1 << 20, 0, 4)])
+def test_resident_hand_offs_when_some_workgroups_remember_and_others_forget(ctx, n, chunk, seed):
+    """A time grid with stretches a million times denser than the rest: the workgroups inside them hand on totals that have
+    NOT forgotten their past (general fold behind the grid-wide wait), the others take their carry from one neighbour -- both
+    roads and both kinds of wait inside one launch, twice back to back (another epoch), against the three launches with the
+    shortcut off (tools/res_stress.py runs many more of these)."""
+    B = _B()
+    rng = np.random.default_rng(seed)
+    sde = _m32(ls=1.0).get_sde()
+    dt = 0.05 * rng.uniform(0.5, 1.5, n)
+    for _ in range(3):
+        a = int(rng.integers(0, n))
+        dt[a:a + int(rng.integers(3000, 30000))] *= 1e-6
+    t = np.cumsum(dt)
+    Fs, Qs = B.discretise(sde.F, sde.P0, t, 0.0)
+    y = np.sin(0.7 * t) + 0.3 * rng.standard_normal(n)
+    y[n // 3: n // 3 + 5000] = np.nan
+    ssm = (sde.P0, Fs, Qs, sde.H, np.array([[0.1]]))
+    ctx.set_resident(0)
+    ctx.set_shortcut(0)
+    try:
+        want = B.pkfs(ssm, y, return_filtered=True, return_loglikelihood=True)
+    finally:
+        ctx.set_shortcut(1)
+    ctx.set_resident(1)
+    ctx.set_chunk(chunk)
+    try:
+        assert ctx.get_family(n, 2) == PGPS_FAMILY_RESIDENT
+        got = B.pkfs(ssm, y, return_filtered=True, return_loglikelihood=True)
+        again = B.pkfs(ssm, y, return_filtered=True, return_loglikelihood=True)
+    finally:
+        ctx.set_chunk(0)
+    for g, w, g2 in zip(got, want, again):
+        assert relerr(g, w) < 1e-9
+        assert np.array_equal(np.asarray(g), np.asarray(g2), equal_nan=True)
