@@ -450,10 +450,10 @@ bool resident_fits(const pgps_ctx* ctx, long N, int d, bool f32) {
     if (N > (long)kBlock * (own_chunk ? ctx->chunk : kResLc) * ctx->n_cu) return false;
     // not while the stream is being captured: the launch's barrier set and hand-off epoch are chosen per launch on the host,
     // and a replayed graph would present the same ones again (counters already at their targets, flags already equal)
+    if (!(ctx->resident > 0 || N >= kResAutoMin)) return false;         // (before the query below: short series never pay for it)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (cs != hipStreamCaptureStatusNone) return false;
-    return ctx->resident > 0 || N >= kResAutoMin;
+    return cs == hipStreamCaptureStatusNone;
 }
 }  // namespace pgps
 
