@@ -71,7 +71,8 @@ int pgps_set_chunk(pgps_ctx* ctx, int steps_per_lane);
 int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
 /* Filter + log-likelihood + smoother of a whole series in ONE resident launch (csrc/pgps_resident.hip.h): fp64, d = 2,
  * series of up to 4096 steps per compute unit (2^20 on MI355X); taken by pgps_pkfs_dev_f64 / pgps_pkfs_f64 and by
- * pgps_gp_dev_f64 / pgps_gp_f64 when smoothed moments are asked for.  Fs, Qs, ys are read once and every output is
+ * pgps_gp_dev_f64 / pgps_gp_f64, and -- in its filter-only form, without the smoothing phase -- by pgps_pkf_dev_f64 /
+ * pgps_pkf_f64 and by pgps_gp_* calls that ask for no smoothed moments.  Fs, Qs, ys are read once and every output is
  * written once (the reference's pkf + pks contract, pssgp/kalman/parallel.py:121-201); the launch needs every workgroup
  * resident, so another stream's kernel holding compute units makes it give up (bounded spins) with bit 1 of
  * pgps_status set and undefined outputs.  A call made while the stream is being captured into a hipGraph takes the three

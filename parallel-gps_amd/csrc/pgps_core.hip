@@ -532,7 +532,7 @@ static int choose_family(const pgps_ctx* ctx, int d, long N, Mode mode) {
     }
     if constexpr (sizeof(T) == 8) {
         // filter + smoother of a whole series that fits the chip: one resident launch (pgps_resident.hip.h)
-        if (mode == MODE_PKFS && resident_fits(ctx, N, d, false)) return PGPS_FAMILY_RESIDENT;
+        if ((mode == MODE_PKFS || mode == MODE_PKF) && resident_fits(ctx, N, d, false)) return PGPS_FAMILY_RESIDENT;
         // row-cooperative family: fp64, d <= 16, whole-series filter / filter+smoother
         const bool whole = mode == MODE_PKF || mode == MODE_PKFS || mode == MODE_PKS;
         // automatic choice from d = 5: at d = 6 the lane-chunk kernels spill (2^18 steps: 1.29 ms against 0.53 ms);
@@ -564,7 +564,7 @@ static int dispatch_scan(pgps_ctx* ctx, int d, const ScanArgs<T>& a, Mode mode) 
             if (aligned16(a.ys)) {
                 ResArgs<double> ra{};
                 ra.s = a;
-                return launch_resident<double, 2>(ctx, ra, false);
+                return launch_resident<double, 2>(ctx, ra, false, mode == MODE_PKFS);
             }
             fam = lane_narrow(ctx, d, a.N) ? PGPS_FAMILY_LANE_NARROW : PGPS_FAMILY_LANE;      // (a misaligned ys: three launches)
         }
@@ -1271,11 +1271,11 @@ static int gp_dev(pgps_ctx* ctx, long N, int d, double lam, const double* N1, co
     g.m.ts = ts;
     g.m.t_prev = (T)t0;
     if constexpr (sizeof(T) == 8) {
-        if (sms != nullptr && resident_fits(ctx, N, d, false) && aligned16(ts) && aligned16(ys)) {
+        if (resident_fits(ctx, N, d, false) && aligned16(ts) && aligned16(ys)) {
             ResArgs<double> ra{};
             ra.s = g.s;
             ra.m = g.m;
-            return launch_resident<double, 2>(ctx, ra, true);
+            return launch_resident<double, 2>(ctx, ra, true, sms != nullptr);
         }
     }
     switch (d) {

@@ -224,7 +224,7 @@ constexpr int kResFlagWord = 1024;          // two arrays of 256 per-workgroup h
 // does a whole-series filter + smoother call of N steps at dimension d (fp64 when !f32) take the resident launch?
 bool resident_fits(const pgps_ctx* ctx, long N, int d, bool f32);
 template <typename T, int D>
-int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused);
+int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused, bool smooth);
 // log-likelihood and the model's adjoints on the fused path (pgps_gpadj.hip.h), fp64, d <= 3: out = 1 + d^2 + 2 d + 1 doubles [device]
 // (T names the unit that holds the instantiation: call it with T = double)
 template <typename T, int D>

@@ -9,7 +9,7 @@
 namespace pgps {
 
 template <typename T, int D>
-int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused) {
+int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused, bool smooth) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ScanArgs<T>& a = ra.s;
     // steps per lane: 16 (4096 per workgroup) -- or 8 where the whole series then still fits the chip: twice the workgroups
@@ -53,17 +53,19 @@ int launch_resident(pgps_ctx* ctx, ResArgs<T> ra, bool fused) {
         ctx->res_stamp_blocks = a.nblocks;
     }
     const dim3 grid(a.nblocks), block(kBlock);
-    if (lc == 8) {
-        if (fused) timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, 8, true>, grid, block, 0, ra);
-        else timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, 8, false>, grid, block, 0, ra);
-    } else {
-        if (fused) timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, kResLc, true>, grid, block, 0, ra);
-        else timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, kResLc, false>, grid, block, 0, ra);
-    }
+    auto go = [&](auto lcv, auto fusedv, auto smoothv) {
+        timed_launch(ctx, PGPS_K_RESIDENT, k_pkfs_resident<T, D, decltype(lcv)::value, decltype(fusedv)::value, decltype(smoothv)::value>,
+                     grid, block, 0, ra);
+    };
+    auto pick = [&](auto lcv) {
+        if (fused) { if (smooth) go(lcv, std::true_type{}, std::true_type{}); else go(lcv, std::true_type{}, std::false_type{}); }
+        else { if (smooth) go(lcv, std::false_type{}, std::true_type{}); else go(lcv, std::false_type{}, std::false_type{}); }
+    };
+    if (lc == 8) pick(std::integral_constant<int, 8>{}); else pick(std::integral_constant<int, kResLc>{});
     HIPCHK(ctx, hipGetLastError());
     return PGPS_OK;
 }
 
-template int launch_resident<PGPS_RES_T, PGPS_RES_D>(pgps_ctx*, ResArgs<PGPS_RES_T>, bool);
+template int launch_resident<PGPS_RES_T, PGPS_RES_D>(pgps_ctx*, ResArgs<PGPS_RES_T>, bool, bool);
 
 }  // namespace pgps

@@ -439,7 +439,9 @@ struct ResLaneValues {
     }
 };
 
-template <typename T, int D, int LC, bool FUSED>
+// SMOOTH = false: the filter alone (pkf: filtered moments and / or the log-likelihood) -- phases 1 and 2 without the smoothing
+// elements, one hand-off; the series still stays on chip between the reduce and the Kalman pass, i.e. Fs, Qs, ys are read once.
+template <typename T, int D, int LC, bool FUSED, bool SMOOTH = true>
 __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
     using CFG = ResCfg<T, D, LC>;
     using GF = typename CFG::GF;
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
     T Fh[MAT], Qh[MAT];
     T Qn[MAT];
     load_rec<T, MAT>(myrec, Qn);
-    {
+    if constexpr (SMOOTH) {
 #pragma unroll
         for (int i = 0; i < MAT; ++i) {
             Fh[i] = wshfl_down(Freg[0][i], 1);
@@ -736,18 +738,20 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
 #else
                 res_kf_step(s, Freg[j], Q, yreg[j], h, Rn, ll, mp, Pp, FP);
 #endif
-                // element of step j - 1: E, g take the registers F_{j-1}, y_{j-1} have left; L waits for its slot
-                SE e, r;
-                element(k0 + j, prev, mp, Pp, FP, e);
-                smth_combine(sagg, e, r);
-                sagg = r;
+                if constexpr (SMOOTH) {
+                    // element of step j - 1: E, g take the registers F_{j-1}, y_{j-1} have left; L waits for its slot
+                    SE e, r;
+                    element(k0 + j, prev, mp, Pp, FP, e);
+                    smth_combine(sagg, e, r);
+                    sagg = r;
 #pragma unroll
-                for (int q = 0; q < MAT; ++q) Freg[j - 1][q] = e.E[q];
-                yreg[j - 1] = e.g[D - 1];
+                    for (int q = 0; q < MAT; ++q) Freg[j - 1][q] = e.E[q];
+                    yreg[j - 1] = e.g[D - 1];
 #pragma unroll
-                for (int q = 0; q < MAT; ++q) {
-                    const T x = q < SYM ? e.L[q < SYM ? q : 0] : e.g[q < SYM ? 0 : q - SYM];
-                    if (i == 0) Lhold[q] = x; else Lnew[i - 1][q] = x;
+                    for (int q = 0; q < MAT; ++q) {
+                        const T x = q < SYM ? e.L[q < SYM ? q : 0] : e.g[q < SYM ? 0 : q - SYM];
+                        if (i == 0) Lhold[q] = x; else Lnew[i - 1][q] = x;
+                    }
                 }
             }
             // filtered moments of step j: P into the slot Q_j has left, m into the staging buffer
@@ -765,10 +769,32 @@ __global__ __launch_bounds__(kBlock) void k_pkfs_resident(const ResArgs<T> ra) {
             res_drain_m<GM, PM>(gM, sb, limM, full, mst);
         }
         res_wave_sync();
-        // L of steps 4 sb - 1 .. 4 sb + 2 into their slots (drained above; LDS keeps a wave's accesses in order)
-        if (sb > 0) store_rec<T, MAT>(myrec + (sb * G - 1) * MAT, Lhold);
+        if constexpr (SMOOTH) {
+            // L of steps 4 sb - 1 .. 4 sb + 2 into their slots (drained above; LDS keeps a wave's accesses in order)
+            if (sb > 0) store_rec<T, MAT>(myrec + (sb * G - 1) * MAT, Lhold);
 #pragma unroll
-        for (int i = 0; i + 1 < G; ++i) store_rec<T, MAT>(myrec + (sb * G + i) * MAT, Lnew[i]);
+            for (int i = 0; i + 1 < G; ++i) store_rec<T, MAT>(myrec + (sb * G + i) * MAT, Lnew[i]);
+        }
+    }
+    if constexpr (!SMOOTH) {
+        // the filter alone: the workgroup's log-likelihood partial out, one arrival; workgroup 0 sums when everyone has arrived
+        PGPS_RSTAMP(5);
+        const double v = ll.value();
+        const double t = block_sum_double(v, lds_ll);
+        if (threadIdx.x == 0) {
+            pub_store(a.llpart + tile, t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            res_arrive(ra.bar, tile);
+        }
+        if (tile == 0 && a.ll != nullptr) {
+            res_wait_all(ra.bar, a.nblocks, 2, a.status);
+            double w = 0.0;
+            for (int b = threadIdx.x; b < a.nblocks; b += kBlock) w += pub_load(a.llpart + b);
+            const double tt = block_sum_double(w, lds_ll);
+            if (threadIdx.x == 0) *a.ll = tt;
+        }
+        PGPS_RSTAMP(9);
+        return;
     }
     {
         // element of the chunk's last step from the step after the chunk

@@ -54,6 +54,12 @@ def _fused_all(sde, t, y, r):
     return dict(fms=out["fms"], fPs=out["fPs"], sms=out["sms"], sPs=out["sPs"], ll=np.array([float(out["ll"])]))
 
 
+def _fused_ll(sde, t, y, r, filtered=False):
+    B = _B()
+    out = B.gp(B.nilpotent_form(sde.F), sde.P0, np.asarray(sde.H).reshape(-1), r, t, y, want_filtered=filtered)
+    return (float(out["ll"]), out["fms"], out["fPs"]) if filtered else float(out["ll"])
+
+
 def _check(got, want, tol=TOL64):
     for name in want:
         e = relerr(got[name], want[name])
@@ -167,7 +173,7 @@ def test_resident_automatic_choice_and_its_limits(ctx):
     assert ctx.get_family((1 << 20) + 1, 2) != PGPS_FAMILY_RESIDENT           # 257 workgroups do not fit 256 CUs
     assert ctx.get_family(1 << 19, 3) != PGPS_FAMILY_RESIDENT
     assert ctx.get_family(1 << 19, 2, f32=True) != PGPS_FAMILY_RESIDENT
-    assert ctx.get_family(1 << 19, 2, what=0) != PGPS_FAMILY_RESIDENT         # pkf
+    assert ctx.get_family(1 << 19, 2, what=0) == PGPS_FAMILY_RESIDENT         # pkf: the filter-only form of the launch
     assert ctx.get_family(1 << 19, 2, what=1) != PGPS_FAMILY_RESIDENT         # pks
     ctx.set_chunk(8)
     try:
@@ -428,3 +434,31 @@ def test_resident_hand_offs_when_some_workgroups_remember_and_others_forget(ctx,
     for g, w, g2 in zip(got, want, again):
         assert relerr(g, w) < 1e-9
         assert np.array_equal(np.asarray(g), np.asarray(g2), equal_nan=True)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 4096, 4097, (1 << 16) + 5, (1 << 19) - 3, (1 << 19) + 4097, 1 << 20])
+def test_resident_filter_alone_matches_the_three_launches(ctx, n):
+    """pkf (filtered moments + log-likelihood) and the fused log-likelihood through the filter-only form of the resident launch
+    (phases 1 and 2, one hand-off) against the three-launch kernels, and at small sizes against the oracle."""
+    B = _B()
+    sde = _m32(ls=0.8).get_sde()
+    t = make_times(n, seed=n % 997)
+    Fs, Qs = B.discretise(sde.F, sde.P0, t, 0.0)
+    ssm = (sde.P0, Fs, Qs, sde.H, np.array([[0.1]]))
+    y = sample_series_fast(ssm, seed=7, nan_frac=0.1 if n > 8 else 0.0)
+    ctx.set_resident(1)
+    assert ctx.get_family(n, 2, what=0) == PGPS_FAMILY_RESIDENT
+    fm, fP, ll = B.pkf(ssm, y, return_loglikelihood=True)
+    ll_fused = _fused_ll(sde, t, y, 0.1)
+    llf2, ffm, ffP = _fused_ll(sde, t, y, 0.1, filtered=True)
+    assert llf2 == ll_fused and relerr(ffm, fm) < 1e-9 and relerr(ffP, fP) < 1e-9
+    ctx.set_resident(0)
+    fm0, fP0, ll0 = B.pkf(ssm, y, return_loglikelihood=True)
+    ll_fused0 = _fused_ll(sde, t, y, 0.1)
+    assert relerr(fm, fm0) < 1e-11 and relerr(fP, fP0) < 1e-11
+    assert abs(float(ll) - float(ll0)) <= 1e-11 * max(1.0, abs(float(ll0)))
+    assert abs(ll_fused - ll_fused0) <= 1e-11 * max(1.0, abs(ll_fused0))
+    assert abs(ll_fused - float(ll)) <= 1e-9 * max(1.0, abs(float(ll)))
+    if n <= 4097:
+        of, oP, oll = O.kf(ssm, y, True)
+        assert relerr(fm, of) < 1e-10 and relerr(fP, oP) < 1e-10 and abs(float(ll) - oll) <= 1e-10 * max(1.0, abs(oll))
