@@ -79,7 +79,7 @@ int pgps_set_single_pass(pgps_ctx* ctx, int mode, int window);
  * launches (the resident launch's barrier set and hand-off epoch are per-launch host state: a replay would reuse them).
  * Series of up to 2048 steps per compute unit run it with 8 steps per lane (twice the workgroups), longer ones with 16;
  * pgps_set_chunk(ctx, 8 or 16) under mode >= 1 pins that choice (any other pinned chunk selects the three launches).
- * mode -1 = automatic (from 2^18 steps), 0 = never (three launches),
+ * mode -1 = automatic (from 2^17 steps), 0 = never (three launches),
  * 1 = wherever the series fits, 2 = as 1 with in-kernel phase stamps kept for pgps_resident_stamps (diagnostics). */
 int pgps_set_resident(pgps_ctx* ctx, int mode);
 /* The forgetting shortcut of the lane-chunk and resident kernels (csrc/pgps_kernels.hip.h): a workgroup whose neighbour's total

@@ -439,7 +439,7 @@ namespace pgps {
 // The resident launch (pgps_resident.hip.h) serves whole-series filter + smoother calls at d = 2 in fp64 whose
 // 256 x 16-step workgroups are all resident at once (one per CU); automatic from kResAutoMin steps, where the scan's
 // streaming outweighs the two grid barriers (below that the narrow build's smaller chunks cover more of the chip).
-constexpr long kResAutoMin = 1L << 18;
+constexpr long kResAutoMin = 1L << 17;       // (2^17 steps: 26.9 against 28.8 us on three launches; equal at 2^16: profiles/r05_experiments.txt item 12)
 bool resident_fits(const pgps_ctx* ctx, long N, int d, bool f32) {
     if (f32 || d != 2 || ctx->resident == 0 || ctx->n_cu <= 0) return false;
     // a pinned geometry or variant of the three-launch path was asked for (a chunk of 8 or 16 together with mode >= 1 pins the

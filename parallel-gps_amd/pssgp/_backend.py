@@ -204,7 +204,7 @@ class Context:
             check(self, self.lib.pgps_set_dma(self.handle, int(mode)), "pgps_set_dma")
 
     def set_resident(self, mode):
-        """Filter + smoother in ONE resident launch (fp64, d = 2, up to 4096 steps per CU): -1 automatic (from 2^18 steps),
+        """Filter + smoother in ONE resident launch (fp64, d = 2, up to 4096 steps per CU): -1 automatic (from 2^17 steps),
         0 never, 1 wherever the series fits, 2 = 1 + in-kernel phase stamps (pgps_set_resident)."""
         if hasattr(self.lib, "pgps_set_resident"):
             check(self, self.lib.pgps_set_resident(self.handle, int(mode)), "pgps_set_resident")

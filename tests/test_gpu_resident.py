@@ -163,12 +163,12 @@ def test_resident_full_size_against_c_oracle(ctx):
 
 
 def test_resident_automatic_choice_and_its_limits(ctx):
-    """Automatic from 2^18 steps, never beyond 4096 steps per CU, never for other dimensions / float32 / pinned geometries /
+    """Automatic from 2^17 steps, never beyond 4096 steps per CU, never for other dimensions / float32 / pinned geometries /
     filter-only or smoother-only calls; a misaligned observation array takes the three launches and still answers."""
     B = _B()
     ctx.set_resident(-1)
-    assert ctx.get_family((1 << 18) - 1, 2) != PGPS_FAMILY_RESIDENT
-    assert ctx.get_family(1 << 18, 2) == PGPS_FAMILY_RESIDENT
+    assert ctx.get_family((1 << 17) - 1, 2) != PGPS_FAMILY_RESIDENT
+    assert ctx.get_family(1 << 17, 2) == PGPS_FAMILY_RESIDENT
     assert ctx.get_family(1 << 20, 2) == PGPS_FAMILY_RESIDENT
     assert ctx.get_family((1 << 20) + 1, 2) != PGPS_FAMILY_RESIDENT           # 257 workgroups do not fit 256 CUs
     assert ctx.get_family(1 << 19, 3) != PGPS_FAMILY_RESIDENT
