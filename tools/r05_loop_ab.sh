@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the round-5 staged-loop order (no load in flight across the back edge; packed float32 algebra) against the
-# library as it was before (libpgps_nopk.so = the old loops, scalar float32), interleaved; one line per run.
+# library as it was before (libpgps_nopk.so = the old loops, scalar float32), interleaved; one line per run.  The rewritten
+# loops were NOT kept (profiles/r05_experiments.txt item 9): this script documents how profiles/r05_loop_ab.txt was made.
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 A=$R/parallel-gps_amd/pssgp/libpgps_nopk.so

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the packed float32 algebra (round 5): libpgps_nopk.so (-DPGPS_PK_F32=0 on the float32 lane-chunk units) against
-# the shipped library, interleaved; one line per run.
+# the shipped library, interleaved; one line per run.  The variant:
+#   make -C parallel-gps_amd/csrc variant NAME=nopk UNIT="inst_f32_2 ... inst_f32_6 instn_f32_2 ... instn_f32_6" EXTRA=-DPGPS_PK_F32=0
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 A=$R/parallel-gps_amd/pssgp/libpgps_nopk.so
